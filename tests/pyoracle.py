@@ -1,0 +1,171 @@
+"""Second, independent oracle for the C++ oracle -- TEST INFRASTRUCTURE ONLY.
+
+The reference has no tests or golden vectors for this path ("parity unpinned"), so the C++
+restatement in oracle/ is pinned by this vectorised numpy/torch statement of the same
+mathematics written from the equations, not from the C++ oracle:
+torch.float64 forward, torch.autograd for the 7-gradient.  Follows
+include/vlcal/costs/nid_cost.hpp:36-107 and src/vlcal/calib/cost_calculator_nid.cpp:21-67.
+"""
+import numpy as np
+import torch
+
+from direct_visual_lidar_calibration_amd import camera_models
+
+_C = torch.tensor(
+    [[1.0, -3.0, 3.0, -1.0], [4.0, 0.0, -6.0, 3.0], [1.0, 3.0, 3.0, -3.0], [0.0, 0.0, 0.0, 1.0]],
+    dtype=torch.float64,
+) / 6.0
+
+
+def _transform(se3, p):
+    v, w, t = se3[0:3], se3[3], se3[4:7]
+    uv = 2.0 * torch.cross(v.expand_as(p), p, dim=-1)
+    return p + w * uv + torch.cross(v.expand_as(p), uv, dim=-1) + t
+
+
+def nid_cost(model, intrinsics, distortion, image_f64, points, intensities, bins, se3, want_grad=True):
+    """Returns dict(ok, cost, grad, hist (raw, [bin_image][bin_points]), hist_image, hist_points)."""
+    img = torch.as_tensor(np.ascontiguousarray(image_f64), dtype=torch.float64)
+    H, W = img.shape
+    P = torch.as_tensor(np.ascontiguousarray(points)[:, :3], dtype=torch.float64)
+    inten = torch.as_tensor(np.ascontiguousarray(intensities), dtype=torch.float64)
+    x = torch.tensor(np.asarray(se3, dtype=np.float64), requires_grad=want_grad)
+    B = int(bins)
+
+    with torch.no_grad():
+        uv0 = camera_models.project(model, intrinsics, distortion, _transform(x.detach(), P))
+        k0 = torch.floor(uv0)
+        inl = (k0[:, 0] >= 0) & (k0[:, 0] < W) & (k0[:, 1] >= 0) & (k0[:, 1] < H)  # NaN -> False
+    idx = torch.nonzero(inl).flatten()
+    Pi = P[idx]
+    bin_pts = torch.clamp((inten[idx] * B).to(torch.int64), 0, B - 1)
+
+    uv = camera_models.project(model, intrinsics, distortion, _transform(x, Pi))
+    knot = torch.floor(uv.detach())
+    s = uv - knot
+    kx = knot[:, 0].to(torch.int64)
+    ky = knot[:, 1].to(torch.int64)
+
+    ones = torch.ones_like(s[:, 0])
+    se_x = torch.stack([ones, s[:, 0], s[:, 0] ** 2, s[:, 0] ** 3], 0)  # (4, n)
+    se_y = torch.stack([ones, s[:, 1], s[:, 1] ** 2, s[:, 1] ** 3], 0)
+    bx = _C @ se_x
+    by = _C @ se_y
+
+    hist = torch.zeros(B * B, dtype=torch.float64)
+    hist_image = torch.zeros(B, dtype=torch.float64)
+    for a in range(4):
+        xa = torch.clamp(kx - 1 + a, 0, W - 1)
+        for b in range(4):
+            yb = torch.clamp(ky - 1 + b, 0, H - 1)
+            w = bx[a] * by[b]
+            pix = img[yb, xa]
+            bin_img = torch.clamp((pix * B).to(torch.int64), max=B - 1)
+            hist = hist.index_add(0, bin_img * B + bin_pts, w)
+            hist_image = hist_image.index_add(0, bin_img, w)
+    hist_points = torch.bincount(bin_pts, minlength=B).to(torch.float64)
+
+    S = hist_points.sum()
+    pj = hist / S
+    pi = hist_image / S
+    pp = hist_points / S
+    Hi = -(pi * torch.log(pi + 1e-6)).sum()
+    Hp = -(pp * torch.log(pp + 1e-6)).sum()
+    Hj = -(pj * torch.log(pj + 1e-6)).sum()
+    MI = Hi + Hp - Hj
+    nid = (Hj - MI) / Hj
+    ok = bool(torch.isfinite(nid))
+    grad = None
+    if want_grad and ok:
+        (g,) = torch.autograd.grad(nid, x)
+        grad = g.numpy().copy()
+    return dict(
+        ok=ok,
+        cost=float(nid),
+        grad=grad,
+        hist=hist.detach().reshape(B, B).numpy().copy(),
+        hist_image=hist_image.detach().numpy().copy(),
+        hist_points=hist_points.numpy().copy(),
+        num_inliers=int(idx.numel()),
+    )
+
+
+def cost_calculator_nid(model, intrinsics, distortion, image_u8, points, intensities, bins, max_fov, T):
+    """CostCalculatorNID::calculate: FoV gate, truncating cast, nearest pixel, integer histogram."""
+    img = torch.as_tensor(np.ascontiguousarray(image_u8).astype(np.int64))
+    H, W = img.shape
+    T = torch.as_tensor(np.asarray(T, dtype=np.float64).reshape(4, 4))
+    P = torch.as_tensor(np.ascontiguousarray(points), dtype=torch.float64)
+    inten = torch.as_tensor(np.ascontiguousarray(intensities), dtype=torch.float64)
+    B = int(bins)
+    pc = (P @ T.T)[:, :3]
+    n = torch.sqrt((pc * pc).sum(-1))
+    zn = torch.where(n > 0, pc[:, 2] / torch.where(n > 0, n, torch.ones_like(n)), pc[:, 2])
+    in_fov = ~(zn < np.cos(max_fov))
+    uv = camera_models.project(model, intrinsics, distortion, pc)
+    ok = torch.isfinite(uv).all(-1) & (uv.abs() < 2.0**31).all(-1)
+    t = torch.trunc(torch.where(ok.unsqueeze(-1), uv, torch.full_like(uv, -5.0)))
+    inl = in_fov & ok & (t[:, 0] >= 0) & (t[:, 0] < W) & (t[:, 1] >= 0) & (t[:, 1] < H)
+    idx = torch.nonzero(inl).flatten()
+    px = t[idx, 0].to(torch.int64)
+    py = t[idx, 1].to(torch.int64)
+    pixel = img[py, px].to(torch.float64) / 255.0
+    image_bin = torch.clamp((pixel * B).to(torch.int64), 0, B - 1)
+    lidar_bin = torch.clamp((inten[idx] * B).to(torch.int64), 0, B - 1)
+    hist = torch.bincount(image_bin * B + lidar_bin, minlength=B * B).reshape(B, B)
+    hi = hist.sum(1).to(torch.float64)
+    hp = hist.sum(0).to(torch.float64)
+    S = hi.sum()
+    pr, ps, prs = hi / S, hp / S, hist.to(torch.float64) / S
+    Hr = -(pr * torch.log(pr + 1e-6)).sum()
+    Hs = -(ps * torch.log(ps + 1e-6)).sum()
+    Hrs = -(prs * torch.log(prs + 1e-6)).sum()
+    MI = Hr + Hs - Hrs
+    return float((Hrs - MI) / Hrs), hist.numpy().copy()
+
+
+def reverse_mode_gradient(model, intrinsics, distortion, image_f64, points, intensities, bins, se3):
+    """The factorisation the GPU path uses: G = dNID/dh from the histogram, then
+    grad = sum_points sum_taps G[b_tap, bin_pts] * d(w_tap)/d(theta).  Evaluated here with torch so
+    the identity itself is tested on the CPU, independent of the HIP kernels."""
+    r = nid_cost(model, intrinsics, distortion, image_f64, points, intensities, bins, se3, want_grad=False)
+    B = int(bins)
+    S = r["hist_points"].sum()
+    pj = r["hist"] / S
+    pi = r["hist_image"] / S
+    pp = r["hist_points"] / S
+    eps = 1e-6
+    Hi = -(pi * np.log(pi + eps)).sum()
+    Hp = -(pp * np.log(pp + eps)).sum()
+    Hj = -(pj * np.log(pj + eps)).sum()
+    phi = lambda p: np.log(p + eps) + p / (p + eps)  # noqa: E731
+    G = (-(Hi + Hp) / Hj**2 * phi(pj) + phi(pi)[:, None] / Hj) / S  # [bin_image][bin_points]
+
+    img = torch.as_tensor(np.ascontiguousarray(image_f64), dtype=torch.float64)
+    H, W = img.shape
+    P = torch.as_tensor(np.ascontiguousarray(points)[:, :3], dtype=torch.float64)
+    inten = torch.as_tensor(np.ascontiguousarray(intensities), dtype=torch.float64)
+    x = torch.tensor(np.asarray(se3, dtype=np.float64), requires_grad=True)
+    with torch.no_grad():
+        uv0 = camera_models.project(model, intrinsics, distortion, _transform(x.detach(), P))
+        k0 = torch.floor(uv0)
+        inl = (k0[:, 0] >= 0) & (k0[:, 0] < W) & (k0[:, 1] >= 0) & (k0[:, 1] < H)
+    idx = torch.nonzero(inl).flatten()
+    bin_pts = torch.clamp((inten[idx] * B).to(torch.int64), 0, B - 1)
+    uv = camera_models.project(model, intrinsics, distortion, _transform(x, P[idx]))
+    knot = torch.floor(uv.detach())
+    s = uv - knot
+    kx, ky = knot[:, 0].to(torch.int64), knot[:, 1].to(torch.int64)
+    ones = torch.ones_like(s[:, 0])
+    bx = _C @ torch.stack([ones, s[:, 0], s[:, 0] ** 2, s[:, 0] ** 3], 0)
+    by = _C @ torch.stack([ones, s[:, 1], s[:, 1] ** 2, s[:, 1] ** 3], 0)
+    Gt = torch.as_tensor(G)
+    total = torch.zeros((), dtype=torch.float64)
+    for a in range(4):
+        xa = torch.clamp(kx - 1 + a, 0, W - 1)
+        for b in range(4):
+            yb = torch.clamp(ky - 1 + b, 0, H - 1)
+            bin_img = torch.clamp((img[yb, xa] * B).to(torch.int64), max=B - 1)
+            total = total + (Gt[bin_img, bin_pts] * bx[a] * by[b]).sum()
+    (g,) = torch.autograd.grad(total, x)
+    return g.numpy().copy(), G
