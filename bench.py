@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py -- NID cost+Jacobian evaluations per second on MI355X (BASELINE.json metric).
+
+A "step" is ONE synchronous evaluation of the hot path -- NIDCost::operator()<Jet<double,7>>, i.e.
+cost + 7-gradient -- over one LiDAR-camera pair at a distinct pose (7 doubles in, 8 doubles out,
+host sync), with the cloud and image already resident in HBM.  Workload at N=1 = BASELINE.json
+configs[1]: 1 pair, 10M-point Ouster-style synthetic cloud + 1920x1080 pinhole, 256 x 256 bins.
+
+N>1 (one process per GPU, launched by torch.distributed.run):
+  --mode pairs  (default) one independent pair per GPU (configs[3] style), no data-path collective,
+                value = pair-evaluations/s over all ranks, scaling "weak";
+  --mode shard  one pair, points sharded over the ranks, RCCL all-reduce of the fixed-point
+                histogram and of the 7-gradient partial per evaluation (configs[2]/[4]), "strong".
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed on the kernel's own
+stream) and `cpu_baseline` (the oracle timed on the host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def algorithmic_bytes(n_points, width, height, bins):
+    """16 B per point (one float32 x,y,z,intensity PLY record) counted once, the
+    8-bit image once, the scalar histogram once, params/outputs."""
+    return 16 * n_points + width * height + 8 * (bins * bins + 2 * bins) + 64
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--points", type=int, default=10_000_000)
+    ap.add_argument("--camera", default="pinhole_1080p")
+    ap.add_argument("--bins", type=int, default=256)
+    ap.add_argument("--precision", default=os.environ.get("NIDREG_BENCH_PRECISION", "fp64"))
+    ap.add_argument("--mode", default="pairs", choices=["pairs", "shard"])
+    ap.add_argument("--columns-per-group", type=int, default=0)
+    ap.add_argument("--target-blocks", type=int, default=0)
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="points of the workload the CPU oracle is timed on (0 = skip)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the NID core)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from direct_visual_lidar_calibration_amd import nid, synth
+
+    # ---- workload (synthetic, seeded; generated on the GPU, then handed over as host arrays like
+    # the reference's Frame / cv::Mat would be)
+    t0 = time.time()
+    if args.mode == "pairs":
+        seed = 20250523 + 2 + rank  # config id 2, a different pair per rank
+        scene = synth.make_scene(args.camera, num_points=args.points, seed=seed, device=f"cuda:{local_rank}")
+        pts, ints = scene.points, scene.intensities
+    else:
+        scene = synth.make_scene(args.camera, num_points=args.points, seed=20250523 + 2, device=f"cuda:{local_rank}")
+        lo = args.points * rank // world
+        hi = args.points * (rank + 1) // world
+        pts, ints = scene.points[lo:hi], scene.intensities[lo:hi]
+    t_gen = time.time() - t0
+    proj = nid.create_camera(scene.model, scene.intrinsics, scene.distortion)
+
+    t0 = time.time()
+    tuning = dict(columns_per_group=args.columns_per_group, target_blocks=args.target_blocks)
+    if args.mode == "shard" and world > 1:
+        from direct_visual_lidar_calibration_amd import parallel
+
+        cost = parallel.ShardedNIDCost(proj, scene.image_f64, pts, ints, args.bins, device=local_rank, precision=args.precision, **tuning)
+    else:
+        cost = nid.NIDCost(proj, scene.image_f64, pts, ints, args.bins, device=local_rank, precision=args.precision, **tuning)
+    t_setup = time.time() - t0
+
+    rng = np.random.default_rng(1234)  # same pose sequence on every rank
+    poses = [synth.random_pose_near(scene.T_camera_lidar_true, rng) for _ in range(args.steps + args.warmup)]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        ok, c, g = cost(poses[k])
+        assert ok
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.warmup, args.warmup + args.steps):
+        ok, c, g = cost(poses[k])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    units = args.steps * (world if args.mode == "pairs" else 1)
+    value = units / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    # ---- per-kernel timing with HIP events on the handle's own stream (extra, untimed evaluations)
+    inner = cost.inner if hasattr(cost, "inner") else cost
+    roof = None
+    if rank == 0 and hasattr(inner, "set_timing") and not hasattr(cost, "inner"):
+        inner.set_timing(True)
+        acc = {}
+        reps = max(10, min(args.steps, 30))
+        for k in range(reps):
+            inner(poses[k % len(poses)])
+            tm = inner.timing_ms()
+            for key, v in tm.items():
+                acc.setdefault(key, []).append(v)
+        inner.set_timing(False)
+        kt = {key: float(np.mean(v)) for key, v in acc.items()}
+        n_local = pts.shape[0]
+        dom = "k_spline_hist" if kt["hist"] >= kt["grad"] else "k_spline_grad"
+        dom_ms = max(kt["hist"], kt["grad"])
+        # algorithmic bytes ONE launch of the dominant kernel moves: 16 B/point + the 8-bit image +
+        # the B x B 64-bit histogram tile traffic (written by pass A, read by pass B)
+        launch_bytes = 16 * n_local + scene.width * scene.height + 8 * args.bins * args.bins
+        achieved = launch_bytes / (dom_ms * 1e-3) / 1e9
+        eval_bytes = algorithmic_bytes(n_local, scene.width, scene.height, args.bins)
+        roof = {
+            "bound": "hbm",
+            "kernel": dom,
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": None,
+            "launch_bytes": launch_bytes,
+            "kernel_ms": {k_: round(v, 4) for k_, v in kt.items()},
+            "eval_bytes": eval_bytes,
+            "eval_achieved_GBs": round(eval_bytes / (kt["total"] * 1e-3) / 1e9, 1),
+            "eval_frac": round(eval_bytes / (kt["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        }
+
+    # ---- CPU baseline: the oracle (faithful restatement, 1 core, Jet<7>) on a bounded sample
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_sample > 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib  # test infrastructure, used here only as the timed CPU baseline
+
+        ns = min(args.cpu_sample, pts.shape[0])
+        # every (N/ns)-th sweep-ordered point keeps the spatial / intensity distribution
+        sel = np.linspace(0, pts.shape[0] - 1, ns).astype(np.int64)
+        sp, si = np.ascontiguousarray(pts[sel]), np.ascontiguousarray(ints[sel])
+        img64 = scene.image_f64
+        ts = []
+        t_budget = time.time()
+        for k in range(5):
+            t1 = time.perf_counter()
+            r = oracle_lib.nid_cost(scene.model, scene.intrinsics, scene.distortion, img64, sp, si, args.bins, poses[k], want_grad=True, threads=1)
+            ts.append(time.perf_counter() - t1)
+            if time.time() - t_budget > 25.0:
+                break
+        t_med = float(np.median(ts))
+        scale = pts.shape[0] / ns
+        cpu = {
+            "value": round(1.0 / (t_med * scale), 6),
+            "unit": "evals/s",
+            "cores": 1,
+            "kind": "port",
+            "sample": f"{len(ts)} cost+Jacobian evals of the oracle (Jet<7>, serial loop like the reference) on {ns} of the {pts.shape[0]} points, "
+            f"median {t_med:.3f} s, scaled linearly x{scale:.1f}; host cpus={os.cpu_count()}",
+            "ns_per_point": round(1e9 * t_med / ns, 1),
+        }
+        # generous variant: same arithmetic, OpenMP over points on all host cores
+        nthr = oracle_lib.num_threads()
+        if nthr > 1:
+            t1 = time.perf_counter()
+            oracle_lib.nid_cost(scene.model, scene.intrinsics, scene.distortion, img64, sp, si, args.bins, poses[0], want_grad=True, threads=nthr)
+            tg = time.perf_counter() - t1
+            cpu["generous_value"] = round(1.0 / (tg * scale), 6)
+            cpu["generous_cores"] = nthr
+
+    if rank == 0:
+        info = inner.info() if hasattr(inner, "info") else {}
+        line = {
+            "metric": "NID cost+Jacobian evals/sec on 10M-pt cloud",
+            "value": round(value, 3),
+            "unit": "evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak" if args.mode == "pairs" else "strong",
+            "vs_baseline": None,
+            "dtype": "f64" if args.precision == "fp64" else "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{'1 pair per GPU' if args.mode == 'pairs' else '1 pair point-sharded'}, {args.points}-pt Ouster-style cloud + "
+                f"{scene.width}x{scene.height} {scene.model}, {args.bins}x{args.bins} NID bins, cost+Jacobian (BASELINE configs[1])",
+                "points": args.points,
+                "image": [scene.width, scene.height],
+                "bins": args.bins,
+                "camera_model": scene.model,
+                "mode": args.mode,
+                "accumulate": "u64 fixed point",
+                "layout": info,
+                "setup_s": round(t_setup, 3),
+                "datagen_s": round(t_gen, 3),
+            },
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        if cpu:
+            line["speedup_vs_cpu_port"] = round(value / cpu["value"], 1)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

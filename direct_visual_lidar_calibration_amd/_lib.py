@@ -1,0 +1,107 @@
+"""ctypes loader for csrc/libnidreg.so (the C ABI of include/nidreg.h).
+
+There is no Python or CPU fallback: if the HIP library is missing or no GPU is usable, loading /
+handle creation raises.  Build it with ``__graft_entry__.build()`` (``make -C csrc``).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC_DIR = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC_DIR, "libnidreg.so")
+
+NIDREG_OK = 0
+NIDREG_FALSE = 1
+NIDREG_OUT_DOUBLES = 16
+
+MODE_SPLINE, MODE_NEAREST = 0, 1
+PREC_FP64, PREC_FP32 = 0, 1
+IMAGE_F64, IMAGE_U8 = 0, 1
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_int64_p = ctypes.POINTER(ctypes.c_int64)
+c_float_p = ctypes.POINTER(ctypes.c_float)
+
+
+class NidregDesc(ctypes.Structure):
+    _fields_ = [
+        ("struct_size", ctypes.c_int32),
+        ("device_id", ctypes.c_int32),
+        ("model_id", ctypes.c_int32),
+        ("mode", ctypes.c_int32),
+        ("precision", ctypes.c_int32),
+        ("bins", ctypes.c_int32),
+        ("intrinsics", ctypes.c_double * 5),
+        ("distortion", ctypes.c_double * 8),
+        ("width", ctypes.c_int32),
+        ("height", ctypes.c_int32),
+        ("image_dtype", ctypes.c_int32),
+        ("reserved0", ctypes.c_int32),
+        ("image", ctypes.c_void_p),
+        ("image_row_stride", ctypes.c_int64),
+        ("num_points", ctypes.c_int64),
+        ("points", ctypes.c_void_p),
+        ("point_stride", ctypes.c_int64),
+        ("intensities", ctypes.c_void_p),
+        ("max_fov", ctypes.c_double),
+        ("columns_per_group", ctypes.c_int32),
+        ("target_blocks", ctypes.c_int32),
+        ("ext_stream", ctypes.c_void_p),
+        ("ext_hist", ctypes.c_void_p),
+        ("ext_out", ctypes.c_void_p),
+    ]
+
+
+EXPORTS = [
+    "nidreg_model_from_name", "nidreg_device_count", "nidreg_create", "nidreg_destroy", "nidreg_eval", "nidreg_eval_iso", "nidreg_eval_multi",
+    "nidreg_eval_iso_multi", "nidreg_get_hist", "nidreg_get_hist_fixed", "nidreg_project", "nidreg_project_model", "nidreg_hist_words", "nidreg_shard_hist",
+    "nidreg_shard_entropy", "nidreg_shard_grad", "nidreg_shard_finish", "nidreg_set_timing", "nidreg_get_timing", "nidreg_get_info", "nidreg_last_error",
+    "nidreg_version",
+]
+
+_lib = None
+
+
+def load():
+    """Load libnidreg.so.  Raises (loudly) when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: the NID core has no CPU fallback; run __graft_entry__.build() (make -C {CSRC_DIR})")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.nidreg_last_error.restype = ctypes.c_char_p
+    lib.nidreg_version.restype = ctypes.c_char_p
+    lib.nidreg_hist_words.restype = ctypes.c_int64
+    lib.nidreg_hist_words.argtypes = [ctypes.c_int]
+    lib.nidreg_destroy.restype = None
+    lib.nidreg_destroy.argtypes = [ctypes.c_void_p]
+    lib.nidreg_create.argtypes = [ctypes.POINTER(NidregDesc), ctypes.POINTER(ctypes.c_void_p)]
+    lib.nidreg_eval.argtypes = [ctypes.c_void_p, c_double_p, c_double_p, c_double_p]
+    lib.nidreg_eval_iso.argtypes = [ctypes.c_void_p, c_double_p, c_double_p]
+    lib.nidreg_eval_multi.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, c_double_p, c_double_p, c_double_p, c_double_p]
+    lib.nidreg_eval_iso_multi.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, c_double_p, c_double_p]
+    lib.nidreg_get_hist.argtypes = [ctypes.c_void_p, c_double_p, c_double_p, c_double_p]
+    lib.nidreg_get_hist_fixed.argtypes = [ctypes.c_void_p, c_int64_p, c_int64_p, ctypes.POINTER(ctypes.c_int)]
+    lib.nidreg_project.argtypes = [ctypes.c_void_p, c_double_p, ctypes.c_int64, c_double_p, c_double_p]
+    lib.nidreg_project_model.argtypes = [ctypes.c_int, c_double_p, c_double_p, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_int64, c_double_p, c_double_p]
+    lib.nidreg_shard_hist.argtypes = [ctypes.c_void_p, c_double_p]
+    lib.nidreg_shard_entropy.argtypes = [ctypes.c_void_p]
+    lib.nidreg_shard_grad.argtypes = [ctypes.c_void_p]
+    lib.nidreg_shard_finish.argtypes = [ctypes.c_void_p, c_double_p, c_double_p]
+    lib.nidreg_set_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.nidreg_get_timing.argtypes = [ctypes.c_void_p, c_float_p]
+    lib.nidreg_get_info.argtypes = [ctypes.c_void_p, c_int64_p]
+    lib.nidreg_model_from_name.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().nidreg_last_error().decode()
+
+
+def check(rc, what):
+    if rc < 0:
+        raise RuntimeError(f"{what} failed ({rc}): {last_error()}")
+    return rc

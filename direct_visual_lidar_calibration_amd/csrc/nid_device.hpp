@@ -1,0 +1,303 @@
+// nid_device.hpp -- device-side building blocks of the NID registration kernels (gfx950 / CDNA4).
+//
+// What the reference computes per point per evaluation (include/vlcal/costs/nid_cost.hpp:46-84,
+// src/vlcal/calib/cost_calculator_nid.cpp:30-52) is re-designed here as a gather/reduce pipeline:
+//   * points are pre-bucketed by their pose-independent histogram column (bin_points), so a
+//     workgroup owns a small tile of the joint histogram in LDS and never touches global atomics
+//     inside the point loop;
+//   * weights are accumulated as 64-bit FIXED-POINT integers (ds_add_u64), which makes the
+//     histogram independent of thread order, workgroup count and GPU count (bit-reproducible,
+//     all-reducible as int64);
+//   * the Jacobian is obtained in reverse mode: dNID/dh (a B x B table) from the finished
+//     histogram, then one more streaming pass that contracts it with d(weight)/d(pose); no
+//     8-wide Jet histogram is ever formed;
+//   * camera models are template parameters (one kernel instantiation per model), written once
+//     for T = real (value) and T = Dual3<real> (value + d/d(x,y,z)).
+// No MFMA: nothing here is a dense contraction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nidreg {
+
+typedef unsigned long long u64;
+
+// ------------------------------------------------------------------------------------------
+// scalar helpers for float / double
+__device__ __forceinline__ float m_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double m_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float m_atan2(float y, float x) { return atan2f(y, x); }
+__device__ __forceinline__ double m_atan2(double y, double x) { return atan2(y, x); }
+__device__ __forceinline__ float m_asin(float x) { return asinf(x); }
+__device__ __forceinline__ double m_asin(double x) { return asin(x); }
+__device__ __forceinline__ float m_atan(float x) { return atanf(x); }
+__device__ __forceinline__ double m_atan(double x) { return atan(x); }
+__device__ __forceinline__ float m_abs(float x) { return fabsf(x); }
+__device__ __forceinline__ double m_abs(double x) { return fabs(x); }
+__device__ __forceinline__ float m_floor(float x) { return floorf(x); }
+__device__ __forceinline__ double m_floor(double x) { return floor(x); }
+__device__ __forceinline__ float m_val(float x) { return x; }
+__device__ __forceinline__ double m_val(double x) { return x; }
+
+// ------------------------------------------------------------------------------------------
+// forward-mode dual number with three partials (d/dx, d/dy, d/dz of the camera-frame point).
+// Same chain rules as the reference's ceres::Jet arithmetic, three slots instead of seven: the
+// remaining 3x7 factor d(p_cam)/d(pose) is linear in the LiDAR point and is folded into a
+// 3x3 + 3 accumulator (see k_spline_grad).
+template <typename real>
+struct Dual3 {
+  real a, d0, d1, d2;
+  __device__ __forceinline__ Dual3() {}
+  __device__ __forceinline__ Dual3(real v) : a(v), d0(0), d1(0), d2(0) {}
+  __device__ __forceinline__ Dual3(real v, real x, real y, real z) : a(v), d0(x), d1(y), d2(z) {}
+};
+
+template <typename real>
+__device__ __forceinline__ real m_val(const Dual3<real>& x) { return x.a; }
+
+#define NID_D Dual3<real>
+template <typename real> __device__ __forceinline__ NID_D operator+(const NID_D& f, const NID_D& g) { return NID_D(f.a + g.a, f.d0 + g.d0, f.d1 + g.d1, f.d2 + g.d2); }
+template <typename real> __device__ __forceinline__ NID_D operator+(const NID_D& f, real s) { return NID_D(f.a + s, f.d0, f.d1, f.d2); }
+template <typename real> __device__ __forceinline__ NID_D operator+(real s, const NID_D& f) { return NID_D(s + f.a, f.d0, f.d1, f.d2); }
+template <typename real> __device__ __forceinline__ NID_D operator-(const NID_D& f, const NID_D& g) { return NID_D(f.a - g.a, f.d0 - g.d0, f.d1 - g.d1, f.d2 - g.d2); }
+template <typename real> __device__ __forceinline__ NID_D operator-(const NID_D& f, real s) { return NID_D(f.a - s, f.d0, f.d1, f.d2); }
+template <typename real> __device__ __forceinline__ NID_D operator-(real s, const NID_D& f) { return NID_D(s - f.a, -f.d0, -f.d1, -f.d2); }
+template <typename real> __device__ __forceinline__ NID_D operator-(const NID_D& f) { return NID_D(-f.a, -f.d0, -f.d1, -f.d2); }
+template <typename real> __device__ __forceinline__ NID_D operator*(const NID_D& f, const NID_D& g) {
+  return NID_D(f.a * g.a, f.a * g.d0 + f.d0 * g.a, f.a * g.d1 + f.d1 * g.a, f.a * g.d2 + f.d2 * g.a);
+}
+template <typename real> __device__ __forceinline__ NID_D operator*(const NID_D& f, real s) { return NID_D(f.a * s, f.d0 * s, f.d1 * s, f.d2 * s); }
+template <typename real> __device__ __forceinline__ NID_D operator*(real s, const NID_D& f) { return NID_D(f.a * s, f.d0 * s, f.d1 * s, f.d2 * s); }
+template <typename real> __device__ __forceinline__ NID_D operator/(const NID_D& f, const NID_D& g) {
+  const real gi = real(1) / g.a;
+  const real q = f.a * gi;
+  return NID_D(q, (f.d0 - q * g.d0) * gi, (f.d1 - q * g.d1) * gi, (f.d2 - q * g.d2) * gi);
+}
+template <typename real> __device__ __forceinline__ NID_D operator/(const NID_D& f, real s) {
+  const real si = real(1) / s;
+  return NID_D(f.a * si, f.d0 * si, f.d1 * si, f.d2 * si);
+}
+template <typename real> __device__ __forceinline__ bool operator<(const NID_D& f, real s) { return f.a < s; }
+template <typename real> __device__ __forceinline__ bool operator>(const NID_D& f, real s) { return f.a > s; }
+template <typename real> __device__ __forceinline__ NID_D m_sqrt(const NID_D& f) {
+  const real t = m_sqrt(f.a);
+  const real k = real(1) / (real(2) * t);
+  return NID_D(t, f.d0 * k, f.d1 * k, f.d2 * k);
+}
+template <typename real> __device__ __forceinline__ NID_D m_atan2(const NID_D& g, const NID_D& f) {
+  const real k = real(1) / (f.a * f.a + g.a * g.a);
+  return NID_D(m_atan2(g.a, f.a), k * (-g.a * f.d0 + f.a * g.d0), k * (-g.a * f.d1 + f.a * g.d1), k * (-g.a * f.d2 + f.a * g.d2));
+}
+template <typename real> __device__ __forceinline__ NID_D m_asin(const NID_D& f) {
+  const real k = real(1) / m_sqrt(real(1) - f.a * f.a);
+  return NID_D(m_asin(f.a), k * f.d0, k * f.d1, k * f.d2);
+}
+template <typename real> __device__ __forceinline__ NID_D m_atan(const NID_D& f) {
+  const real k = real(1) / (real(1) + f.a * f.a);
+  return NID_D(m_atan(f.a), k * f.d0, k * f.d1, k * f.d2);
+}
+template <typename real> __device__ __forceinline__ NID_D m_abs(const NID_D& f) {
+  const real s = f.a < real(0) ? real(-1) : real(1);
+  return NID_D(m_abs(f.a), s * f.d0, s * f.d1, s * f.d2);
+}
+#undef NID_D
+
+template <typename T> struct scalar_of { typedef T type; };
+template <typename real> struct scalar_of<Dual3<real> > { typedef real type; };
+
+// ------------------------------------------------------------------------------------------
+// kernel-argument PODs
+template <typename real>
+struct CamParams {
+  real intr[5];
+  real dist[8];
+};
+// p_cam = R p + t with R = I + 2 w [v]x + 2 [v]x^2 built on the host from the UN-normalised
+// quaternion exactly as Sophus' SO3 * point expands (nid_cost.hpp:47)
+template <typename real>
+struct PoseParams {
+  real R[9];
+  real t[3];
+};
+// rows 0..2 of a 4x4 row-major isometry (cost_calculator_nid.cpp:31)
+template <typename real>
+struct IsoParams {
+  real m[12];
+};
+
+enum { MODEL_PLUMB_BOB = 0, MODEL_FISHEYE = 1, MODEL_OMNIDIR = 2, MODEL_EQUIRECT = 3, MODEL_ATAN = 4, MODEL_RATIONAL = 5 };
+
+// ------------------------------------------------------------------------------------------
+// projection models (reference: include/camera/{pinhole,fisheye,omnidir,equirectangular,atan,
+// rational_polynomial}.hpp), T = real or Dual3<real>.
+template <int MODEL, typename T, typename real>
+__device__ __forceinline__ void project(const CamParams<real>& c, const T& x, const T& y, const T& z, T& u, T& v) {
+  if (MODEL == MODEL_PLUMB_BOB) {  // pinhole.hpp:13-51, distortion k1 k2 p1 p2 k3
+    const real k1 = c.dist[0], k2 = c.dist[1], p1 = c.dist[2], p2 = c.dist[3], k3 = c.dist[4];
+    const T px = x / z, py = y / z;
+    const T x2 = px * px, y2 = py * py;
+    const T r2 = x2 + y2;
+    const T r4 = r2 * r2;
+    const T r6 = r2 * r4;
+    const T rc = real(1) + k1 * r2 + k2 * r4 + k3 * r6;
+    const T t1 = real(2) * px * py;
+    const T t2 = r2 + real(2) * x2;
+    const T t3 = r2 + real(2) * y2;
+    const T dx = rc * px + p1 * t1 + p2 * t2;
+    const T dy = rc * py + p1 * t3 + p2 * t1;
+    u = c.intr[0] * dx + c.intr[2];
+    v = c.intr[1] * dy + c.intr[3];
+  } else if (MODEL == MODEL_FISHEYE) {  // fisheye.hpp:14-36 (abs(z) at :16)
+    const real k1 = c.dist[0], k2 = c.dist[1], k3 = c.dist[2], k4 = c.dist[3];
+    const T r = m_sqrt(x * x + y * y);
+    const T theta = m_atan2(r, m_abs(z));
+    const T th2 = theta * theta;
+    const T th4 = th2 * th2;
+    const T th6 = th4 * th2;
+    const T th8 = th4 * th4;
+    const T theta_d = theta * (real(1) + k1 * th2 + k2 * th4 + k3 * th6 + k4 * th8);
+    const T s = theta_d / r;
+    u = c.intr[0] * (s * x) + c.intr[2];
+    v = c.intr[1] * (s * y) + c.intr[3];
+  } else if (MODEL == MODEL_OMNIDIR) {  // omnidir.hpp:14-41
+    const real xi = c.intr[4];
+    const real k1 = c.dist[0], k2 = c.dist[1], p1 = c.dist[2], p2 = c.dist[3];
+    const T n2 = x * x + y * y + z * z;
+    T sx = x, sy = y, sz = z;
+    if (n2 > real(0)) {
+      const T n = m_sqrt(n2);
+      sx = x / n;
+      sy = y / n;
+      sz = z / n;
+    }
+    const T den = sz + xi;
+    const T ux = sx / den, uy = sy / den;
+    const T r2 = ux * ux + uy * uy;
+    const T r4 = r2 * r2;
+    const T dr = real(1) + k1 * r2 + k2 * r4;
+    const T x2 = ux * ux, y2 = uy * uy, xy = ux * uy;
+    const T nx = ux * dr + (real(2) * p1) * xy + p2 * (r2 + real(2) * x2);
+    const T ny = uy * dr + p1 * (r2 + real(2) * y2) + (real(2) * p2) * xy;
+    u = c.intr[0] * nx + c.intr[2];
+    v = c.intr[1] * ny + c.intr[3];
+  } else if (MODEL == MODEL_EQUIRECT) {  // equirectangular.hpp:14-28, intr = [W H]
+    const T n2 = x * x + y * y + z * z;
+    if (n2 < real(1e-3)) {
+      u = T(c.intr[0] / real(2));
+      v = T(c.intr[1] / real(2));
+    } else {
+      const T n = m_sqrt(n2);
+      const T bx = x / n, by = y / n, bz = z / n;
+      const T lat = -m_asin(by);
+      const T lon = m_atan2(bx, bz);
+      u = c.intr[0] * (real(0.5) + lon / real(2.0 * 3.14159265358979323846));
+      v = c.intr[1] * (real(0.5) - lat / real(3.14159265358979323846));
+    }
+  } else if (MODEL == MODEL_ATAN) {  // atan.hpp:14-39
+    const real d0 = c.dist[0];
+    const T px = x / z, py = y / z;
+    const T r = m_sqrt(px * px + py * py);
+    T dx = px, dy = py;
+    if (!(r < real(1e-3) || d0 < real(1e-7))) {
+      const real d1 = real(1) / d0;
+      const real d2 = real(2) * tan(d0 / real(2));
+      const T factor = d1 * m_atan(r * d2) / r;
+      dx = factor * px;
+      dy = factor * py;
+    }
+    u = c.intr[0] * dx + c.intr[2];
+    v = c.intr[1] * dy + c.intr[3];
+  } else {  // rational_polynomial.hpp:11-58, k1 k2 p1 p2 k3 k4 k5 k6
+    const real k1 = c.dist[0], k2 = c.dist[1], p1 = c.dist[2], p2 = c.dist[3];
+    const real k3 = c.dist[4], k4 = c.dist[5], k5 = c.dist[6], k6 = c.dist[7];
+    const T px = x / z, py = y / z;
+    const T x2 = px * px, y2 = py * py;
+    const T r2 = x2 + y2;
+    const T r4 = r2 * r2;
+    const T r6 = r2 * r4;
+    const T num = real(1) + k1 * r2 + k2 * r4 + k3 * r6;
+    const T den = real(1) + k4 * r2 + k5 * r4 + k6 * r6;
+    const T rc = den > real(1e-8) ? num / den : num;
+    const T t1 = real(2) * px * py;
+    const T t2 = r2 + real(2) * x2;
+    const T t3 = r2 + real(2) * y2;
+    const T dx = rc * px + p1 * t1 + p2 * t2;
+    const T dy = rc * py + p1 * t3 + p2 * t1;
+    u = c.intr[0] * dx + c.intr[2];
+    v = c.intr[1] * dy + c.intr[3];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// device point records (written once per handle by the host-side bucketing)
+struct Rec32 {  // 16 B: one PLY record (float xyz) + the pose-independent histogram column
+  float x, y, z;
+  uint32_t bin;
+};
+struct Rec64 {  // 32 B: used only when the caller's doubles do not round-trip through float
+  double x, y, z;
+  uint64_t bin;
+};
+
+template <typename real>
+__device__ __forceinline__ void load_rec(const Rec32* p, real& x, real& y, real& z, uint32_t& bin) {
+  const float4 v = *reinterpret_cast<const float4*>(p);  // one 16 B/lane coalesced load
+  x = real(v.x);
+  y = real(v.y);
+  z = real(v.z);
+  bin = __float_as_uint(v.w);
+}
+template <typename real>
+__device__ __forceinline__ void load_rec(const Rec64* p, real& x, real& y, real& z, uint32_t& bin) {
+  const double2 a = reinterpret_cast<const double2*>(p)[0];
+  const double2 b = reinterpret_cast<const double2*>(p)[1];
+  x = real(a.x);
+  y = real(a.y);
+  z = real(b.x);
+  bin = uint32_t(__double_as_longlong(b.y));
+}
+
+struct Chunk {  // one workgroup's slice of the bucketed cloud
+  uint32_t start;
+  uint32_t count;
+  uint32_t group;  // histogram columns [group*GW, (group+1)*GW)
+  uint32_t pad;
+};
+
+// uniform cubic B-spline basis, the reference's 4x4 coefficient matrix / 6 (nid_cost.hpp:29-33),
+// evaluated as C * [1 s s^2 s^3]^T in the same term order
+template <typename real>
+__device__ __forceinline__ void bspline(real s, real* b) {
+  const real s2 = s * s, s3 = s2 * s;
+  const real k16 = real(1.0 / 6.0), k36 = real(3.0 / 6.0), k46 = real(4.0 / 6.0), k66 = real(6.0 / 6.0);
+  b[0] = ((k16 - k36 * s) + k36 * s2) - k16 * s3;
+  b[1] = (k46 - k66 * s2) + k36 * s3;
+  b[2] = ((k16 + k36 * s) + k36 * s2) - k36 * s3;
+  b[3] = k16 * s3;
+}
+template <typename real>
+__device__ __forceinline__ void bspline_deriv(real s, real* d) {
+  const real s2 = s * s;
+  d[0] = (real(-0.5) + s) - real(0.5) * s2;
+  d[1] = real(-2) * s + real(1.5) * s2;
+  d[2] = (real(0.5) + s) - real(1.5) * s2;
+  d[3] = real(0.5) * s2;
+}
+
+// weight in [0,1] -> unsigned fixed point with `frac` fractional bits via the magic-constant
+// trick: magic = 2^(52-frac); the low mantissa bits of (w + magic) are round-to-nearest(w * 2^frac)
+__device__ __forceinline__ u64 to_fixed(double w, double magic) {
+  const double d = fmax(w, 0.0) + magic;
+  return u64(__double_as_longlong(d)) & 0x000FFFFFFFFFFFFFull;
+}
+
+// 4 consecutive bytes at an arbitrary byte address, as two aligned dword loads + funnel shift
+__device__ __forceinline__ uint32_t load_u8x4(const uint8_t* p) {
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~uintptr_t(3));
+  const uint32_t lo = q[0], hi = q[1];
+  const uint32_t sh = uint32_t(a & 3u) * 8u;
+  return uint32_t(((uint64_t(hi) << 32) | uint64_t(lo)) >> sh);
+}
+
+}  // namespace nidreg

@@ -1,0 +1,458 @@
+// nid_kernels.hpp -- the HIP kernels of the NID registration core (gfx950, wave64).
+//
+// Pipeline of one NIDCost evaluation (include/vlcal/costs/nid_cost.hpp:36-107 redesigned):
+//   memset(hist)                      B*B + tail 64-bit words
+//   k_spline_hist   <model,rec,real>  stream points once; LDS-tiled fixed-point joint histogram
+//   k_entropy_partial                 per column-group: sum p log(p+eps), row partials, column sums
+//   k_entropy_final                   H_image, H_points, H_joint -> NID, dNID/dh coefficients
+//   k_spline_grad   <model,rec,real>  stream points again; contract dNID/dh with d(weight)/d(p_cam),
+//                                     fold d(p_cam)/d(pose) into a 3x3 + 3 accumulator per workgroup
+//   k_grad_final                      reduce workgroup partials, chain to d/d[qx qy qz qw tx ty tz]
+// and of one CostCalculatorNID evaluation (src/vlcal/calib/cost_calculator_nid.cpp:21-67):
+//   memset(hist); k_nearest_hist; k_entropy_partial; k_entropy_final
+//
+// All kernels: 256 threads (4 waves of 64); dynamic LDS only, base 16-B aligned.
+#pragma once
+#include "nid_device.hpp"
+
+namespace nidreg {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+
+// tail words behind the B*B joint histogram
+constexpr int kTailInliers = 0;  // number of inlier points (plain count)
+constexpr int kTailWords = 8;
+
+// scalars written by k_entropy_final for k_spline_grad / the host
+struct EntropyScalars {
+  double nid;      // the cost
+  double S;        // inlier count
+  double coefA;    // -(Hi + Hp) / (Hj^2 * S)
+  double coefB;    // 1 / (Hj * S)
+  double Hi, Hp, Hj;
+  double status;   // 0 = finite, 1 = non-finite NID (functor returns false)
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// pass A (SPLINE): joint histogram with bicubic B-spline soft assignment.
+// LDS: tile[GW*B] u64 (this workgroup's GW histogram columns) + 1 u32 inlier counter.
+template <int MODEL, typename Rec, typename real>
+__global__ __launch_bounds__(kThreads) void k_spline_hist(
+  const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint8_t* __restrict__ img, int pitch, int W, int H, PoseParams<real> pose, CamParams<real> cam, int B,
+  int GW, double magic, u64* __restrict__ hist) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u64* tile = reinterpret_cast<u64*>(smem);
+  const int tile_n = GW * B;
+  unsigned int* s_inl = reinterpret_cast<unsigned int*>(tile + tile_n);
+
+  const int tid = threadIdx.x;
+  const Chunk ch = chunks[blockIdx.x];
+  for (int k = tid; k < tile_n; k += kThreads) tile[k] = 0;
+  if (tid == 0) *s_inl = 0;
+  __syncthreads();
+
+  const real fW = real(W), fH = real(H);
+  const uint32_t col0 = ch.group * uint32_t(GW);
+  unsigned int inl = 0;
+
+  for (uint32_t i = tid; i < ch.count; i += kThreads) {
+    real x, y, z;
+    uint32_t bin;
+    load_rec<real>(pts + ch.start + i, x, y, z, bin);
+    const real cx = ((pose.R[0] * x + pose.R[1] * y) + pose.R[2] * z) + pose.t[0];
+    const real cy = ((pose.R[3] * x + pose.R[4] * y) + pose.R[5] * z) + pose.t[1];
+    const real cz = ((pose.R[6] * x + pose.R[7] * y) + pose.R[8] * z) + pose.t[2];
+    real u, v;
+    project<MODEL, real, real>(cam, cx, cy, cz, u, v);
+    // floor(u) in [0,W) and floor(v) in [0,H); NaN / inf / overflow compare false -> outlier
+    // (the reference's int conversion sends those to INT_MIN, nid_cost.hpp:52-58)
+    const bool in = (u >= real(0)) && (u < fW) && (v >= real(0)) && (v < fH);
+    if (in) {
+      inl++;
+      const real fu = m_floor(u), fv = m_floor(v);
+      const int kx = int(fu), ky = int(fv);
+      real bx[4], by[4];
+      bspline<real>(u - fu, bx);
+      bspline<real>(v - fv, by);
+      u64* col = tile + (bin - col0) * uint32_t(B);
+      // padded bin image: tap (a,b) of knot (kx,ky) lives at [ky + b][kx + a] (edge-replicated,
+      // which is the reference's clamp of knots_x / knots_y, nid_cost.hpp:70-73)
+      const uint8_t* p0 = img + size_t(ky) * size_t(pitch) + size_t(kx);
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const uint32_t px4 = load_u8x4(p0 + size_t(b) * size_t(pitch));
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+          const uint32_t r = (px4 >> (8 * a)) & 0xffu;
+          const real w = bx[a] * by[b];
+          atomicAdd(&col[r], to_fixed(double(w), magic));  // ds_add_u64
+        }
+      }
+    }
+  }
+
+  // inlier count: wave-reduce, one LDS add per wave
+  unsigned int winl = inl;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) winl += __shfl_down(winl, off, 64);
+  if ((tid & 63) == 0 && winl) atomicAdd(s_inl, winl);
+  __syncthreads();
+
+  // flush the tile: contiguous in the [bin_points][bin_image] device layout
+  u64* dst = hist + size_t(ch.group) * size_t(tile_n);
+  for (int k = tid; k < tile_n; k += kThreads) {
+    const u64 vv = tile[k];
+    if (vv) atomicAdd(&dst[k], vv);
+  }
+  if (tid == 0 && *s_inl) atomicAdd(&hist[size_t(B) * size_t(B) + kTailInliers], u64(*s_inl));
+}
+
+// ------------------------------------------------------------------------------------------
+// pass A (NEAREST): CostCalculatorNID's hard assignment.  FoV gate on the normalised camera-frame
+// point, truncating int cast, one count per inlier.  The arithmetic order matches the reference
+// expression tree so that, compiled with -ffp-contract=off, +,-,*,/,sqrt results are bit-identical
+// to the CPU's and the integer histogram is exactly reproducible.
+template <int MODEL, typename Rec, typename real>
+__global__ __launch_bounds__(kThreads) void k_nearest_hist(
+  const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint8_t* __restrict__ img, int pitch, int W, int H, IsoParams<real> iso, CamParams<real> cam, int B,
+  int GW, real cos_fov, u64* __restrict__ hist) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u64* tile = reinterpret_cast<u64*>(smem);
+  const int tile_n = GW * B;
+  unsigned int* s_inl = reinterpret_cast<unsigned int*>(tile + tile_n);
+
+  const int tid = threadIdx.x;
+  const Chunk ch = chunks[blockIdx.x];
+  for (int k = tid; k < tile_n; k += kThreads) tile[k] = 0;
+  if (tid == 0) *s_inl = 0;
+  __syncthreads();
+
+  const real fW = real(W), fH = real(H);
+  const uint32_t col0 = ch.group * uint32_t(GW);
+  unsigned int inl = 0;
+
+  for (uint32_t i = tid; i < ch.count; i += kThreads) {
+    real x, y, z;
+    uint32_t bin;
+    load_rec<real>(pts + ch.start + i, x, y, z, bin);
+    // Eigen 4x4 * (x y z 1): ((m0 x + m1 y) + m2 z) + m3 * 1
+    const real cx = ((iso.m[0] * x + iso.m[1] * y) + iso.m[2] * z) + iso.m[3];
+    const real cy = ((iso.m[4] * x + iso.m[5] * y) + iso.m[6] * z) + iso.m[7];
+    const real cz = ((iso.m[8] * x + iso.m[9] * y) + iso.m[10] * z) + iso.m[11];
+    const real n2 = (cx * cx + cy * cy) + cz * cz;
+    const real zn = n2 > real(0) ? cz / m_sqrt(n2) : cz;
+    if (zn < cos_fov) continue;  // out of FoV (cost_calculator_nid.cpp:32)
+    real u, v;
+    project<MODEL, real, real>(cam, cx, cy, cz, u, v);
+    // trunc(u) in [0,W)  <=>  -1 < u < W ; NaN false (cost_calculator_nid.cpp:37-41)
+    const bool in = (u > real(-1)) && (u < fW) && (v > real(-1)) && (v < fH);
+    if (in) {
+      inl++;
+      const int px = int(u), py = int(v);  // truncation toward zero
+      const uint32_t r = img[size_t(py + 1) * size_t(pitch) + size_t(px + 1)];
+      atomicAdd(&tile[(bin - col0) * uint32_t(B) + r], u64(1));
+    }
+  }
+
+  unsigned int winl = inl;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) winl += __shfl_down(winl, off, 64);
+  if ((tid & 63) == 0 && winl) atomicAdd(s_inl, winl);
+  __syncthreads();
+
+  u64* dst = hist + size_t(ch.group) * size_t(tile_n);
+  for (int k = tid; k < tile_n; k += kThreads) {
+    const u64 vv = tile[k];
+    if (vv) atomicAdd(&dst[k], vv);
+  }
+  if (tid == 0 && *s_inl) atomicAdd(&hist[size_t(B) * size_t(B) + kTailInliers], u64(*s_inl));
+}
+
+#ifdef NID_COMMON_KERNELS
+// ------------------------------------------------------------------------------------------
+// entropy, part 1: one workgroup per column group.  hist layout [c][r] (c = bin_points,
+// r = bin_image).  Writes  part_hj[g] = sum p log(p + 1e-6) over the group's bins,
+// row_part[g][r] = sum_c h[c][r] (fixed point), col_sum[c] = sum_r h[c][r] (fixed point).
+__global__ __launch_bounds__(kThreads) void k_entropy_partial(const u64* __restrict__ hist, int B, int GW, double inv_unit, double* __restrict__ part_hj, u64* __restrict__ row_part, u64* __restrict__ col_sum) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u64* s_row = reinterpret_cast<u64*>(smem);  // B
+  u64* s_col = s_row + B;                     // GW
+  double* s_red = reinterpret_cast<double*>(s_col + GW);  // kWaves
+
+  const int tid = threadIdx.x;
+  const int g = blockIdx.x;
+  const int c0 = g * GW;
+  const int ncols = min(GW, B - c0);
+  for (int k = tid; k < B; k += kThreads) s_row[k] = 0;
+  for (int k = tid; k < GW; k += kThreads) s_col[k] = 0;
+  __syncthreads();
+
+  const double S = double(hist[size_t(B) * size_t(B) + kTailInliers]);
+  const double scale = inv_unit / S;  // fixed-point word -> probability
+  const u64* src = hist + size_t(c0) * size_t(B);
+  double acc = 0.0;
+  const int n = ncols * B;
+  for (int k = tid; k < n; k += kThreads) {
+    const u64 v = src[k];
+    if (v) {
+      const double p = double(v) * scale;
+      acc += p * log(p + 1e-6);
+      atomicAdd(&s_row[k % B], v);
+      atomicAdd(&s_col[k / B], v);
+    }
+  }
+  acc = wave_sum(acc);
+  if ((tid & 63) == 0) s_red[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+    for (int w = 0; w < kWaves; w++) t += s_red[w];
+    part_hj[g] = t;
+  }
+  for (int k = tid; k < B; k += kThreads) row_part[size_t(g) * size_t(B) + k] = s_row[k];
+  for (int k = tid; k < ncols; k += kThreads) col_sum[c0 + k] = s_col[k];
+}
+
+// entropy, part 2: single workgroup.  hist_image = row sums, hist_points = column sums / unit
+// (partition of unity: the 16 weights of an inlier sum to 1), S = inlier count.
+// nid_cost.hpp:86-104: NID = (Hj - MI) / Hj, MI = Hi + Hp - Hj.
+__global__ __launch_bounds__(kThreads) void k_entropy_final(
+  const u64* __restrict__ hist, int B, int NG, double inv_unit, const double* __restrict__ part_hj, const u64* __restrict__ row_part, const u64* __restrict__ col_sum,
+  double* __restrict__ phi_q, double* __restrict__ hist_image_out, double* __restrict__ hist_points_out, EntropyScalars* __restrict__ scal, double* __restrict__ out) {
+  __shared__ double s_red[3 * kWaves];
+  const int tid = threadIdx.x;
+  const double S = double(hist[size_t(B) * size_t(B) + kTailInliers]);
+  double hi_acc = 0.0, hp_acc = 0.0, hj_acc = 0.0;
+  for (int r = tid; r < B; r += kThreads) {
+    u64 t = 0;
+    for (int g = 0; g < NG; g++) t += row_part[size_t(g) * size_t(B) + r];
+    const double raw = double(t) * inv_unit;  // raw (un-normalised) hist_image[r]
+    const double q = raw / S;
+    hi_acc += q * log(q + 1e-6);
+    phi_q[r] = log(q + 1e-6) + q / (q + 1e-6);
+    hist_image_out[r] = raw;
+  }
+  for (int c = tid; c < B; c += kThreads) {
+    const double cnt = rint(double(col_sum[c]) * inv_unit);  // exact inlier count of column c
+    const double p = cnt / S;
+    hp_acc += p * log(p + 1e-6);
+    hist_points_out[c] = cnt;
+  }
+  for (int g = tid; g < NG; g += kThreads) hj_acc += part_hj[g];
+  hi_acc = wave_sum(hi_acc);
+  hp_acc = wave_sum(hp_acc);
+  hj_acc = wave_sum(hj_acc);
+  if ((tid & 63) == 0) {
+    s_red[(tid >> 6) * 3 + 0] = hi_acc;
+    s_red[(tid >> 6) * 3 + 1] = hp_acc;
+    s_red[(tid >> 6) * 3 + 2] = hj_acc;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (int w = 0; w < kWaves; w++) {
+      a += s_red[w * 3 + 0];
+      b += s_red[w * 3 + 1];
+      c += s_red[w * 3 + 2];
+    }
+    const double Hi = -a, Hp = -b, Hj = -c;
+    const double MI = Hi + Hp - Hj;
+    const double nid = (Hj - MI) / Hj;
+    EntropyScalars e;
+    e.nid = nid;
+    e.S = S;
+    e.coefA = -(Hi + Hp) / (Hj * Hj * S);
+    e.coefB = 1.0 / (Hj * S);
+    e.Hi = Hi;
+    e.Hp = Hp;
+    e.Hj = Hj;
+    e.status = isfinite(nid) ? 0.0 : 1.0;
+    *scal = e;
+    out[0] = nid;
+    out[8] = e.status;
+    out[9] = S;
+  }
+}
+
+#endif  // NID_COMMON_KERNELS
+
+// ------------------------------------------------------------------------------------------
+// pass B (SPLINE): gradient.  G[c][r] = coefA * phi(h[c][r] / S) + coefB * phi_q[r] with
+// phi(p) = log(p + eps) + p / (p + eps) is dNID/d(raw weight in bin (r,c)) (DESIGN.md derivation).
+// Per point: (gx, gy) = sum_taps G * d(w_tap)/d(u, v); gp = (gx gy) * d(uv)/d(p_cam) (Dual3
+// projection); accumulate M += gp p^T (3x3) and gt += gp (3).  One 12-double partial per workgroup.
+// LDS: gtile[GW*B] doubles + kWaves*12 doubles.
+template <int MODEL, typename Rec, typename real>
+__global__ __launch_bounds__(kThreads) void k_spline_grad(
+  const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint8_t* __restrict__ img, int pitch, int W, int H, PoseParams<real> pose, CamParams<real> cam, int B,
+  int GW, double inv_unit, const u64* __restrict__ hist, const double* __restrict__ phi_q, const EntropyScalars* __restrict__ scal, double* __restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* gtile = reinterpret_cast<double*>(smem);
+  const int tile_n = GW * B;
+  double* s_red = gtile + tile_n;
+
+  const int tid = threadIdx.x;
+  const Chunk ch = chunks[blockIdx.x];
+  {
+    const double coefA = scal->coefA, coefB = scal->coefB;
+    const double scale = inv_unit / scal->S;
+    const u64* src = hist + size_t(ch.group) * size_t(tile_n);
+    const int ncols = min(GW, B - int(ch.group) * GW);
+    const int n = ncols * B;
+    for (int k = tid; k < n; k += kThreads) {
+      const double p = double(src[k]) * scale;
+      gtile[k] = coefA * (log(p + 1e-6) + p / (p + 1e-6)) + coefB * phi_q[k % B];
+    }
+  }
+  __syncthreads();
+
+  const real fW = real(W), fH = real(H);
+  const uint32_t col0 = ch.group * uint32_t(GW);
+  double acc[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) acc[k] = 0.0;
+
+  typedef Dual3<real> D;
+  for (uint32_t i = tid; i < ch.count; i += kThreads) {
+    real x, y, z;
+    uint32_t bin;
+    load_rec<real>(pts + ch.start + i, x, y, z, bin);
+    const real cx = ((pose.R[0] * x + pose.R[1] * y) + pose.R[2] * z) + pose.t[0];
+    const real cy = ((pose.R[3] * x + pose.R[4] * y) + pose.R[5] * z) + pose.t[1];
+    const real cz = ((pose.R[6] * x + pose.R[7] * y) + pose.R[8] * z) + pose.t[2];
+    D u, v;
+    project<MODEL, D, real>(cam, D(cx, real(1), real(0), real(0)), D(cy, real(0), real(1), real(0)), D(cz, real(0), real(0), real(1)), u, v);
+    const bool in = (u.a >= real(0)) && (u.a < fW) && (v.a >= real(0)) && (v.a < fH);
+    if (in) {
+      const real fu = m_floor(u.a), fv = m_floor(v.a);
+      const int kx = int(fu), ky = int(fv);
+      real bx[4], by[4], dbx[4], dby[4];
+      bspline<real>(u.a - fu, bx);
+      bspline<real>(v.a - fv, by);
+      bspline_deriv<real>(u.a - fu, dbx);
+      bspline_deriv<real>(v.a - fv, dby);
+      const double* gcol = gtile + (bin - col0) * uint32_t(B);
+      const uint8_t* p0 = img + size_t(ky) * size_t(pitch) + size_t(kx);
+      real gx = real(0), gy = real(0);
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const uint32_t px4 = load_u8x4(p0 + size_t(b) * size_t(pitch));
+        real sa = real(0), sb = real(0);
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+          const real g = real(gcol[(px4 >> (8 * a)) & 0xffu]);
+          sa += g * dbx[a];
+          sb += g * bx[a];
+        }
+        gx += sa * by[b];
+        gy += sb * dby[b];
+      }
+      const double gp0 = double(gx * u.d0 + gy * v.d0);
+      const double gp1 = double(gx * u.d1 + gy * v.d1);
+      const double gp2 = double(gx * u.d2 + gy * v.d2);
+      const double dx = double(x), dy = double(y), dz = double(z);
+      acc[0] += gp0 * dx;
+      acc[1] += gp0 * dy;
+      acc[2] += gp0 * dz;
+      acc[3] += gp1 * dx;
+      acc[4] += gp1 * dy;
+      acc[5] += gp1 * dz;
+      acc[6] += gp2 * dx;
+      acc[7] += gp2 * dy;
+      acc[8] += gp2 * dz;
+      acc[9] += gp0;
+      acc[10] += gp1;
+      acc[11] += gp2;
+    }
+  }
+
+#pragma unroll
+  for (int k = 0; k < 12; k++) {
+    const double t = wave_sum(acc[k]);
+    if ((tid & 63) == 0) s_red[(tid >> 6) * 12 + k] = t;
+  }
+  __syncthreads();
+  if (tid < 12) {
+    double t = 0.0;
+    for (int w = 0; w < kWaves; w++) t += s_red[w * 12 + tid];
+    partials[size_t(blockIdx.x) * 12 + tid] = t;
+  }
+}
+
+#ifdef NID_COMMON_KERNELS
+// reduce workgroup partials (fixed order -> run-to-run reproducible) and chain M, gt to the ambient
+// 7-gradient of p_cam = p + 2 w (v x p) + 2 v x (v x p) + t  (SURVEY.md Appendix C):
+//   A = (M21 - M12, M02 - M20, M10 - M01);  grad_w = 2 v.A;
+//   grad_v = 2 w A + 2 (M v + M^T v - 2 tr(M) v);  grad_t = gt.
+// out[1..7] = d NID / d [qx qy qz qw tx ty tz]
+__global__ __launch_bounds__(kThreads) void k_grad_final(const double* __restrict__ partials, int nblocks, double qx, double qy, double qz, double qw, double* __restrict__ out) {
+  __shared__ double s_red[kWaves * 12];
+  const int tid = threadIdx.x;
+  double acc[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) acc[k] = 0.0;
+  for (int b = tid; b < nblocks; b += kThreads) {
+#pragma unroll
+    for (int k = 0; k < 12; k++) acc[k] += partials[size_t(b) * 12 + k];
+  }
+#pragma unroll
+  for (int k = 0; k < 12; k++) {
+    const double t = wave_sum(acc[k]);
+    if ((tid & 63) == 0) s_red[(tid >> 6) * 12 + k] = t;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double M[12];
+    for (int k = 0; k < 12; k++) {
+      double t = 0.0;
+      for (int w = 0; w < kWaves; w++) t += s_red[w * 12 + k];
+      M[k] = t;
+    }
+    const double A0 = M[7] - M[5], A1 = M[2] - M[6], A2 = M[3] - M[1];
+    const double tr = M[0] + M[4] + M[8];
+    const double Mv0 = M[0] * qx + M[1] * qy + M[2] * qz;
+    const double Mv1 = M[3] * qx + M[4] * qy + M[5] * qz;
+    const double Mv2 = M[6] * qx + M[7] * qy + M[8] * qz;
+    const double Mtv0 = M[0] * qx + M[3] * qy + M[6] * qz;
+    const double Mtv1 = M[1] * qx + M[4] * qy + M[7] * qz;
+    const double Mtv2 = M[2] * qx + M[5] * qy + M[8] * qz;
+    out[1] = 2.0 * qw * A0 + 2.0 * (Mv0 + Mtv0 - 2.0 * tr * qx);
+    out[2] = 2.0 * qw * A1 + 2.0 * (Mv1 + Mtv1 - 2.0 * tr * qy);
+    out[3] = 2.0 * qw * A2 + 2.0 * (Mv2 + Mtv2 - 2.0 * tr * qz);
+    out[4] = 2.0 * (qx * A0 + qy * A1 + qz * A2);
+    out[5] = M[9];
+    out[6] = M[10];
+    out[7] = M[11];
+  }
+}
+
+#endif  // NID_COMMON_KERNELS
+
+// GenericCameraBase::project on the device (test / utility path): uv and the 2x3 Jacobian
+template <int MODEL, typename real>
+__global__ void k_project(const double* __restrict__ p3, long long n, CamParams<real> cam, double* __restrict__ uv, double* __restrict__ jac) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  typedef Dual3<real> D;
+  D u, v;
+  project<MODEL, D, real>(cam, D(real(p3[3 * i]), real(1), real(0), real(0)), D(real(p3[3 * i + 1]), real(0), real(1), real(0)), D(real(p3[3 * i + 2]), real(0), real(0), real(1)), u, v);
+  uv[2 * i] = double(u.a);
+  uv[2 * i + 1] = double(v.a);
+  if (jac) {
+    jac[6 * i + 0] = double(u.d0);
+    jac[6 * i + 1] = double(u.d1);
+    jac[6 * i + 2] = double(u.d2);
+    jac[6 * i + 3] = double(v.d0);
+    jac[6 * i + 4] = double(v.d1);
+    jac[6 * i + 5] = double(v.d2);
+  }
+}
+
+}  // namespace nidreg

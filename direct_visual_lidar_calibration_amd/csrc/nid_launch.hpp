@@ -1,0 +1,41 @@
+// nid_launch.hpp -- host-visible launch wrappers around the templated kernels.  The double and the
+// float instantiations live in separate translation units because they are compiled with different
+// floating-point contraction rules (nid_kernels_f64.hip: -ffp-contract=off so +,-,*,/,sqrt match the
+// CPU bit for bit; nid_kernels_f32.hip: fused multiply-adds allowed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nidreg {
+
+struct Chunk;
+struct EntropyScalars;
+
+struct PassArgs {
+  int model;
+  int rec64;  // 1: Rec64 records (double xyz), 0: Rec32
+  const void* pts;
+  const Chunk* chunks;
+  int nchunks;
+  const uint8_t* img;  // padded, edge-replicated bin image
+  int pitch, W, H, B, GW;
+  double R[9], t[3];  // SPLINE pose
+  double iso[12];     // NEAREST pose (rows 0..2 of the 4x4)
+  double intr[5], dist[8];
+  double magic;     // 2^(52 - frac_bits)
+  double inv_unit;  // 2^(-frac_bits)
+  double cos_fov;
+  unsigned long long* hist;
+  const double* phi_q;
+  const EntropyScalars* scal;
+  double* partials;
+  hipStream_t stream;
+  size_t lds_hist, lds_grad;
+};
+
+template <typename real> hipError_t launch_spline_hist(const PassArgs& a);
+template <typename real> hipError_t launch_spline_grad(const PassArgs& a);
+template <typename real> hipError_t launch_nearest_hist(const PassArgs& a);
+template <typename real> hipError_t launch_project(int model, const double* intr, const double* dist, const double* p3, long long n, double* uv, double* jac, hipStream_t stream);
+
+}  // namespace nidreg

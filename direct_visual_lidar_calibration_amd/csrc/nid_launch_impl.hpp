@@ -1,0 +1,97 @@
+// nid_launch_impl.hpp -- bodies of the launch wrappers; included by exactly one TU per `real`.
+#pragma once
+#include "nid_kernels.hpp"
+#include "nid_launch.hpp"
+
+namespace nidreg {
+
+template <typename real>
+static CamParams<real> make_cam(const double* intr, const double* dist) {
+  CamParams<real> c;
+  for (int i = 0; i < 5; i++) c.intr[i] = real(intr[i]);
+  for (int i = 0; i < 8; i++) c.dist[i] = real(dist[i]);
+  return c;
+}
+template <typename real>
+static PoseParams<real> make_pose(const PassArgs& a) {
+  PoseParams<real> p;
+  for (int i = 0; i < 9; i++) p.R[i] = real(a.R[i]);
+  for (int i = 0; i < 3; i++) p.t[i] = real(a.t[i]);
+  return p;
+}
+template <typename real>
+static IsoParams<real> make_iso(const PassArgs& a) {
+  IsoParams<real> p;
+  for (int i = 0; i < 12; i++) p.m[i] = real(a.iso[i]);
+  return p;
+}
+
+template <typename K>
+static hipError_t ensure_lds(K kernel, size_t bytes) {
+  if (bytes > 64 * 1024) return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes));
+  return hipSuccess;
+}
+
+#define NID_MODEL_SWITCH(MACRO)                       \
+  switch (a.model) {                                  \
+    case MODEL_PLUMB_BOB: MACRO(MODEL_PLUMB_BOB); break; \
+    case MODEL_FISHEYE: MACRO(MODEL_FISHEYE); break;  \
+    case MODEL_OMNIDIR: MACRO(MODEL_OMNIDIR); break;  \
+    case MODEL_EQUIRECT: MACRO(MODEL_EQUIRECT); break; \
+    case MODEL_ATAN: MACRO(MODEL_ATAN); break;        \
+    case MODEL_RATIONAL: MACRO(MODEL_RATIONAL); break; \
+    default: return hipErrorInvalidValue;             \
+  }
+
+template <typename real, typename Rec>
+static hipError_t launch_spline_hist_rec(const PassArgs& a) {
+  const PoseParams<real> pose = make_pose<real>(a);
+  const CamParams<real> cam = make_cam<real>(a.intr, a.dist);
+#define NID_LAUNCH(M)                                                                                                                                  \
+  {                                                                                                                                                    \
+    auto k = k_spline_hist<M, Rec, real>;                                                                                                              \
+    hipError_t e = ensure_lds(k, a.lds_hist);                                                                                                          \
+    if (e != hipSuccess) return e;                                                                                                                     \
+    hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(kThreads), a.lds_hist, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, pose, cam, \
+                       a.B, a.GW, a.magic, a.hist);                                                                                                    \
+  }
+  NID_MODEL_SWITCH(NID_LAUNCH)
+#undef NID_LAUNCH
+  return hipGetLastError();
+}
+
+template <typename real, typename Rec>
+static hipError_t launch_spline_grad_rec(const PassArgs& a) {
+  const PoseParams<real> pose = make_pose<real>(a);
+  const CamParams<real> cam = make_cam<real>(a.intr, a.dist);
+#define NID_LAUNCH(M)                                                                                                                                  \
+  {                                                                                                                                                    \
+    auto k = k_spline_grad<M, Rec, real>;                                                                                                              \
+    hipError_t e = ensure_lds(k, a.lds_grad);                                                                                                          \
+    if (e != hipSuccess) return e;                                                                                                                     \
+    hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(kThreads), a.lds_grad, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, pose, cam, \
+                       a.B, a.GW, a.inv_unit, a.hist, a.phi_q, a.scal, a.partials);                                                                    \
+  }
+  NID_MODEL_SWITCH(NID_LAUNCH)
+#undef NID_LAUNCH
+  return hipGetLastError();
+}
+
+template <typename real, typename Rec>
+static hipError_t launch_nearest_hist_rec(const PassArgs& a) {
+  const IsoParams<real> iso = make_iso<real>(a);
+  const CamParams<real> cam = make_cam<real>(a.intr, a.dist);
+#define NID_LAUNCH(M)                                                                                                                                  \
+  {                                                                                                                                                    \
+    auto k = k_nearest_hist<M, Rec, real>;                                                                                                             \
+    hipError_t e = ensure_lds(k, a.lds_hist);                                                                                                          \
+    if (e != hipSuccess) return e;                                                                                                                     \
+    hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(kThreads), a.lds_hist, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, iso, cam,  \
+                       a.B, a.GW, real(a.cos_fov), a.hist);                                                                                            \
+  }
+  NID_MODEL_SWITCH(NID_LAUNCH)
+#undef NID_LAUNCH
+  return hipGetLastError();
+}
+
+}  // namespace nidreg

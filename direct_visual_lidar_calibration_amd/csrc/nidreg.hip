@@ -1,0 +1,701 @@
+// nidreg.hip -- host side of the C ABI declared in include/nidreg.h.
+//
+// Owns: device residency of one LiDAR-camera pair (bucketed point records, padded bin image,
+// fixed-point histogram, scratch), the per-evaluation launch sequence, and the multi-handle
+// (multi-pair / multi-GPU) fan-out.  No CPU compute path exists here: every evaluation runs the
+// HIP kernels of nid_kernels.hpp, and creation fails when no gfx950 device is usable.
+#define NID_COMMON_KERNELS
+#include "nid_kernels.hpp"
+#include "nid_launch.hpp"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/nidreg.h"
+
+using namespace nidreg;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t _e = (expr);                                                                             \
+    if (_e != hipSuccess) return fail(NIDREG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+// double -> int exactly as the reference's x86-64 build converts (cvttsd2si): NaN / overflow -> INT_MIN
+inline int cast_int(double d) {
+  if (!(d > -2147483649.0 && d < 2147483648.0)) return INT_MIN;
+  return static_cast<int>(d);
+}
+
+const int kNumIntr[6] = {4, 4, 5, 2, 4, 4};
+const int kNumDist[6] = {5, 4, 4, 0, 1, 8};
+
+}  // namespace
+
+struct nidreg_handle {
+  int device = 0;
+  int model = 0, mode = 0, precision = 0, bins = 0;
+  int W = 0, H = 0, pitch = 0;
+  int GW = 0, NG = 0;
+  int frac_bits = 0;
+  int rec64 = 0;
+  int64_t num_points = 0;
+  int nchunks = 0;
+  double intr[5] = {0}, dist[8] = {0};
+  double max_fov = 0.0;
+
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  void* d_pts = nullptr;
+  Chunk* d_chunks = nullptr;
+  uint8_t* d_img = nullptr;
+  u64* d_hist = nullptr;
+  bool own_hist = false;
+  double* d_out = nullptr;
+  bool own_out = false;
+  double* d_part_hj = nullptr;
+  u64* d_row_part = nullptr;
+  u64* d_col_sum = nullptr;
+  double* d_phi_q = nullptr;
+  double* d_hist_image = nullptr;
+  double* d_hist_points = nullptr;
+  EntropyScalars* d_scal = nullptr;
+  double* d_partials = nullptr;
+  double* h_out = nullptr;  // pinned
+
+  size_t lds_hist = 0, lds_grad = 0, lds_entropy = 0;
+  int64_t hist_words = 0;
+
+  bool timing = false;
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool ev_grad = false;
+  double last_q[4] = {0, 0, 0, 1};
+  double last_R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  double last_t[3] = {0, 0, 0};
+};
+
+namespace {
+
+void free_handle(nidreg_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->d_pts) (void)hipFree(h->d_pts);
+  if (h->d_chunks) (void)hipFree(h->d_chunks);
+  if (h->d_img) (void)hipFree(h->d_img);
+  if (h->own_hist && h->d_hist) (void)hipFree(h->d_hist);
+  if (h->own_out && h->d_out) (void)hipFree(h->d_out);
+  if (h->d_part_hj) (void)hipFree(h->d_part_hj);
+  if (h->d_row_part) (void)hipFree(h->d_row_part);
+  if (h->d_col_sum) (void)hipFree(h->d_col_sum);
+  if (h->d_phi_q) (void)hipFree(h->d_phi_q);
+  if (h->d_hist_image) (void)hipFree(h->d_hist_image);
+  if (h->d_hist_points) (void)hipFree(h->d_hist_points);
+  if (h->d_scal) (void)hipFree(h->d_scal);
+  if (h->d_partials) (void)hipFree(h->d_partials);
+  if (h->h_out) (void)hipHostFree(h->h_out);
+  for (int i = 0; i < 6; i++)
+    if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+  if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+void fill_pass_args(const nidreg_handle* h, PassArgs& a) {
+  std::memset(&a, 0, sizeof(a));
+  a.model = h->model;
+  a.rec64 = h->rec64;
+  a.pts = h->d_pts;
+  a.chunks = h->d_chunks;
+  a.nchunks = h->nchunks;
+  a.img = h->d_img;
+  a.pitch = h->pitch;
+  a.W = h->W;
+  a.H = h->H;
+  a.B = h->bins;
+  a.GW = h->GW;
+  std::memcpy(a.intr, h->intr, sizeof(a.intr));
+  std::memcpy(a.dist, h->dist, sizeof(a.dist));
+  a.magic = std::ldexp(1.0, 52 - h->frac_bits);
+  a.inv_unit = std::ldexp(1.0, -h->frac_bits);
+  a.cos_fov = std::cos(h->max_fov);
+  a.hist = h->d_hist;
+  a.phi_q = h->d_phi_q;
+  a.scal = h->d_scal;
+  a.partials = h->d_partials;
+  a.stream = h->stream;
+  a.lds_hist = h->lds_hist;
+  a.lds_grad = h->lds_grad;
+}
+
+// R = I + 2 w [v]x + 2 [v]x^2 from the un-normalised quaternion (Sophus SO3 * point expanded)
+void pose_from_se3(const double* se3, double* R, double* t) {
+  const double x = se3[0], y = se3[1], z = se3[2], w = se3[3];
+  R[0] = 1.0 - 2.0 * (y * y + z * z);
+  R[1] = 2.0 * (x * y - w * z);
+  R[2] = 2.0 * (x * z + w * y);
+  R[3] = 2.0 * (x * y + w * z);
+  R[4] = 1.0 - 2.0 * (x * x + z * z);
+  R[5] = 2.0 * (y * z - w * x);
+  R[6] = 2.0 * (x * z - w * y);
+  R[7] = 2.0 * (y * z + w * x);
+  R[8] = 1.0 - 2.0 * (x * x + y * y);
+  t[0] = se3[4];
+  t[1] = se3[5];
+  t[2] = se3[6];
+}
+
+int launch_hist_spline(nidreg_handle* h, const double* se3) {
+  PassArgs a;
+  fill_pass_args(h, a);
+  pose_from_se3(se3, a.R, a.t);
+  for (int k = 0; k < 4; k++) h->last_q[k] = se3[k];
+  std::memcpy(h->last_R, a.R, sizeof(a.R));
+  std::memcpy(h->last_t, a.t, sizeof(a.t));
+  HIP_TRY(hipMemsetAsync(h->d_hist, 0, size_t(h->hist_words) * sizeof(u64), h->stream));
+  if (h->timing) HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+  if (h->precision == NIDREG_PREC_FP32) {
+    HIP_TRY(launch_spline_hist<float>(a));
+  } else {
+    HIP_TRY(launch_spline_hist<double>(a));
+  }
+  return NIDREG_OK;
+}
+
+int launch_hist_nearest(nidreg_handle* h, const double* T) {
+  PassArgs a;
+  fill_pass_args(h, a);
+  for (int k = 0; k < 12; k++) a.iso[k] = T[k];
+  HIP_TRY(hipMemsetAsync(h->d_hist, 0, size_t(h->hist_words) * sizeof(u64), h->stream));
+  if (h->timing) HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+  if (h->precision == NIDREG_PREC_FP32) {
+    HIP_TRY(launch_nearest_hist<float>(a));
+  } else {
+    HIP_TRY(launch_nearest_hist<double>(a));
+  }
+  return NIDREG_OK;
+}
+
+int launch_entropy(nidreg_handle* h) {
+  const double inv_unit = std::ldexp(1.0, -h->frac_bits);
+  hipLaunchKernelGGL(k_entropy_partial, dim3(h->NG), dim3(kThreads), h->lds_entropy, h->stream, h->d_hist, h->bins, h->GW, inv_unit, h->d_part_hj, h->d_row_part, h->d_col_sum);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(
+    k_entropy_final, dim3(1), dim3(kThreads), 0, h->stream, h->d_hist, h->bins, h->NG, inv_unit, h->d_part_hj, h->d_row_part, h->d_col_sum, h->d_phi_q, h->d_hist_image,
+    h->d_hist_points, h->d_scal, h->d_out);
+  HIP_TRY(hipGetLastError());
+  return NIDREG_OK;
+}
+
+int launch_grad(nidreg_handle* h) {
+  PassArgs a;
+  fill_pass_args(h, a);
+  // same pose as the histogram pass of this evaluation
+  std::memcpy(a.R, h->last_R, sizeof(a.R));
+  std::memcpy(a.t, h->last_t, sizeof(a.t));
+  if (h->precision == NIDREG_PREC_FP32) {
+    HIP_TRY(launch_spline_grad<float>(a));
+  } else {
+    HIP_TRY(launch_spline_grad<double>(a));
+  }
+  if (h->timing) HIP_TRY(hipEventRecord(h->ev[4], h->stream));
+  hipLaunchKernelGGL(k_grad_final, dim3(1), dim3(kThreads), 0, h->stream, h->d_partials, h->nchunks, h->last_q[0], h->last_q[1], h->last_q[2], h->last_q[3], h->d_out);
+  HIP_TRY(hipGetLastError());
+  return NIDREG_OK;
+}
+
+// asynchronous part of nidreg_eval
+int eval_launch(nidreg_handle* h, const double* se3, bool want_grad) {
+  if (h->mode != NIDREG_MODE_SPLINE) return fail(NIDREG_ERR_INVALID, "nidreg_eval: handle was created in NEAREST mode");
+  HIP_TRY(hipSetDevice(h->device));
+  if (h->timing) HIP_TRY(hipEventRecord(h->ev[0], h->stream));
+  int rc = launch_hist_spline(h, se3);
+  if (rc) return rc;
+  if (h->timing) HIP_TRY(hipEventRecord(h->ev[2], h->stream));
+  rc = launch_entropy(h);
+  if (rc) return rc;
+  if (h->timing) HIP_TRY(hipEventRecord(h->ev[3], h->stream));
+  h->ev_grad = want_grad;
+  if (want_grad) {
+    rc = launch_grad(h);
+    if (rc) return rc;
+  } else if (h->timing) {
+    HIP_TRY(hipEventRecord(h->ev[4], h->stream));
+  }
+  if (h->timing) HIP_TRY(hipEventRecord(h->ev[5], h->stream));
+  HIP_TRY(hipMemcpyAsync(h->h_out, h->d_out, NIDREG_OUT_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  return NIDREG_OK;
+}
+
+int eval_finish(nidreg_handle* h, double* cost, double* grad7) {
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (cost) *cost = h->h_out[0];
+  if (grad7)
+    for (int k = 0; k < 7; k++) grad7[k] = h->h_out[1 + k];
+  return h->h_out[8] != 0.0 ? NIDREG_FALSE : NIDREG_OK;
+}
+
+int iso_launch(nidreg_handle* h, const double* T) {
+  if (h->mode != NIDREG_MODE_NEAREST) return fail(NIDREG_ERR_INVALID, "nidreg_eval_iso: handle was created in SPLINE mode");
+  HIP_TRY(hipSetDevice(h->device));
+  if (h->timing) HIP_TRY(hipEventRecord(h->ev[0], h->stream));
+  int rc = launch_hist_nearest(h, T);
+  if (rc) return rc;
+  if (h->timing) HIP_TRY(hipEventRecord(h->ev[2], h->stream));
+  rc = launch_entropy(h);
+  if (rc) return rc;
+  if (h->timing) {
+    HIP_TRY(hipEventRecord(h->ev[3], h->stream));
+    HIP_TRY(hipEventRecord(h->ev[4], h->stream));
+    HIP_TRY(hipEventRecord(h->ev[5], h->stream));
+  }
+  h->ev_grad = false;
+  HIP_TRY(hipMemcpyAsync(h->h_out, h->d_out, NIDREG_OUT_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  return NIDREG_OK;
+}
+
+// visual_camera_calibration.cpp:149-156: delta = init^-1 * T; reject when |t| > 0.2 m or angle > 2 deg
+bool trust_gate_ok(const double* init, const double* se3) {
+  const double x0 = -init[0], y0 = -init[1], z0 = -init[2], w0 = init[3];
+  const double x1 = se3[0], y1 = se3[1], z1 = se3[2], w1 = se3[3];
+  const double qw = w0 * w1 - x0 * x1 - y0 * y1 - z0 * z1;
+  const double qx = w0 * x1 + x0 * w1 + y0 * z1 - z0 * y1;
+  const double qy = w0 * y1 - x0 * z1 + y0 * w1 + z0 * x1;
+  const double qz = w0 * z1 + x0 * y1 - y0 * x1 + z0 * w1;
+  // R0^T (t - t0) with the unit-quaternion rotation of init
+  const double ix = init[0], iy = init[1], iz = init[2], iw = init[3];
+  const double R0[9] = {1 - 2 * (iy * iy + iz * iz), 2 * (ix * iy - iz * iw),     2 * (ix * iz + iy * iw),     2 * (ix * iy + iz * iw),    1 - 2 * (ix * ix + iz * iz),
+                        2 * (iy * iz - ix * iw),     2 * (ix * iz - iy * iw),     2 * (iy * iz + ix * iw),     1 - 2 * (ix * ix + iy * iy)};
+  const double d[3] = {se3[4] - init[4], se3[5] - init[5], se3[6] - init[6]};
+  const double tx = R0[0] * d[0] + R0[3] * d[1] + R0[6] * d[2];
+  const double ty = R0[1] * d[0] + R0[4] * d[1] + R0[7] * d[2];
+  const double tz = R0[2] * d[0] + R0[5] * d[1] + R0[8] * d[2];
+  const double tn = std::sqrt(tx * tx + ty * ty + tz * tz);
+  const double ang = 2.0 * std::atan2(std::sqrt(qx * qx + qy * qy + qz * qz), std::fabs(qw));
+  return !(tn > 0.2 || ang > 2.0 * M_PI / 180.0);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* nidreg_last_error(void) { return g_last_error.c_str(); }
+const char* nidreg_version(void) { return "nidreg 0.1 (gfx950, hand-written HIP)"; }
+
+int nidreg_model_from_name(const char* name, int* num_intrinsics, int* num_distortion) {
+  if (!name) return -1;
+  const std::string s(name);
+  int id = -1;
+  if (s == "plumb_bob") id = NIDREG_MODEL_PLUMB_BOB;
+  else if (s == "fisheye" || s == "equidistant") id = NIDREG_MODEL_FISHEYE;
+  else if (s == "atan") id = NIDREG_MODEL_ATAN;
+  else if (s == "omnidir") id = NIDREG_MODEL_OMNIDIR;
+  else if (s == "equirectangular") id = NIDREG_MODEL_EQUIRECTANGULAR;
+  else if (s == "rational_polynomial") id = NIDREG_MODEL_RATIONAL_POLYNOMIAL;
+  if (id < 0) return -1;
+  if (num_intrinsics) *num_intrinsics = kNumIntr[id];
+  if (num_distortion) *num_distortion = kNumDist[id];
+  return id;
+}
+
+int nidreg_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int64_t nidreg_hist_words(int bins) {
+  // room for a partially filled last column group plus the tail words
+  return int64_t(bins) * bins + kTailWords;
+}
+
+int nidreg_create(const nidreg_desc* d, nidreg_handle** out) {
+  if (!d || !out) return fail(NIDREG_ERR_INVALID, "nidreg_create: null argument");
+  *out = nullptr;
+  if (d->struct_size != int32_t(sizeof(nidreg_desc))) return fail(NIDREG_ERR_INVALID, "nidreg_create: struct_size mismatch");
+  if (d->model_id < 0 || d->model_id > 5) return fail(NIDREG_ERR_INVALID, "nidreg_create: unknown camera model");
+  if (d->bins < 2 || d->bins > NIDREG_MAX_BINS) return fail(NIDREG_ERR_INVALID, "nidreg_create: bins must be in [2, 256]");
+  if (d->width < 1 || d->height < 1 || !d->image) return fail(NIDREG_ERR_INVALID, "nidreg_create: bad image");
+  if (d->num_points < 0 || d->num_points > int64_t(INT_MAX)) return fail(NIDREG_ERR_INVALID, "nidreg_create: bad num_points");
+  if (d->num_points > 0 && (!d->points || !d->intensities)) return fail(NIDREG_ERR_INVALID, "nidreg_create: null points");
+  if (d->mode != NIDREG_MODE_SPLINE && d->mode != NIDREG_MODE_NEAREST) return fail(NIDREG_ERR_INVALID, "nidreg_create: bad mode");
+  if (d->precision != NIDREG_PREC_FP64 && d->precision != NIDREG_PREC_FP32) return fail(NIDREG_ERR_INVALID, "nidreg_create: bad precision");
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(NIDREG_ERR_NO_DEVICE, "nidreg_create: no HIP device (the NID core has no CPU path)");
+  if (d->device_id < 0 || d->device_id >= ndev) return fail(NIDREG_ERR_INVALID, "nidreg_create: device_id out of range");
+  HIP_TRY(hipSetDevice(d->device_id));
+
+  nidreg_handle* h = new nidreg_handle();
+  h->device = d->device_id;
+  h->model = d->model_id;
+  h->mode = d->mode;
+  h->precision = d->precision;
+  h->bins = d->bins;
+  h->W = d->width;
+  h->H = d->height;
+  h->num_points = d->num_points;
+  h->max_fov = d->max_fov;
+  std::memcpy(h->intr, d->intrinsics, sizeof(h->intr));
+  std::memcpy(h->dist, d->distortion, sizeof(h->dist));
+  const int B = h->bins;
+  const int64_t N = h->num_points;
+
+#define CREATE_TRY(expr)                                                                     \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) {                                                                  \
+      free_handle(h);                                                                        \
+      return fail(NIDREG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));        \
+    }                                                                                        \
+  } while (0)
+
+  // ---- tiling: GW histogram columns per workgroup (LDS tile = GW * B 64-bit words)
+  int GW = d->columns_per_group > 0 ? d->columns_per_group : 16;
+  GW = std::min(GW, B);
+  while (size_t(GW) * B * 8 > 128 * 1024 && GW > 1) GW /= 2;
+  h->GW = GW;
+  h->NG = (B + GW - 1) / GW;
+  h->lds_hist = size_t(GW) * B * 8 + 16;
+  h->lds_grad = size_t(GW) * B * 8 + size_t(kWaves) * 12 * 8;
+  h->lds_entropy = size_t(B) * 8 + size_t(GW) * 8 + size_t(kWaves) * 8;
+
+  // ---- fixed point: sum over a bin <= N * 2^frac must stay below 2^63
+  int nbits = 1;
+  while ((int64_t(1) << nbits) <= N) nbits++;
+  h->frac_bits = d->mode == NIDREG_MODE_NEAREST ? 0 : std::min(40, 62 - nbits);
+
+  // ---- bin image, padded by 1 (left/top) and >= 2 (right/bottom), edge replicated:
+  // bin_image = min(int(pix * bins), bins - 1) (nid_cost.hpp:78-79) for CV_64FC1 input;
+  // max(0, min(bins-1, int(u8 / 255.0 * bins))) (cost_calculator_nid.cpp:43-46) for CV_8UC1 input.
+  const int W = h->W, H = h->H;
+  h->pitch = ((W + 8) + 3) & ~3;
+  const int PH = H + 3;
+  std::vector<uint8_t> img(size_t(h->pitch) * PH + 16, 0);
+  {
+    uint8_t lut[256];
+    for (int k = 0; k < 256; k++) lut[k] = uint8_t(std::max(0, std::min(B - 1, cast_int(k / 255.0 * B))));
+    const uint8_t* base = static_cast<const uint8_t*>(d->image);
+    for (int py = 0; py < PH; py++) {
+      const int sy = std::min(std::max(py - 1, 0), H - 1);
+      uint8_t* dst = img.data() + size_t(py) * h->pitch;
+      if (d->image_dtype == NIDREG_IMAGE_F64) {
+        const double* row = reinterpret_cast<const double*>(base + size_t(sy) * d->image_row_stride);
+        for (int px = 0; px < h->pitch; px++) {
+          const int sx = std::min(std::max(px - 1, 0), W - 1);
+          dst[px] = uint8_t(std::max(0, std::min(cast_int(row[sx] * B), B - 1)));
+        }
+      } else {
+        const uint8_t* row = base + size_t(sy) * d->image_row_stride;
+        for (int px = 0; px < h->pitch; px++) {
+          const int sx = std::min(std::max(px - 1, 0), W - 1);
+          dst[px] = lut[row[sx]];
+        }
+      }
+    }
+  }
+  CREATE_TRY(hipMalloc(&h->d_img, img.size()));
+  CREATE_TRY(hipMemcpy(h->d_img, img.data(), img.size(), hipMemcpyHostToDevice));
+
+  // ---- points: bin_points = max(0, min(bins-1, int(intensity * bins))) (nid_cost.hpp:49,
+  // cost_calculator_nid.cpp:47) is pose independent -> bucket by column group (stable), so a
+  // workgroup owns GW histogram columns.  Records are float32 when that is lossless or when the
+  // caller asked for FP32 geometry; otherwise double.
+  const char* pbase = reinterpret_cast<const char*>(d->points);
+  const int64_t pstride = d->point_stride > 0 ? d->point_stride : 32;
+  bool lossless = true;
+  std::vector<uint32_t> bin(N);
+  std::vector<int64_t> gcount(h->NG + 1, 0);
+  for (int64_t i = 0; i < N; i++) {
+    const double* p = reinterpret_cast<const double*>(pbase + i * pstride);
+    if (lossless) {
+      for (int k = 0; k < 3; k++)
+        if (double(float(p[k])) != p[k] && p[k] == p[k]) lossless = false;
+    }
+    const int b = std::max(0, std::min(B - 1, cast_int(d->intensities[i] * B)));
+    bin[i] = uint32_t(b);
+    gcount[b / GW + 1]++;
+  }
+  for (int g = 0; g < h->NG; g++) gcount[g + 1] += gcount[g];
+  h->rec64 = (d->precision == NIDREG_PREC_FP64 && !lossless) ? 1 : 0;
+  const size_t rec_bytes = h->rec64 ? sizeof(Rec64) : sizeof(Rec32);
+  {
+    std::vector<int64_t> cursor(gcount.begin(), gcount.end() - 1);
+    std::vector<unsigned char> recs(size_t(std::max<int64_t>(N, 1)) * rec_bytes);
+    for (int64_t i = 0; i < N; i++) {
+      const double* p = reinterpret_cast<const double*>(pbase + i * pstride);
+      const int64_t dst = cursor[bin[i] / GW]++;
+      if (h->rec64) {
+        Rec64 r;
+        r.x = p[0];
+        r.y = p[1];
+        r.z = p[2];
+        r.bin = bin[i];
+        std::memcpy(recs.data() + size_t(dst) * rec_bytes, &r, rec_bytes);
+      } else {
+        Rec32 r;
+        r.x = float(p[0]);
+        r.y = float(p[1]);
+        r.z = float(p[2]);
+        r.bin = bin[i];
+        std::memcpy(recs.data() + size_t(dst) * rec_bytes, &r, rec_bytes);
+      }
+    }
+    CREATE_TRY(hipMalloc(&h->d_pts, recs.size() + 64));
+    CREATE_TRY(hipMemcpy(h->d_pts, recs.data(), recs.size(), hipMemcpyHostToDevice));
+  }
+
+  // ---- chunk table: each chunk = one workgroup, points of one column group only
+  {
+    const int target = d->target_blocks > 0 ? d->target_blocks : 2048;
+    int64_t CH = (N + target - 1) / std::max(target, 1);
+    CH = std::max<int64_t>(kThreads, ((CH + kThreads - 1) / kThreads) * kThreads);
+    std::vector<Chunk> chunks;
+    for (int g = 0; g < h->NG; g++) {
+      for (int64_t s = gcount[g]; s < gcount[g + 1]; s += CH) {
+        Chunk c;
+        c.start = uint32_t(s);
+        c.count = uint32_t(std::min<int64_t>(CH, gcount[g + 1] - s));
+        c.group = uint32_t(g);
+        c.pad = 0;
+        chunks.push_back(c);
+      }
+    }
+    h->nchunks = int(chunks.size());
+    CREATE_TRY(hipMalloc(&h->d_chunks, std::max<size_t>(chunks.size(), 1) * sizeof(Chunk)));
+    if (!chunks.empty()) CREATE_TRY(hipMemcpy(h->d_chunks, chunks.data(), chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice));
+  }
+
+  // ---- per-evaluation scratch
+  h->hist_words = nidreg_hist_words(B);
+  if (d->ext_stream) {
+    h->stream = static_cast<hipStream_t>(d->ext_stream);
+  } else {
+    CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->own_stream = true;
+  }
+  if (d->ext_hist) {
+    h->d_hist = static_cast<u64*>(d->ext_hist);
+  } else {
+    CREATE_TRY(hipMalloc(&h->d_hist, size_t(h->hist_words) * sizeof(u64)));
+    h->own_hist = true;
+  }
+  if (d->ext_out) {
+    h->d_out = static_cast<double*>(d->ext_out);
+  } else {
+    CREATE_TRY(hipMalloc(&h->d_out, NIDREG_OUT_DOUBLES * sizeof(double)));
+    h->own_out = true;
+  }
+  CREATE_TRY(hipMemset(h->d_out, 0, NIDREG_OUT_DOUBLES * sizeof(double)));
+  CREATE_TRY(hipMemset(h->d_hist, 0, size_t(h->hist_words) * sizeof(u64)));
+  CREATE_TRY(hipMalloc(&h->d_part_hj, size_t(h->NG) * sizeof(double)));
+  CREATE_TRY(hipMalloc(&h->d_row_part, size_t(h->NG) * B * sizeof(u64)));
+  CREATE_TRY(hipMalloc(&h->d_col_sum, size_t(B) * sizeof(u64)));
+  CREATE_TRY(hipMalloc(&h->d_phi_q, size_t(B) * sizeof(double)));
+  CREATE_TRY(hipMalloc(&h->d_hist_image, size_t(B) * sizeof(double)));
+  CREATE_TRY(hipMalloc(&h->d_hist_points, size_t(B) * sizeof(double)));
+  CREATE_TRY(hipMalloc(&h->d_scal, sizeof(EntropyScalars)));
+  CREATE_TRY(hipMalloc(&h->d_partials, std::max<size_t>(h->nchunks, 1) * 12 * sizeof(double)));
+  CREATE_TRY(hipHostMalloc(&h->h_out, NIDREG_OUT_DOUBLES * sizeof(double), hipHostMallocDefault));
+  std::memset(h->h_out, 0, NIDREG_OUT_DOUBLES * sizeof(double));
+  for (int i = 0; i < 6; i++) CREATE_TRY(hipEventCreate(&h->ev[i]));
+#undef CREATE_TRY
+  *out = h;
+  return NIDREG_OK;
+}
+
+void nidreg_destroy(nidreg_handle* h) { free_handle(h); }
+
+int nidreg_eval(nidreg_handle* h, const double* se3, double* cost, double* grad7) {
+  if (!h || !se3) return fail(NIDREG_ERR_INVALID, "nidreg_eval: null argument");
+  const int rc = eval_launch(h, se3, grad7 != nullptr);
+  if (rc) return rc;
+  return eval_finish(h, cost, grad7);
+}
+
+int nidreg_eval_iso(nidreg_handle* h, const double* T, double* cost) {
+  if (!h || !T) return fail(NIDREG_ERR_INVALID, "nidreg_eval_iso: null argument");
+  const int rc = iso_launch(h, T);
+  if (rc) return rc;
+  return eval_finish(h, cost, nullptr) < 0 ? NIDREG_ERR_HIP : NIDREG_OK;  // CostCalculatorNID has no finite check
+}
+
+int nidreg_eval_multi(nidreg_handle* const* handles, int n, const double* init_se3, const double* se3, double* cost, double* grad7) {
+  if (!handles || n <= 0 || !se3) return fail(NIDREG_ERR_INVALID, "nidreg_eval_multi: bad argument");
+  if (init_se3 && !trust_gate_ok(init_se3, se3)) return NIDREG_FALSE;
+  for (int i = 0; i < n; i++) {
+    const int rc = eval_launch(handles[i], se3, grad7 != nullptr);
+    if (rc) return rc;
+  }
+  double csum = 0.0, gsum[7] = {0, 0, 0, 0, 0, 0, 0};
+  bool all_ok = true;
+  for (int i = 0; i < n; i++) {
+    double c = 0.0, g[7];
+    const int rc = eval_finish(handles[i], &c, grad7 ? g : nullptr);
+    if (rc < 0) return rc;
+    if (rc == NIDREG_FALSE) all_ok = false;
+    csum += c;
+    if (grad7)
+      for (int k = 0; k < 7; k++) gsum[k] += g[k];
+  }
+  if (cost) *cost = csum;
+  if (grad7)
+    for (int k = 0; k < 7; k++) grad7[k] = gsum[k];
+  return all_ok ? NIDREG_OK : NIDREG_FALSE;
+}
+
+int nidreg_eval_iso_multi(nidreg_handle* const* handles, int n, const double* T, double* cost) {
+  if (!handles || n <= 0 || !T) return fail(NIDREG_ERR_INVALID, "nidreg_eval_iso_multi: bad argument");
+  for (int i = 0; i < n; i++) {
+    const int rc = iso_launch(handles[i], T);
+    if (rc) return rc;
+  }
+  double csum = 0.0;
+  for (int i = 0; i < n; i++) {
+    double c = 0.0;
+    const int rc = eval_finish(handles[i], &c, nullptr);
+    if (rc < 0) return rc;
+    csum += c;
+  }
+  if (cost) *cost = csum;
+  return NIDREG_OK;
+}
+
+int nidreg_get_hist_fixed(nidreg_handle* h, int64_t* joint, int64_t* inliers, int* frac_bits) {
+  if (!h) return fail(NIDREG_ERR_INVALID, "nidreg_get_hist_fixed: null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  const int B = h->bins;
+  std::vector<u64> tmp(size_t(h->hist_words));
+  HIP_TRY(hipMemcpy(tmp.data(), h->d_hist, tmp.size() * sizeof(u64), hipMemcpyDeviceToHost));
+  if (joint) {
+    // device layout [bin_points][bin_image] -> [bin_image][bin_points]
+    for (int c = 0; c < B; c++)
+      for (int r = 0; r < B; r++) joint[size_t(r) * B + c] = int64_t(tmp[size_t(c) * B + r]);
+  }
+  if (inliers) *inliers = int64_t(tmp[size_t(B) * B + kTailInliers]);
+  if (frac_bits) *frac_bits = h->frac_bits;
+  return NIDREG_OK;
+}
+
+int nidreg_get_hist(nidreg_handle* h, double* joint, double* hist_image, double* hist_points) {
+  if (!h) return fail(NIDREG_ERR_INVALID, "nidreg_get_hist: null handle");
+  const int B = h->bins;
+  if (joint) {
+    std::vector<int64_t> fx(size_t(B) * B);
+    const int rc = nidreg_get_hist_fixed(h, fx.data(), nullptr, nullptr);
+    if (rc) return rc;
+    const double inv_unit = std::ldexp(1.0, -h->frac_bits);
+    for (size_t k = 0; k < fx.size(); k++) joint[k] = double(fx[k]) * inv_unit;
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (hist_image) HIP_TRY(hipMemcpy(hist_image, h->d_hist_image, size_t(B) * sizeof(double), hipMemcpyDeviceToHost));
+  if (hist_points) HIP_TRY(hipMemcpy(hist_points, h->d_hist_points, size_t(B) * sizeof(double), hipMemcpyDeviceToHost));
+  return NIDREG_OK;
+}
+
+int nidreg_project(nidreg_handle* h, const double* p3, int64_t n, double* uv, double* jac) {
+  if (!h || !p3 || !uv || n < 0) return fail(NIDREG_ERR_INVALID, "nidreg_project: bad argument");
+  if (n == 0) return NIDREG_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  double *d_p = nullptr, *d_uv = nullptr, *d_j = nullptr;
+  HIP_TRY(hipMalloc(&d_p, size_t(n) * 3 * sizeof(double)));
+  HIP_TRY(hipMalloc(&d_uv, size_t(n) * 2 * sizeof(double)));
+  if (jac) HIP_TRY(hipMalloc(&d_j, size_t(n) * 6 * sizeof(double)));
+  HIP_TRY(hipMemcpy(d_p, p3, size_t(n) * 3 * sizeof(double), hipMemcpyHostToDevice));
+  hipError_t e = h->precision == NIDREG_PREC_FP32 ? launch_project<float>(h->model, h->intr, h->dist, d_p, n, d_uv, d_j, h->stream)
+                                                  : launch_project<double>(h->model, h->intr, h->dist, d_p, n, d_uv, d_j, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e == hipSuccess) e = hipMemcpy(uv, d_uv, size_t(n) * 2 * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && jac) e = hipMemcpy(jac, d_j, size_t(n) * 6 * sizeof(double), hipMemcpyDeviceToHost);
+  (void)hipFree(d_p);
+  (void)hipFree(d_uv);
+  if (d_j) (void)hipFree(d_j);
+  if (e != hipSuccess) return fail(NIDREG_ERR_HIP, std::string("nidreg_project: ") + hipGetErrorString(e));
+  return NIDREG_OK;
+}
+
+int nidreg_project_model(int model_id, const double* intrinsics, const double* distortion, int device_id, int precision, const double* p3, int64_t n, double* uv, double* jac) {
+  if (model_id < 0 || model_id > 5 || !intrinsics || !distortion || !p3 || !uv || n < 0) return fail(NIDREG_ERR_INVALID, "nidreg_project_model: bad argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(NIDREG_ERR_NO_DEVICE, "nidreg_project_model: no HIP device");
+  nidreg_handle tmp;
+  tmp.device = device_id;
+  tmp.model = model_id;
+  tmp.precision = precision;
+  std::memcpy(tmp.intr, intrinsics, sizeof(tmp.intr));
+  std::memcpy(tmp.dist, distortion, sizeof(tmp.dist));
+  tmp.stream = nullptr;  // default stream
+  return nidreg_project(&tmp, p3, n, uv, jac);
+}
+
+int nidreg_shard_hist(nidreg_handle* h, const double* se3) {
+  if (!h || !se3) return fail(NIDREG_ERR_INVALID, "nidreg_shard_hist: null argument");
+  if (h->mode != NIDREG_MODE_SPLINE) return fail(NIDREG_ERR_INVALID, "nidreg_shard_hist: SPLINE handles only");
+  HIP_TRY(hipSetDevice(h->device));
+  return launch_hist_spline(h, se3);
+}
+
+int nidreg_shard_entropy(nidreg_handle* h) {
+  if (!h) return fail(NIDREG_ERR_INVALID, "nidreg_shard_entropy: null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  return launch_entropy(h);
+}
+
+int nidreg_shard_grad(nidreg_handle* h) {
+  if (!h) return fail(NIDREG_ERR_INVALID, "nidreg_shard_grad: null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  return launch_grad(h);
+}
+
+int nidreg_shard_finish(nidreg_handle* h, double* cost, double* grad7) {
+  if (!h) return fail(NIDREG_ERR_INVALID, "nidreg_shard_finish: null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipMemcpyAsync(h->h_out, h->d_out, NIDREG_OUT_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  return eval_finish(h, cost, grad7);
+}
+
+int nidreg_set_timing(nidreg_handle* h, int enable) {
+  if (!h) return fail(NIDREG_ERR_INVALID, "nidreg_set_timing: null handle");
+  h->timing = enable != 0;
+  return NIDREG_OK;
+}
+
+int nidreg_get_timing(nidreg_handle* h, float* ms6) {
+  if (!h || !ms6) return fail(NIDREG_ERR_INVALID, "nidreg_get_timing: null argument");
+  if (!h->timing) return fail(NIDREG_ERR_INVALID, "nidreg_get_timing: timing not enabled");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipEventSynchronize(h->ev[5]));
+  HIP_TRY(hipEventElapsedTime(&ms6[0], h->ev[0], h->ev[5]));
+  for (int k = 0; k < 5; k++) HIP_TRY(hipEventElapsedTime(&ms6[1 + k], h->ev[k], h->ev[k + 1]));
+  return NIDREG_OK;
+}
+
+int nidreg_get_info(nidreg_handle* h, int64_t* info8) {
+  if (!h || !info8) return fail(NIDREG_ERR_INVALID, "nidreg_get_info: null argument");
+  info8[0] = h->rec64 ? int64_t(sizeof(Rec64)) : int64_t(sizeof(Rec32));
+  info8[1] = h->nchunks;
+  info8[2] = h->GW;
+  info8[3] = h->frac_bits;
+  info8[4] = int64_t(h->lds_hist);
+  info8[5] = h->pitch;
+  info8[6] = h->num_points;
+  info8[7] = h->rec64 ? 0 : 1;
+  return NIDREG_OK;
+}
+
+}  // extern "C"

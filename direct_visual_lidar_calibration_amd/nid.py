@@ -1,0 +1,319 @@
+"""Host-side mirror of the reference's cost-function interface for the NID hot path.
+
+Same names, argument meaning and error behaviour as the reference classes, so parity tests read
+like tests of the reference would:
+
+=====================================  ==========================================================
+here                                   reference
+=====================================  ==========================================================
+``create_camera(model, intr, dist)``   ``camera::create_camera`` (src/camera/create_camera.cpp:34-51):
+                                       returns ``None`` on unknown model / intrinsic-count mismatch
+``GenericCamera.project(p)``           ``GenericCameraBase::project`` (generic_camera_base.hpp:29)
+``NIDCost(proj, img64, pts, I, bins)`` ``vlcal::NIDCost`` ctor (include/vlcal/costs/nid_cost.hpp:23)
+``NIDCost.__call__(params)``           ``NIDCost::operator()<T>`` (:36-107): ``(ok, cost, grad7)``
+``MultiNIDCost(init).add(c)``          ``MultiNIDCost`` (visual_camera_calibration.cpp:141-178)
+``CostCalculatorNID(proj, img8, ...)`` ``vlcal::CostCalculatorNID`` (cost_calculator_nid.cpp:13-17)
+``CostCalculatorNID.calculate(T)``     ``CostCalculatorNID::calculate`` (:21-67)
+``estimate_camera_fov(proj, size)``    ``vlcal::estimate_camera_fov`` (estimate_fov.cpp:36-51)
+=====================================  ==========================================================
+
+All arithmetic of the cost functions runs in the HIP library behind ``include/nidreg.h``; this file
+only marshals numpy arrays across the C ABI.  There is no CPU implementation to fall back to.
+"""
+import ctypes
+import math
+
+import numpy as np
+
+from . import _lib
+from .dfo import NelderMead, NelderMeadParams
+
+_MODEL_COUNTS = {0: (4, 5), 1: (4, 4), 2: (5, 4), 3: (2, 0), 4: (4, 1), 5: (4, 8)}
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(_lib.c_double_p)
+
+
+class GenericCamera:
+    """What ``camera::create_camera`` hands back: an opaque projection object.  Unlike the
+    reference's ``GenericCameraBase`` it also exposes the model id and parameters, which the GPU
+    cost objects need (SURVEY.md hard part 5)."""
+
+    def __init__(self, model, model_id, intrinsics, distortion):
+        self.model = model
+        self.model_id = model_id
+        self.intrinsics = list(intrinsics)
+        self.distortion = list(distortion)
+        self._intr5 = np.zeros(5)
+        self._intr5[: len(intrinsics)] = intrinsics
+        self._dist8 = np.zeros(8)
+        self._dist8[: len(distortion)] = distortion
+
+    def project(self, point_3d, device=0, precision="fp64", jacobian=False):
+        """``GenericCameraBase::project`` evaluated by the device projection code (any (n,3) batch)."""
+        lib = _lib.load()
+        p = np.ascontiguousarray(np.asarray(point_3d, dtype=np.float64).reshape(-1, 3))
+        n = p.shape[0]
+        uv = np.empty((n, 2))
+        jac = np.empty((n, 2, 3)) if jacobian else None
+        rc = lib.nidreg_project_model(self.model_id, _dp(self._intr5), _dp(self._dist8), device, _prec(precision), _dp(p), n, _dp(uv), _dp(jac))
+        _lib.check(rc, "nidreg_project_model")
+        if np.ndim(point_3d) == 1:
+            return (uv[0], jac[0]) if jacobian else uv[0]
+        return (uv, jac) if jacobian else uv
+
+    __call__ = project
+
+
+def create_camera(camera_model, intrinsics, distortion_coeffs):
+    """``camera::create_camera``: ``None`` when the model is unknown or the number of intrinsics is
+    wrong (create_camera.cpp:19-22,49-50); distortion zero-padded / truncated (:24-27)."""
+    lib = _lib.load()
+    ni, nd = ctypes.c_int(0), ctypes.c_int(0)
+    mid = lib.nidreg_model_from_name(str(camera_model).encode(), ctypes.byref(ni), ctypes.byref(nd))
+    if mid < 0:
+        return None
+    if len(intrinsics) != ni.value:
+        return None
+    dist = [0.0] * nd.value
+    for i in range(min(len(distortion_coeffs), nd.value)):
+        dist[i] = float(distortion_coeffs[i])
+    return GenericCamera(camera_model, mid, [float(x) for x in intrinsics], dist)
+
+
+def _prec(precision):
+    if precision in ("fp64", "f64", _lib.PREC_FP64):
+        return _lib.PREC_FP64
+    if precision in ("fp32", "f32", _lib.PREC_FP32):
+        return _lib.PREC_FP32
+    raise ValueError(f"unknown precision {precision!r}")
+
+
+class _Handle:
+    """RAII owner of one ``nidreg_handle`` (device residency of one LiDAR-camera pair)."""
+
+    def __init__(self, proj, image, points, intensities, bins, mode, precision, device, max_fov=0.0, columns_per_group=0, target_blocks=0, ext_stream=None, ext_hist=None, ext_out=None):
+        if proj is None:
+            raise ValueError("camera is None (create_camera failed)")
+        lib = _lib.load()
+        self._lib = lib
+        points = np.ascontiguousarray(points, dtype=np.float64)
+        intensities = np.ascontiguousarray(intensities, dtype=np.float64)
+        if points.ndim != 2 or points.shape[1] != 4:
+            raise ValueError("points must be (N, 4) float64 (x y z 1), like Frame::points")
+        if intensities.shape != (points.shape[0],):
+            raise ValueError("intensities must be (N,)")
+        if mode == _lib.MODE_SPLINE:
+            image = np.ascontiguousarray(image, dtype=np.float64)
+            image_dtype = _lib.IMAGE_F64
+        else:
+            image = np.ascontiguousarray(image, dtype=np.uint8)
+            image_dtype = _lib.IMAGE_U8
+        d = _lib.NidregDesc()
+        d.struct_size = ctypes.sizeof(_lib.NidregDesc)
+        d.device_id = int(device)
+        d.model_id = proj.model_id
+        d.mode = mode
+        d.precision = _prec(precision)
+        d.bins = int(bins)
+        for i in range(5):
+            d.intrinsics[i] = proj._intr5[i]
+        for i in range(8):
+            d.distortion[i] = proj._dist8[i]
+        d.height, d.width = image.shape
+        d.image_dtype = image_dtype
+        d.image = image.ctypes.data
+        d.image_row_stride = image.strides[0]
+        d.num_points = points.shape[0]
+        d.points = points.ctypes.data
+        d.point_stride = points.strides[0] if points.shape[0] else 32
+        d.intensities = intensities.ctypes.data
+        d.max_fov = float(max_fov)
+        d.columns_per_group = int(columns_per_group)
+        d.target_blocks = int(target_blocks)
+        d.ext_stream = ext_stream
+        d.ext_hist = ext_hist
+        d.ext_out = ext_out
+        h = ctypes.c_void_p()
+        _lib.check(lib.nidreg_create(ctypes.byref(d), ctypes.byref(h)), "nidreg_create")
+        self.h = h
+        self.bins = int(bins)
+        self.num_points = points.shape[0]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._lib.nidreg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- diagnostics shared by both cost classes
+    def histograms(self):
+        """Raw (un-normalised) histograms of the last evaluation: joint [bin_image][bin_points],
+        hist_image, hist_points."""
+        B = self.bins
+        joint, hi, hp = np.empty((B, B)), np.empty(B), np.empty(B)
+        _lib.check(self._lib.nidreg_get_hist(self.h, _dp(joint), _dp(hi), _dp(hp)), "nidreg_get_hist")
+        return joint, hi, hp
+
+    def histogram_fixed(self):
+        B = self.bins
+        joint = np.empty((B, B), dtype=np.int64)
+        inl = ctypes.c_int64(0)
+        frac = ctypes.c_int(0)
+        rc = self._lib.nidreg_get_hist_fixed(self.h, joint.ctypes.data_as(_lib.c_int64_p), ctypes.byref(inl), ctypes.byref(frac))
+        _lib.check(rc, "nidreg_get_hist_fixed")
+        return joint, inl.value, frac.value
+
+    def set_timing(self, enable=True):
+        _lib.check(self._lib.nidreg_set_timing(self.h, 1 if enable else 0), "nidreg_set_timing")
+
+    def timing_ms(self):
+        ms = (ctypes.c_float * 6)()
+        _lib.check(self._lib.nidreg_get_timing(self.h, ms), "nidreg_get_timing")
+        return dict(total=ms[0], memset=ms[1], hist=ms[2], entropy=ms[3], grad=ms[4], grad_final=ms[5])
+
+    def info(self):
+        v = (ctypes.c_int64 * 8)()
+        _lib.check(self._lib.nidreg_get_info(self.h, v), "nidreg_get_info")
+        keys = ["record_bytes", "num_chunks", "columns_per_group", "frac_bits", "lds_bytes", "image_pitch", "num_points", "float32_records"]
+        return dict(zip(keys, [int(x) for x in v]))
+
+
+class NIDCost(_Handle):
+    """``vlcal::NIDCost`` (nid_cost.hpp:21-116) on the GPU.
+
+    ``NIDCost(proj, normalized_image, points, intensities, bins=16)`` -- ``normalized_image`` is the
+    CV_64FC1 image in [0,1] (``convertTo(CV_64FC1, 1/255)``), ``points`` the (N,4) xyz1 doubles of
+    ``Frame::points``, ``intensities`` the (N,) doubles of ``Frame::intensities``.
+    """
+
+    def __init__(self, proj, normalized_image, points, intensities, bins=16, device=0, precision="fp64", **tuning):
+        super().__init__(proj, normalized_image, points, intensities, bins, _lib.MODE_SPLINE, precision, device, **tuning)
+
+    def __call__(self, T_camera_lidar_params, want_grad=True):
+        """``operator()(params, residual)``: params = [qx qy qz qw tx ty tz].  Returns
+        ``(ok, cost, grad7)``; ``ok`` False = the functor's ``return false`` (non-finite NID).
+        ``want_grad=False`` is the T=double instantiation (cost only, ``grad7`` None)."""
+        x = np.ascontiguousarray(T_camera_lidar_params, dtype=np.float64)
+        cost = ctypes.c_double(float("nan"))
+        grad = np.empty(7) if want_grad else None
+        rc = _lib.check(self._lib.nidreg_eval(self.h, _dp(x), ctypes.byref(cost), _dp(grad)), "nidreg_eval")
+        return rc == _lib.NIDREG_OK, cost.value, grad
+
+    # split-phase API for point-sharded multi-GPU evaluation (see parallel.ShardedNIDCost)
+    def shard_hist(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        _lib.check(self._lib.nidreg_shard_hist(self.h, _dp(x)), "nidreg_shard_hist")
+
+    def shard_entropy(self):
+        _lib.check(self._lib.nidreg_shard_entropy(self.h), "nidreg_shard_entropy")
+
+    def shard_grad(self):
+        _lib.check(self._lib.nidreg_shard_grad(self.h), "nidreg_shard_grad")
+
+    def shard_finish(self, want_grad=True):
+        cost = ctypes.c_double(float("nan"))
+        grad = np.empty(7) if want_grad else None
+        rc = _lib.check(self._lib.nidreg_shard_finish(self.h, ctypes.byref(cost), _dp(grad)), "nidreg_shard_finish")
+        return rc == _lib.NIDREG_OK, cost.value, grad
+
+
+class MultiNIDCost:
+    """``MultiNIDCost`` (visual_camera_calibration.cpp:141-178): trust gate (0.2 m / 2 deg from
+    ``init_T_camera_lidar``), all pairs evaluated concurrently, residual = plain sum, ``False`` if
+    the gate rejects or any pair failed."""
+
+    def __init__(self, init_T_camera_lidar):
+        self.init = None if init_T_camera_lidar is None else np.ascontiguousarray(init_T_camera_lidar, dtype=np.float64)
+        self.costs = []
+
+    def add(self, cost):
+        self.costs.append(cost)
+
+    def __call__(self, params, want_grad=True):
+        lib = _lib.load()
+        x = np.ascontiguousarray(params, dtype=np.float64)
+        n = len(self.costs)
+        arr = (ctypes.c_void_p * n)(*[c.h for c in self.costs])
+        cost = ctypes.c_double(float("nan"))
+        grad = np.empty(7) if want_grad else None
+        rc = _lib.check(lib.nidreg_eval_multi(arr, n, _dp(self.init), _dp(x), ctypes.byref(cost), _dp(grad)), "nidreg_eval_multi")
+        return rc == _lib.NIDREG_OK, cost.value, grad
+
+
+def estimate_direction(proj, pt_2d, device=0):
+    """estimate_fov.cpp:17-34: invert the projection at one pixel with NelderMead<2> defaults."""
+
+    def to_dir(x):
+        sa, ca = math.sin(x[0]), math.cos(x[0])
+        sb, cb = math.sin(x[1]), math.cos(x[1])
+        return np.array([sb, -sa * cb, ca * cb])  # AngleAxis(x0, X) * AngleAxis(x1, Y) * UnitZ
+
+    def f(x):
+        uv = proj.project(to_dir(x), device=device)
+        err = float((pt_2d[0] - uv[0]) ** 2 + (pt_2d[1] - uv[1]) ** 2)
+        return err if math.isfinite(err) else float(np.finfo(np.float64).max)
+
+    result = NelderMead(NelderMeadParams()).optimize(f, np.zeros(2))
+    return to_dir(result.x)
+
+
+def estimate_camera_fov(proj, image_size, device=0):
+    """estimate_fov.cpp:36-51: max view angle over (0,0), (W/2,0), (0,H/2) (integer division)."""
+    w, h = int(image_size[0]), int(image_size[1])
+    corners = [(0.0, 0.0), (float(w // 2), 0.0), (0.0, float(h // 2))]
+    max_fov = 0.0
+    for c in corners:
+        d = estimate_direction(proj, c, device=device)
+        n = np.linalg.norm(d)
+        fov = math.acos((d / n)[2] if n > 0 else d[2])
+        if fov > max_fov:
+            max_fov = fov
+    return max_fov
+
+
+class NIDCostParams:
+    """cost_calculator_nid.cpp:7-9"""
+
+    def __init__(self, bins=16):
+        self.bins = bins
+
+
+class CostCalculatorNID(_Handle):
+    """``vlcal::CostCalculatorNID`` on the GPU.  ``image`` is the 8-bit gray image
+    (``VisualLiDARData::image``); ``max_fov`` defaults to ``estimate_camera_fov(proj, size)`` like
+    the reference constructor (cost_calculator_nid.cpp:13-17)."""
+
+    def __init__(self, proj, image, points, intensities, params=None, max_fov=None, device=0, precision="fp64", **tuning):
+        params = params or NIDCostParams()
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        if max_fov is None:
+            max_fov = estimate_camera_fov(proj, (image.shape[1], image.shape[0]), device=device)
+        self.max_fov = float(max_fov)
+        super().__init__(proj, image, points, intensities, params.bins, _lib.MODE_NEAREST, precision, device, max_fov=self.max_fov, **tuning)
+
+    def calculate(self, T_camera_lidar):
+        """``calculate(const Eigen::Isometry3d&)``: 4x4 matrix -> NID (no finite check, like the
+        reference)."""
+        T = np.ascontiguousarray(np.asarray(T_camera_lidar, dtype=np.float64).reshape(4, 4))
+        cost = ctypes.c_double(float("nan"))
+        _lib.check(self._lib.nidreg_eval_iso(self.h, _dp(T), ctypes.byref(cost)), "nidreg_eval_iso")
+        return cost.value
+
+
+def sum_costs(costs, T_camera_lidar):
+    """The Nelder-Mead objective's ``sum_i costs[i]->calculate(T)`` (visual_camera_calibration.cpp:
+    106-110), all pairs in flight at once."""
+    lib = _lib.load()
+    T = np.ascontiguousarray(np.asarray(T_camera_lidar, dtype=np.float64).reshape(4, 4))
+    n = len(costs)
+    arr = (ctypes.c_void_p * n)(*[c.h for c in costs])
+    cost = ctypes.c_double(float("nan"))
+    _lib.check(lib.nidreg_eval_iso_multi(arr, n, _dp(T), ctypes.byref(cost)), "nidreg_eval_iso_multi")
+    return cost.value

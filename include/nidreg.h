@@ -1,0 +1,177 @@
+/*
+ * nidreg.h -- C ABI of the MI355X-native NID direct LiDAR-camera registration core.
+ *
+ * This is the drop-in boundary for the hot path of koide3/direct_visual_lidar_calibration's
+ * `calibrate`: everything behind these entry points runs as hand-written HIP kernels on gfx950
+ * (direct_visual_lidar_calibration_amd/csrc/).  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Reference interfaces each entry point replaces (paths relative to the reference tree):
+ *   nidreg_model_from_name   camera::create_camera model strings + parameter counts
+ *                            (src/camera/create_camera.cpp:17-51)
+ *   nidreg_create            vlcal::NIDCost::NIDCost           (include/vlcal/costs/nid_cost.hpp:23-34)
+ *                            vlcal::CostCalculatorNID ctor     (src/vlcal/calib/cost_calculator_nid.cpp:13-17)
+ *   nidreg_eval              NIDCost::operator()<double | ceres::Jet<double,7>>
+ *                                                              (include/vlcal/costs/nid_cost.hpp:36-107)
+ *   nidreg_eval_iso          CostCalculatorNID::calculate      (src/vlcal/calib/cost_calculator_nid.cpp:21-67)
+ *   nidreg_eval_multi        MultiNIDCost::operator()          (src/vlcal/calib/visual_camera_calibration.cpp:147-173)
+ *   nidreg_eval_iso_multi    the Nelder-Mead objective's sum over pairs
+ *                                                              (src/vlcal/calib/visual_camera_calibration.cpp:103-119)
+ *   nidreg_project           GenericCameraBase::project        (include/camera/generic_camera_base.hpp:29)
+ *   nidreg_shard_*           (no reference counterpart) split-phase evaluation of one pair whose
+ *                            points are sharded over several GPUs; the caller all-reduces the
+ *                            fixed-point histogram (RCCL) between the phases.
+ *   nidreg_destroy           ~NIDCost / ~CostCalculatorNID
+ *
+ * Conventions
+ *   - return value: 0 = ok; NIDREG_FALSE (1) = the functor's `return false` (non-finite NID,
+ *     nid_cost.hpp:98-102, or the 0.2 m / 2 deg trust gate, visual_camera_calibration.cpp:154);
+ *     < 0 = error (nidreg_last_error() gives the text for the calling thread).
+ *   - pose for nidreg_eval*: Sophus SE3d::data() order [qx qy qz qw tx ty tz] = T_camera_lidar,
+ *     quaternion NOT re-normalised (the reference differentiates the un-normalised formula).
+ *     The 7-gradient returned is the ambient Jet gradient d NID / d [qx qy qz qw tx ty tz].
+ *   - pose for nidreg_eval_iso*: row-major 4x4 T_camera_lidar (Eigen::Isometry3d::matrix()).
+ *   - histograms handed back are row-major [bin_image][bin_points] like `hist(bin_image, bin_points)`.
+ *   - threading: concurrent calls on DIFFERENT handles from different host threads are safe (the
+ *     reference evaluates one NIDCost per OpenMP thread, visual_camera_calibration.cpp:161);
+ *     concurrent calls on the same handle are not supported (never happens in the reference).
+ *   - the caller keeps ownership of every host buffer; nidreg_create copies what it needs.
+ */
+#ifndef NIDREG_H
+#define NIDREG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NIDREG_OK 0
+#define NIDREG_FALSE 1
+#define NIDREG_ERR_INVALID (-1)     /* bad argument / unsupported configuration */
+#define NIDREG_ERR_HIP (-2)         /* HIP runtime error */
+#define NIDREG_ERR_NO_DEVICE (-3)   /* no usable gfx950 device */
+
+/* camera models (create_camera.cpp:34-51) */
+#define NIDREG_MODEL_PLUMB_BOB 0            /* "plumb_bob": 4 intrinsics, 5 distortion (k1 k2 p1 p2 k3) */
+#define NIDREG_MODEL_FISHEYE 1              /* "fisheye" | "equidistant": 4 + 4 */
+#define NIDREG_MODEL_OMNIDIR 2              /* "omnidir": 5 (fx fy cx cy xi) + 4 */
+#define NIDREG_MODEL_EQUIRECTANGULAR 3      /* "equirectangular": 2 (W H) + 0 */
+#define NIDREG_MODEL_ATAN 4                 /* "atan": 4 + 1 */
+#define NIDREG_MODEL_RATIONAL_POLYNOMIAL 5  /* "rational_polynomial": 4 + 8 (k1 k2 p1 p2 k3 k4 k5 k6) */
+
+/* which reference functor the handle implements */
+#define NIDREG_MODE_SPLINE 0   /* NIDCost: B-spline soft assignment, value + Jacobian */
+#define NIDREG_MODE_NEAREST 1  /* CostCalculatorNID: FoV gate + nearest pixel, integer histogram */
+
+/* per-point arithmetic */
+#define NIDREG_PREC_FP64 0  /* transform / projection / weights in double (parity mode) */
+#define NIDREG_PREC_FP32 1  /* transform / projection / weights in float; histogram still 64-bit fixed point */
+
+#define NIDREG_IMAGE_F64 0  /* CV_64FC1 normalised to [0,1] (what NIDCost receives) */
+#define NIDREG_IMAGE_U8 1   /* CV_8UC1 (what CostCalculatorNID receives) */
+
+#define NIDREG_MAX_BINS 256
+
+typedef struct nidreg_handle nidreg_handle;
+
+typedef struct nidreg_desc {
+  int32_t struct_size;      /* sizeof(nidreg_desc), for forward compatibility */
+  int32_t device_id;        /* HIP device ordinal */
+  int32_t model_id;         /* NIDREG_MODEL_* */
+  int32_t mode;             /* NIDREG_MODE_* */
+  int32_t precision;        /* NIDREG_PREC_* */
+  int32_t bins;             /* nid_bins, 2..256 */
+  double intrinsics[5];     /* exactly the model's count is read */
+  double distortion[8];     /* already zero-padded / truncated like create_camera.cpp:24-27 */
+  int32_t width, height;    /* image cols, rows */
+  int32_t image_dtype;      /* NIDREG_IMAGE_* */
+  int32_t reserved0;
+  const void* image;        /* host pointer, rows x cols */
+  int64_t image_row_stride; /* bytes between rows (cv::Mat::step) */
+  int64_t num_points;       /* Frame::size() */
+  const double* points;     /* host; Eigen::Vector4d (x y z 1) per point */
+  int64_t point_stride;     /* bytes between points (32 for Frame::points) */
+  const double* intensities;/* host; Frame::intensities */
+  double max_fov;           /* NEAREST only: estimate_camera_fov() result [rad] */
+  /* tuning (0 = default) */
+  int32_t columns_per_group;/* histogram columns (bin_points values) a workgroup owns in LDS */
+  int32_t target_blocks;    /* approximate number of point chunks = workgroups per pass */
+  /* optional externally owned device resources (sharded multi-GPU use); NULL = internal */
+  void* ext_stream;         /* hipStream_t the handle launches on */
+  void* ext_hist;           /* device buffer of nidreg_hist_words(bins) 64-bit words */
+  void* ext_out;            /* device buffer of NIDREG_OUT_DOUBLES doubles */
+} nidreg_desc;
+
+#define NIDREG_OUT_DOUBLES 16  /* [0]=cost [1..7]=grad7 [8]=status [9]=inliers [10..15] reserved */
+
+/* model string -> NIDREG_MODEL_* (or -1); optionally returns the parameter counts */
+int nidreg_model_from_name(const char* name, int* num_intrinsics, int* num_distortion);
+
+int nidreg_device_count(void);
+
+int nidreg_create(const nidreg_desc* desc, nidreg_handle** out);
+void nidreg_destroy(nidreg_handle* h);
+
+/* NIDCost::operator(): cost (+ gradient when grad7 != NULL) at se3 = [qx qy qz qw tx ty tz] */
+int nidreg_eval(nidreg_handle* h, const double* se3, double* cost, double* grad7);
+
+/* CostCalculatorNID::calculate at a row-major 4x4 T_camera_lidar */
+int nidreg_eval_iso(nidreg_handle* h, const double* T_camera_lidar, double* cost);
+
+/* MultiNIDCost::operator(): trust gate against init_se3 (NULL = no gate), all handles launched
+ * concurrently (one per pair, possibly on different GPUs), plain sum of costs / gradients,
+ * NIDREG_FALSE if the gate rejects or any pair is non-finite. */
+int nidreg_eval_multi(nidreg_handle* const* handles, int n, const double* init_se3, const double* se3, double* cost, double* grad7);
+
+/* sum_i CostCalculatorNID_i::calculate(T) */
+int nidreg_eval_iso_multi(nidreg_handle* const* handles, int n, const double* T_camera_lidar, double* cost);
+
+/* raw histograms of the most recent evaluation (any pointer may be NULL).
+ * joint: bins*bins doubles [bin_image][bin_points]; hist_image, hist_points: bins doubles. */
+int nidreg_get_hist(nidreg_handle* h, double* joint, double* hist_image, double* hist_points);
+/* the same joint histogram as exact integers: fixed-point words (value * 2^frac_bits) in SPLINE
+ * mode, counts (frac_bits = 0) in NEAREST mode. */
+int nidreg_get_hist_fixed(nidreg_handle* h, int64_t* joint, int64_t* inliers, int* frac_bits);
+
+/* GenericCameraBase::project for n points (host in, host out), evaluated on the device with the
+ * same projection code the cost kernels use.  p3: n x 3 doubles, uv: n x 2 doubles,
+ * jac (nullable): n x 6 doubles = d(u,v)/d(x,y,z) row-major 2x3. */
+int nidreg_project(nidreg_handle* h, const double* p3, int64_t n, double* uv, double* jac);
+/* the same without a handle (used for one-time host set-up such as estimate_camera_fov,
+ * src/vlcal/common/estimate_fov.cpp:17-51); intrinsics[5] / distortion[8] as in nidreg_desc */
+int nidreg_project_model(int model_id, const double* intrinsics, const double* distortion, int device_id, int precision, const double* p3, int64_t n, double* uv, double* jac);
+
+/* ---- split-phase evaluation for a pair whose points are sharded across GPUs --------------
+ * rank r:  nidreg_shard_hist(h, se3)      zero + accumulate this shard's fixed-point histogram
+ *          <caller: all-reduce(sum, int64) of ext_hist over ranks, ordered on ext_stream>
+ *          nidreg_shard_entropy(h)        entropy tail on the full histogram -> cost
+ *          nidreg_shard_grad(h)           this shard's gradient partial -> out[1..7]
+ *          <caller: all-reduce(sum, f64) of out[1..7]>
+ *          nidreg_shard_finish(h, ...)    stream sync + read back
+ * All shard calls are asynchronous on the handle's stream except nidreg_shard_finish. */
+int64_t nidreg_hist_words(int bins); /* 64-bit words in the histogram buffer (bins*bins + tail) */
+int nidreg_shard_hist(nidreg_handle* h, const double* se3);
+int nidreg_shard_entropy(nidreg_handle* h);
+int nidreg_shard_grad(nidreg_handle* h);
+int nidreg_shard_finish(nidreg_handle* h, double* cost, double* grad7);
+
+/* device-side timing of the most recent nidreg_eval / nidreg_eval_iso in milliseconds (HIP events
+ * recorded on the handle's stream, i.e. the stream the kernels run on):
+ * [0]=whole launch sequence [1]=histogram memset [2]=histogram kernel [3]=entropy kernels
+ * [4]=gradient kernel (0 if not run) [5]=gradient finalisation.
+ * Only recorded after nidreg_set_timing(h, 1). */
+int nidreg_set_timing(nidreg_handle* h, int enable);
+int nidreg_get_timing(nidreg_handle* h, float* ms6);
+
+/* layout facts for DESIGN.md / bench: [0]=record bytes per point on device, [1]=number of chunks,
+ * [2]=columns per group, [3]=fixed-point fraction bits, [4]=LDS bytes per workgroup,
+ * [5]=padded image pitch, [6]=points stored (after dropping none), [7]=1 if float32 records */
+int nidreg_get_info(nidreg_handle* h, int64_t* info8);
+
+const char* nidreg_last_error(void);
+const char* nidreg_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NIDREG_H */

@@ -81,7 +81,7 @@ def nid_cost(model, intrinsics, distortion, image_f64, points, intensities, bins
         grad = g.numpy().copy()
     return dict(
         ok=ok,
-        cost=float(nid),
+        cost=float(nid.detach()),
         grad=grad,
         hist=hist.detach().reshape(B, B).numpy().copy(),
         hist_image=hist_image.detach().numpy().copy(),

@@ -1,0 +1,68 @@
+"""CPU tests of the C-ABI boundary: the HIP library builds for gfx950, loads, and exports exactly the
+entry points include/nidreg.h declares.  No compute calls (there is no GPU here)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "nidreg.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(nidreg_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_build_entry_point():
+    import __graft_entry__
+
+    __graft_entry__.build()
+
+
+def test_library_exports_every_declared_symbol():
+    from direct_visual_lidar_calibration_amd import _lib
+
+    lib = _lib.load()
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), f"libnidreg.so does not export {s}"
+    assert sorted(_lib.EXPORTS) == syms
+    assert b"gfx950" in lib.nidreg_version()
+
+
+def test_desc_struct_layout_matches_header():
+    """sizeof(nidreg_desc) seen by the C compiler == the ctypes mirror."""
+    from direct_visual_lidar_calibration_amd import _lib
+
+    code = '#include <stdio.h>\n#include "nidreg.h"\nint main(){printf("%zu %zu %zu\\n", sizeof(nidreg_desc), __builtin_offsetof(nidreg_desc, image), __builtin_offsetof(nidreg_desc, ext_out));return 0;}\n'
+    exe = "/tmp/_nidreg_sizeof"
+    subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=code.encode(), check=True)
+    out = subprocess.check_output([exe]).decode().split()
+    assert int(out[0]) == ctypes.sizeof(_lib.NidregDesc)
+    assert int(out[1]) == _lib.NidregDesc.image.offset
+    assert int(out[2]) == _lib.NidregDesc.ext_out.offset
+
+
+def test_model_table_and_no_device_error():
+    from direct_visual_lidar_calibration_amd import _lib, nid
+
+    lib = _lib.load()
+    ni, nd = ctypes.c_int(), ctypes.c_int()
+    table = {"plumb_bob": (0, 4, 5), "fisheye": (1, 4, 4), "equidistant": (1, 4, 4), "omnidir": (2, 5, 4), "equirectangular": (3, 2, 0), "atan": (4, 4, 1),
+             "rational_polynomial": (5, 4, 8)}
+    for name, (mid, a, b) in table.items():
+        assert lib.nidreg_model_from_name(name.encode(), ctypes.byref(ni), ctypes.byref(nd)) == mid
+        assert (ni.value, nd.value) == (a, b)
+    assert lib.nidreg_model_from_name(b"pinhole", None, None) == -1
+    assert nid.create_camera("pinhole", [1, 2, 3, 4], []) is None
+    if lib.nidreg_device_count() == 0:
+        # the product path fails loudly without a GPU: no CPU fallback
+        import numpy as np
+
+        cam = nid.create_camera("plumb_bob", [100, 100, 50, 50], [])
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            nid.NIDCost(cam, np.zeros((100, 100)), np.zeros((4, 4)), np.zeros(4), 16)

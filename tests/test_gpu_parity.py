@@ -1,0 +1,304 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Run with ``pytest -m gpu`` on an MI355X.
+
+Tolerances (ours; the reference defines none -- SURVEY.md section 7):
+  * NEAREST (CostCalculatorNID): integer joint histogram BIT-EXACT; NID abs <= 1e-12.
+  * SPLINE  (NIDCost), fp64: raw joint histogram abs <= 1e-9 per bin (fixed point 2^-39..2^-40
+    per tap); NID abs <= 1e-10; 7-gradient rel <= 1e-7 (+ abs 1e-10).
+  * SPLINE fp32 geometry: NID abs <= 2e-5, gradient rel <= 2e-2 of its norm.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib
+from direct_visual_lidar_calibration_amd import nid, se3, synth
+
+pytestmark = pytest.mark.gpu
+
+CAMERAS = {
+    "plumb_bob": ("plumb_bob", [210.0, 205.0, 160.0, 120.0], [-0.04, 0.08, 1e-4, -3e-4, -0.04], 320, 240),
+    "fisheye": ("fisheye", [140.0, 140.0, 160.0, 120.0], [-0.01, 0.002, -1e-4, 1e-5], 320, 240),
+    "omnidir": ("omnidir", [110.0, 110.0, 160.0, 160.0, 1.0], [-0.02, 0.003, 1e-4, -2e-4], 320, 320),
+    "equirectangular": ("equirectangular", [384.0, 256.0], [], 384, 256),
+    "atan": ("atan", [210.0, 205.0, 160.0, 120.0], [0.6], 320, 240),
+    "rational_polynomial": ("rational_polynomial", [210.0, 205.0, 160.0, 120.0], [0.05, -0.02, 1e-4, -2e-4, 0.01, 0.03, -0.01, 0.002], 320, 240),
+}
+
+_scene_cache = {}
+
+
+def scene_for(name, n=30000, seed=11):
+    key = (name, n, seed)
+    if key not in _scene_cache:
+        _scene_cache[key] = synth.make_scene(CAMERAS[name], num_points=n, seed=seed)
+    return _scene_cache[key]
+
+
+def oracle_nid(s, bins, x, **kw):
+    return oracle_lib.nid_cost(s.model, s.intrinsics, s.distortion, s.image_f64, s.points, s.intensities, bins, x, **kw)
+
+
+@pytest.mark.parametrize("model", list(CAMERAS))
+def test_project_matches_oracle(model):
+    s = scene_for(model, n=2000)
+    proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
+    T = se3.to_matrix(s.T_camera_lidar_true)
+    pc = s.points[:, :3] @ T[:3, :3].T + T[:3, 3]
+    uv, jac = proj.project(pc, jacobian=True)
+    ruv, rjac = oracle_lib.project_jacobian(s.model, s.intrinsics, s.distortion, pc)
+    assert np.allclose(uv, ruv, rtol=1e-12, atol=1e-9)
+    assert np.allclose(jac, rjac, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("model", list(CAMERAS))
+@pytest.mark.parametrize("bins", [16, 256])
+def test_spline_value_gradient_histogram(model, bins):
+    s = scene_for(model)
+    proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
+    cost = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, bins)
+    assert cost.info()["float32_records"] == 1  # synthetic clouds are PLY-float32 representable
+    for x in (s.T_camera_lidar_init, s.T_camera_lidar_true):
+        ref = oracle_nid(s, bins, x, want_hist=True)
+        ok, c, g = cost(x)
+        assert ok and ref["ok"]
+        assert abs(c - ref["cost"]) <= 1e-10
+        assert np.allclose(g, ref["grad"], rtol=1e-7, atol=1e-10)
+        joint, hi, hp = cost.histograms()
+        assert np.abs(joint - ref["hist"]).max() <= 1e-9
+        assert np.abs(hi - ref["hist_image"]).max() <= 1e-8
+        assert np.array_equal(hp, ref["hist_points"])  # integer inlier counts per column
+        # cost-only instantiation (T = double) gives the same value
+        ok2, c2, g2 = cost(x, want_grad=False)
+        assert ok2 and g2 is None and c2 == c
+    cost.close()
+
+
+def test_spline_is_deterministic_and_tiling_independent():
+    """Fixed-point accumulation: the histogram (hence the cost) is bit-identical across repeated
+    runs, workgroup counts and column-group widths."""
+    s = scene_for("plumb_bob")
+    proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
+    x = s.T_camera_lidar_init
+    ref = None
+    for gw, tb in [(16, 0), (16, 37), (1, 64), (4, 500), (64, 8), (256, 16)]:
+        cost = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, 256, columns_per_group=gw, target_blocks=tb)
+        for _ in range(2):
+            ok, c, g = cost(x)
+            fx, inl, frac = cost.histogram_fixed()
+            if ref is None:
+                ref = (fx.copy(), inl, c)
+            assert np.array_equal(fx, ref[0]) and inl == ref[1]
+            assert c == ref[2]
+        cost.close()
+
+
+def test_spline_double_records_when_not_float_representable():
+    s = scene_for("plumb_bob", n=8000)
+    pts = s.points.copy()
+    pts[:, :3] += 1e-9 * np.arange(pts.shape[0])[:, None]  # no longer float32-exact
+    proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
+    cost = nid.NIDCost(proj, s.image_f64, pts, s.intensities, 16)
+    assert cost.info()["float32_records"] == 0 and cost.info()["record_bytes"] == 32
+    x = s.T_camera_lidar_init
+    ref = oracle_lib.nid_cost(s.model, s.intrinsics, s.distortion, s.image_f64, pts, s.intensities, 16, x)
+    ok, c, g = cost(x)
+    assert ok and abs(c - ref["cost"]) <= 1e-10
+    assert np.allclose(g, ref["grad"], rtol=1e-7, atol=1e-10)
+    cost.close()
+
+
+@pytest.mark.parametrize("model", ["plumb_bob", "fisheye", "omnidir", "equirectangular"])
+def test_spline_fp32_geometry_close(model):
+    s = scene_for(model)
+    proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
+    cost = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, 256, precision="fp32")
+    x = s.T_camera_lidar_init
+    ref = oracle_nid(s, 256, x)
+    ok, c, g = cost(x)
+    assert ok
+    assert abs(c - ref["cost"]) <= 2e-5
+    assert np.linalg.norm(g - ref["grad"]) <= 2e-2 * np.linalg.norm(ref["grad"])
+    cost.close()
+
+
+def test_spline_edge_cases():
+    s = scene_for("plumb_bob", n=5000)
+    proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
+    # (a) every point behind / outside: sum == 0 -> NaN -> functor returns false (nid_cost.hpp:98-102)
+    far = se3.compose(s.T_camera_lidar_true, np.array([0, 0, 0, 1, 0, 0, 500.0]))
+    x_out = se3.compose(np.array([0, 1.0, 0, 0, 0, 0, 0]), far)  # 180 deg about y then pushed away
+    cost = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, 16)
+    ref = oracle_nid(s, 16, x_out)
+    ok, c, g = cost(x_out)
+    assert ok == ref["ok"]
+    # (b) empty cloud
+    empty = nid.NIDCost(proj, s.image_f64, np.zeros((0, 4)), np.zeros(0), 16)
+    ok, c, g = empty(s.T_camera_lidar_true)
+    assert not ok
+    empty.close()
+    # (c) points exactly at the camera centre (division by zero in the projection) and NaNs
+    pts = s.points.copy()
+    Tinv = np.linalg.inv(se3.to_matrix(s.T_camera_lidar_true))
+    pts[0, :3] = Tinv[:3, 3]
+    pts[1, :3] = np.nan
+    ints = s.intensities.copy()
+    ints[2] = 1.5  # clamps to the last bin
+    ints[3] = -0.2  # clamps to bin 0
+    c2 = nid.NIDCost(proj, s.image_f64, pts, ints, 16)
+    ref = oracle_lib.nid_cost(s.model, s.intrinsics, s.distortion, s.image_f64, pts, ints, 16, s.T_camera_lidar_true, want_hist=True)
+    ok, c, g = c2(s.T_camera_lidar_true)
+    assert ok == ref["ok"] and abs(c - ref["cost"]) <= 1e-10
+    joint, hi, hp = c2.histograms()
+    assert np.array_equal(hp, ref["hist_points"])
+    c2.close()
+    # (d) unnormalised quaternion: the reference differentiates the un-normalised formula
+    xq = s.T_camera_lidar_init.copy()
+    xq[:4] *= 1.01
+    ref = oracle_nid(s, 16, xq)
+    ok, c, g = cost(xq)
+    assert ok == ref["ok"] and abs(c - ref["cost"]) <= 1e-10
+    assert np.allclose(g, ref["grad"], rtol=1e-7, atol=1e-10)
+    cost.close()
+
+
+def test_border_points_contribute_clamped_taps():
+    """Knots on the image border keep their 16 taps with clamped pixel coordinates
+    (nid_cost.hpp:70-73): a cloud projected onto the first/last rows and columns."""
+    model, intr, dist, W, H = CAMERAS["plumb_bob"]
+    s = scene_for("plumb_bob", n=4000)
+    rng = np.random.default_rng(3)
+    uv = np.stack([rng.uniform(0, W, 4000), rng.uniform(0, H, 4000)], -1)
+    uv[:1000, 0] = rng.uniform(0, 1, 1000)
+    uv[1000:2000, 0] = rng.uniform(W - 1, W, 1000)
+    uv[2000:3000, 1] = rng.uniform(0, 1, 1000)
+    uv[3000:, 1] = rng.uniform(H - 1, H, 1000)
+    import torch
+
+    from direct_visual_lidar_calibration_amd import camera_models
+
+    bear = camera_models.unproject(model, intr, dist, torch.tensor(uv)).numpy()
+    T = se3.to_matrix(s.T_camera_lidar_true)
+    pc = bear * rng.uniform(2.0, 9.0, (4000, 1))
+    pl = (pc - T[:3, 3]) @ T[:3, :3]
+    pts = np.concatenate([pl.astype(np.float32).astype(np.float64), np.ones((4000, 1))], -1)
+    ints = rng.integers(0, 256, 4000) / 256.0
+    proj = nid.create_camera(model, intr, dist)
+    cost = nid.NIDCost(proj, s.image_f64, pts, ints, 64)
+    ref = oracle_lib.nid_cost(model, intr, dist, s.image_f64, pts, ints, 64, s.T_camera_lidar_true, want_hist=True)
+    ok, c, g = cost(s.T_camera_lidar_true)
+    assert ok and abs(c - ref["cost"]) <= 1e-10
+    joint, _, hp = cost.histograms()
+    assert np.abs(joint - ref["hist"]).max() <= 1e-9
+    assert np.array_equal(hp, ref["hist_points"])
+    assert np.allclose(g, ref["grad"], rtol=1e-7, atol=1e-10)
+    cost.close()
+
+
+@pytest.mark.parametrize("model", list(CAMERAS))
+@pytest.mark.parametrize("bins", [16, 256])
+def test_nearest_integer_histogram_bit_exact(model, bins):
+    s = scene_for(model)
+    proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
+    max_fov = oracle_lib.estimate_camera_fov(s.model, s.intrinsics, s.distortion, s.width, s.height)
+    calc = nid.CostCalculatorNID(proj, s.image_u8, s.points, s.intensities, nid.NIDCostParams(bins), max_fov=max_fov)
+    rng = np.random.default_rng(5)
+    for k in range(3):
+        x = synth.random_pose_near(s.T_camera_lidar_true, rng) if k else s.T_camera_lidar_true
+        T = se3.to_matrix(x)
+        ref_cost, ref_hist = oracle_lib.cost_calculator_nid(s.model, s.intrinsics, s.distortion, s.image_u8, s.points, s.intensities, bins, max_fov, T, want_hist=True)
+        c = calc.calculate(T)
+        fx, inl, frac = calc.histogram_fixed()
+        assert frac == 0
+        assert np.array_equal(fx, ref_hist)
+        assert inl == ref_hist.sum()
+        assert abs(c - ref_cost) <= 1e-12
+    calc.close()
+
+
+def test_estimate_camera_fov_matches_oracle():
+    for model in ("plumb_bob", "fisheye", "omnidir"):
+        s = scene_for(model, n=2000)
+        proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
+        a = nid.estimate_camera_fov(proj, (s.width, s.height))
+        b = oracle_lib.estimate_camera_fov(s.model, s.intrinsics, s.distortion, s.width, s.height)
+        assert abs(a - b) < 1e-6
+
+
+def test_multi_nid_cost_sum_and_trust_gate():
+    s1 = scene_for("plumb_bob", n=12000, seed=21)
+    s2 = scene_for("plumb_bob", n=9000, seed=22)
+    proj = nid.create_camera(s1.model, s1.intrinsics, s1.distortion)
+    init = s1.T_camera_lidar_true
+    multi = nid.MultiNIDCost(init)
+    for s in (s1, s2):
+        multi.add(nid.NIDCost(proj, s.image_f64, s.points, s.intensities, 16))
+    pairs = [(s.image_f64, s.points, s.intensities) for s in (s1, s2)]
+    x = se3.plus(init, np.array([0.01, -0.02, 0.015, 0.004, -0.003, 0.002]))
+    ok, c, g = multi(x)
+    rok, rc, rg = oracle_lib.multi_nid_cost(s1.model, s1.intrinsics, s1.distortion, pairs, 16, init, x)
+    assert ok and rok and abs(c - rc) <= 2e-10 and np.allclose(g, rg, rtol=1e-7, atol=1e-10)
+    # outside the 0.2 m / 2 deg gate -> false without evaluating
+    for delta in ([0.25, 0, 0, 0, 0, 0], [0, 0, 0, 0, np.radians(2.5), 0]):
+        xg = se3.plus(init, np.array(delta, dtype=float))
+        ok, _, _ = multi(xg)
+        rok, _, _ = oracle_lib.multi_nid_cost(s1.model, s1.intrinsics, s1.distortion, pairs, 16, init, xg)
+        assert not ok and not rok
+    for c_ in multi.costs:
+        c_.close()
+
+
+def test_create_camera_error_behaviour():
+    assert nid.create_camera("no_such_model", [1, 2, 3, 4], []) is None
+    assert nid.create_camera("plumb_bob", [1, 2, 3], []) is None  # intrinsic count mismatch
+    cam = nid.create_camera("plumb_bob", [1, 2, 3, 4], [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7])  # truncated to 5
+    assert cam is not None and cam.distortion == [0.1, 0.2, 0.3, 0.4, 0.5]
+    assert nid.create_camera("equidistant", [1, 2, 3, 4], []).model_id == nid.create_camera("fisheye", [1, 2, 3, 4], [0]).model_id
+    with pytest.raises(RuntimeError):
+        s = scene_for("plumb_bob", n=2000)
+        proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
+        nid.NIDCost(proj, s.image_f64, s.points, s.intensities, 1000)  # bins > 256 unsupported
+
+
+def test_full_size_properties_cfg2_like():
+    """Size-independent properties at (a slice of) BASELINE config 2's shape: 1080p pinhole, 256
+    bins, 2M points: partition of unity (sum of the joint histogram == number of inliers, row sums ==
+    hist_image, column sums == hist_points), shard additivity of the fixed-point histogram, and a
+    central finite-difference check of the tangent gradient."""
+    s = synth.make_scene("pinhole_1080p", num_points=2_000_000, seed=20250525)
+    proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
+    x = s.T_camera_lidar_init
+    full = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, 256)
+    ok, c, g = full(x)
+    assert ok
+    fx, inl, frac = full.histogram_fixed()
+    joint, hi, hp = full.histograms()
+    unit = 2.0**frac
+    assert abs(fx.sum() / unit - inl) < 1e-3
+    assert np.allclose(fx.sum(1) / unit, hi, atol=1e-6)
+    assert np.array_equal(np.rint(fx.sum(0) / unit), hp) and hp.sum() == inl
+    # shards: histograms of disjoint point slices add up exactly (what the RCCL all-reduce relies on)
+    n = s.points.shape[0]
+    acc = np.zeros_like(fx)
+    acc_inl = 0
+    for a, b in ((0, n // 3), (n // 3, n)):
+        part = nid.NIDCost(proj, s.image_f64, s.points[a:b], s.intensities[a:b], 256)
+        part(x, want_grad=False)
+        pfx, pinl, pfrac = part.histogram_fixed()
+        assert pfrac == frac
+        acc += pfx
+        acc_inl += pinl
+        part.close()
+    assert acc_inl == inl
+    assert np.array_equal(acc, fx)  # integer fixed point: exactly additive
+    # finite differences on the 6-D tangent
+    J = se3.plus_jacobian(x)
+    gt = J.T @ g
+    h = 1e-6
+    for k in range(6):
+        e = np.zeros(6)
+        e[k] = h
+        _, cp, _ = full(se3.plus(x, e), want_grad=False)
+        _, cm, _ = full(se3.plus(x, -e), want_grad=False)
+        fd = (cp - cm) / (2 * h)
+        assert abs(fd - gt[k]) <= 2e-4 * max(1.0, abs(gt[k])), (k, fd, gt[k])
+    full.close()
