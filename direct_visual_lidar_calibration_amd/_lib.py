@@ -8,7 +8,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC_DIR, "libnidreg.so")
+# NIDREG_LIB lets development tools (tools/ablate.py) load an instrumented build of the same ABI
+LIB_PATH = os.environ.get("NIDREG_LIB", os.path.join(CSRC_DIR, "libnidreg.so"))
 
 NIDREG_OK = 0
 NIDREG_FALSE = 1

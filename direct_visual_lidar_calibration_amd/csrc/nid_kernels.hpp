@@ -19,6 +19,7 @@ namespace nidreg {
 
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
+constexpr int kUnroll = 4;  // point records in flight per thread
 
 // tail words behind the B*B joint histogram
 constexpr int kTailInliers = 0;  // number of inlier points (plain count)
@@ -43,7 +44,9 @@ __device__ __forceinline__ double wave_sum(double v) {
 // ------------------------------------------------------------------------------------------
 // pass A (SPLINE): joint histogram with bicubic B-spline soft assignment.
 // LDS: tile[GW*B] u64 (this workgroup's GW histogram columns) + 1 u32 inlier counter.
-template <int MODEL, typename Rec, typename real>
+// ABL (development builds only, -DNID_ABLATE): bit0 = no LDS atomics, bit1 = no image loads,
+// bit2 = no projection, bit3 = no flush -- phase ablation for profiling (cdna_hip_programming.md 5.4).
+template <int MODEL, typename Rec, typename real, int ABL = 0>
 __global__ __launch_bounds__(kThreads) void k_spline_hist(
   const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint8_t* __restrict__ img, int pitch, int W, int H, PoseParams<real> pose, CamParams<real> cam, int B,
   int GW, double magic, u64* __restrict__ hist) {
@@ -61,16 +64,34 @@ __global__ __launch_bounds__(kThreads) void k_spline_hist(
   const real fW = real(W), fH = real(H);
   const uint32_t col0 = ch.group * uint32_t(GW);
   unsigned int inl = 0;
+  u64 abl_acc = 0;
 
-  for (uint32_t i = tid; i < ch.count; i += kThreads) {
-    real x, y, z;
-    uint32_t bin;
-    load_rec<real>(pts + ch.start + i, x, y, z, bin);
+  // kUnroll records per thread are fetched before any of them is processed: one 16-B load per wave
+  // in flight is latency bound (measured 1.45 TB/s); four keep ~64 KB per CU outstanding
+  for (uint32_t base = 0; base < ch.count; base += kThreads * kUnroll) {
+    real xs[kUnroll], ys[kUnroll], zs[kUnroll];
+    uint32_t bins_[kUnroll];
+#pragma unroll
+    for (int k = 0; k < kUnroll; k++) {
+      const uint32_t ii = min(base + uint32_t(k) * kThreads + tid, ch.count - 1u);
+      load_rec<real>(pts + ch.start + ii, xs[k], ys[k], zs[k], bins_[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < kUnroll; k++) {
+    const uint32_t i = base + uint32_t(k) * kThreads + tid;
+    if (i >= ch.count) break;
+    const real x = xs[k], y = ys[k], z = zs[k];
+    const uint32_t bin = bins_[k];
     const real cx = ((pose.R[0] * x + pose.R[1] * y) + pose.R[2] * z) + pose.t[0];
     const real cy = ((pose.R[3] * x + pose.R[4] * y) + pose.R[5] * z) + pose.t[1];
     const real cz = ((pose.R[6] * x + pose.R[7] * y) + pose.R[8] * z) + pose.t[2];
     real u, v;
-    project<MODEL, real, real>(cam, cx, cy, cz, u, v);
+    if (ABL & 4) {
+      u = real((bin * 7919u + i * 31u) % uint32_t(W)) + real(0.37) + cx * real(1e-9);
+      v = real((bin * 104729u + i * 17u) % uint32_t(H)) + real(0.61) + cy * real(1e-9) + cz * real(1e-9);
+    } else {
+      project<MODEL, real, real>(cam, cx, cy, cz, u, v);
+    }
     // floor(u) in [0,W) and floor(v) in [0,H); NaN / inf / overflow compare false -> outlier
     // (the reference's int conversion sends those to INT_MIN, nid_cost.hpp:52-58)
     const bool in = (u >= real(0)) && (u < fW) && (v >= real(0)) && (v < fH);
@@ -87,14 +108,18 @@ __global__ __launch_bounds__(kThreads) void k_spline_hist(
       const uint8_t* p0 = img + size_t(ky) * size_t(pitch) + size_t(kx);
 #pragma unroll
       for (int b = 0; b < 4; b++) {
-        const uint32_t px4 = load_u8x4(p0 + size_t(b) * size_t(pitch));
+        const uint32_t px4 = (ABL & 2) ? (uint32_t(kx + b) * 2654435761u) ^ (uint32_t(ky) * 40503u) : load_u8x4(p0 + size_t(b) * size_t(pitch));
 #pragma unroll
         for (int a = 0; a < 4; a++) {
-          const uint32_t r = (px4 >> (8 * a)) & 0xffu;
+          const uint32_t r = ((px4 >> (8 * a)) & 0xffu) % uint32_t((ABL & 2) ? B : 256);
           const real w = bx[a] * by[b];
-          atomicAdd(&col[r], to_fixed(double(w), magic));  // ds_add_u64
+          if (ABL & 1)
+            abl_acc += to_fixed(double(w), magic) + r;
+          else
+            atomicAdd(&col[r], to_fixed(double(w), magic));  // ds_add_u64
         }
       }
+    }
     }
   }
 
@@ -107,10 +132,13 @@ __global__ __launch_bounds__(kThreads) void k_spline_hist(
 
   // flush the tile: contiguous in the [bin_points][bin_image] device layout
   u64* dst = hist + size_t(ch.group) * size_t(tile_n);
-  for (int k = tid; k < tile_n; k += kThreads) {
-    const u64 vv = tile[k];
-    if (vv) atomicAdd(&dst[k], vv);
+  if (!(ABL & 8)) {
+    for (int k = tid; k < tile_n; k += kThreads) {
+      const u64 vv = tile[k];
+      if (vv) atomicAdd(&dst[k], vv);
+    }
   }
+  if (ABL && abl_acc == 0x123456789abcull) dst[0] = abl_acc;  // keeps ablated values live
   if (tid == 0 && *s_inl) atomicAdd(&hist[size_t(B) * size_t(B) + kTailInliers], u64(*s_inl));
 }
 
@@ -138,26 +166,39 @@ __global__ __launch_bounds__(kThreads) void k_nearest_hist(
   const uint32_t col0 = ch.group * uint32_t(GW);
   unsigned int inl = 0;
 
-  for (uint32_t i = tid; i < ch.count; i += kThreads) {
-    real x, y, z;
-    uint32_t bin;
-    load_rec<real>(pts + ch.start + i, x, y, z, bin);
+  // kUnroll records per thread are fetched before any of them is processed: one 16-B load per wave
+  // in flight is latency bound (measured 1.45 TB/s); four keep ~64 KB per CU outstanding
+  for (uint32_t base = 0; base < ch.count; base += kThreads * kUnroll) {
+    real xs[kUnroll], ys[kUnroll], zs[kUnroll];
+    uint32_t bins_[kUnroll];
+#pragma unroll
+    for (int k = 0; k < kUnroll; k++) {
+      const uint32_t ii = min(base + uint32_t(k) * kThreads + tid, ch.count - 1u);
+      load_rec<real>(pts + ch.start + ii, xs[k], ys[k], zs[k], bins_[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < kUnroll; k++) {
+    const uint32_t i = base + uint32_t(k) * kThreads + tid;
+    if (i >= ch.count) break;
+    const real x = xs[k], y = ys[k], z = zs[k];
+    const uint32_t bin = bins_[k];
     // Eigen 4x4 * (x y z 1): ((m0 x + m1 y) + m2 z) + m3 * 1
     const real cx = ((iso.m[0] * x + iso.m[1] * y) + iso.m[2] * z) + iso.m[3];
     const real cy = ((iso.m[4] * x + iso.m[5] * y) + iso.m[6] * z) + iso.m[7];
     const real cz = ((iso.m[8] * x + iso.m[9] * y) + iso.m[10] * z) + iso.m[11];
     const real n2 = (cx * cx + cy * cy) + cz * cz;
     const real zn = n2 > real(0) ? cz / m_sqrt(n2) : cz;
-    if (zn < cos_fov) continue;  // out of FoV (cost_calculator_nid.cpp:32)
+    const bool in_fov = !(zn < cos_fov);  // out of FoV otherwise (cost_calculator_nid.cpp:32)
     real u, v;
     project<MODEL, real, real>(cam, cx, cy, cz, u, v);
     // trunc(u) in [0,W)  <=>  -1 < u < W ; NaN false (cost_calculator_nid.cpp:37-41)
-    const bool in = (u > real(-1)) && (u < fW) && (v > real(-1)) && (v < fH);
+    const bool in = in_fov && (u > real(-1)) && (u < fW) && (v > real(-1)) && (v < fH);
     if (in) {
       inl++;
       const int px = int(u), py = int(v);  // truncation toward zero
       const uint32_t r = img[size_t(py + 1) * size_t(pitch) + size_t(px + 1)];
       atomicAdd(&tile[(bin - col0) * uint32_t(B) + r], u64(1));
+    }
     }
   }
 
@@ -289,7 +330,8 @@ __global__ __launch_bounds__(kThreads) void k_entropy_final(
 // Per point: (gx, gy) = sum_taps G * d(w_tap)/d(u, v); gp = (gx gy) * d(uv)/d(p_cam) (Dual3
 // projection); accumulate M += gp p^T (3x3) and gt += gp (3).  One 12-double partial per workgroup.
 // LDS: gtile[GW*B] doubles + kWaves*12 doubles.
-template <int MODEL, typename Rec, typename real>
+// ABL bits (development builds): bit0 = no G-tile LDS reads, bit1 = no image loads, bit2 = no projection.
+template <int MODEL, typename Rec, typename real, int ABL = 0>
 __global__ __launch_bounds__(kThreads) void k_spline_grad(
   const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint8_t* __restrict__ img, int pitch, int W, int H, PoseParams<real> pose, CamParams<real> cam, int B,
   int GW, double inv_unit, const u64* __restrict__ hist, const double* __restrict__ phi_q, const EntropyScalars* __restrict__ scal, double* __restrict__ partials) {
@@ -320,15 +362,32 @@ __global__ __launch_bounds__(kThreads) void k_spline_grad(
   for (int k = 0; k < 12; k++) acc[k] = 0.0;
 
   typedef Dual3<real> D;
-  for (uint32_t i = tid; i < ch.count; i += kThreads) {
-    real x, y, z;
-    uint32_t bin;
-    load_rec<real>(pts + ch.start + i, x, y, z, bin);
+  // kUnroll records per thread are fetched before any of them is processed: one 16-B load per wave
+  // in flight is latency bound (measured 1.45 TB/s); four keep ~64 KB per CU outstanding
+  for (uint32_t base = 0; base < ch.count; base += kThreads * kUnroll) {
+    real xs[kUnroll], ys[kUnroll], zs[kUnroll];
+    uint32_t bins_[kUnroll];
+#pragma unroll
+    for (int k = 0; k < kUnroll; k++) {
+      const uint32_t ii = min(base + uint32_t(k) * kThreads + tid, ch.count - 1u);
+      load_rec<real>(pts + ch.start + ii, xs[k], ys[k], zs[k], bins_[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < kUnroll; k++) {
+    const uint32_t i = base + uint32_t(k) * kThreads + tid;
+    if (i >= ch.count) break;
+    const real x = xs[k], y = ys[k], z = zs[k];
+    const uint32_t bin = bins_[k];
     const real cx = ((pose.R[0] * x + pose.R[1] * y) + pose.R[2] * z) + pose.t[0];
     const real cy = ((pose.R[3] * x + pose.R[4] * y) + pose.R[5] * z) + pose.t[1];
     const real cz = ((pose.R[6] * x + pose.R[7] * y) + pose.R[8] * z) + pose.t[2];
     D u, v;
-    project<MODEL, D, real>(cam, D(cx, real(1), real(0), real(0)), D(cy, real(0), real(1), real(0)), D(cz, real(0), real(0), real(1)), u, v);
+    if (ABL & 4) {
+      u = D(real((bin * 7919u + i * 31u) % uint32_t(W)) + real(0.37) + cx * real(1e-9), real(1), real(0.5), real(0.25));
+      v = D(real((bin * 104729u + i * 17u) % uint32_t(H)) + real(0.61) + cy * real(1e-9) + cz * real(1e-9), real(0.5), real(1), real(0.25));
+    } else {
+      project<MODEL, D, real>(cam, D(cx, real(1), real(0), real(0)), D(cy, real(0), real(1), real(0)), D(cz, real(0), real(0), real(1)), u, v);
+    }
     const bool in = (u.a >= real(0)) && (u.a < fW) && (v.a >= real(0)) && (v.a < fH);
     if (in) {
       const real fu = m_floor(u.a), fv = m_floor(v.a);
@@ -343,11 +402,12 @@ __global__ __launch_bounds__(kThreads) void k_spline_grad(
       real gx = real(0), gy = real(0);
 #pragma unroll
       for (int b = 0; b < 4; b++) {
-        const uint32_t px4 = load_u8x4(p0 + size_t(b) * size_t(pitch));
+        const uint32_t px4 = (ABL & 2) ? (uint32_t(kx + b) * 2654435761u) ^ (uint32_t(ky) * 40503u) : load_u8x4(p0 + size_t(b) * size_t(pitch));
         real sa = real(0), sb = real(0);
 #pragma unroll
         for (int a = 0; a < 4; a++) {
-          const real g = real(gcol[(px4 >> (8 * a)) & 0xffu]);
+          const uint32_t r = ((px4 >> (8 * a)) & 0xffu) % uint32_t((ABL & 2) ? B : 256);
+          const real g = (ABL & 1) ? real(r) * real(1e-3) : real(gcol[r]);
           sa += g * dbx[a];
           sb += g * bx[a];
         }
@@ -370,6 +430,7 @@ __global__ __launch_bounds__(kThreads) void k_spline_grad(
       acc[9] += gp0;
       acc[10] += gp1;
       acc[11] += gp2;
+    }
     }
   }
 

@@ -290,15 +290,19 @@ def test_full_size_properties_cfg2_like():
         part.close()
     assert acc_inl == inl
     assert np.array_equal(acc, fx)  # integer fixed point: exactly additive
-    # finite differences on the 6-D tangent
-    J = se3.plus_jacobian(x)
-    gt = J.T @ g
+    # finite differences on the 6-D tangent, at a pose where every point is >= 1 px inside the
+    # image (the inlier test makes NID discontinuous where points cross the border, which central
+    # differences see and the Jet / analytic gradient by construction does not)
+    xs = se3.plus(s.T_camera_lidar_true, np.array([4e-4, -3e-4, 5e-4, 2e-4, -1.5e-4, 1e-4]))
+    ok, c, g = full(xs)
+    assert ok and full.histogram_fixed()[1] == n
+    gt = se3.plus_jacobian(xs).T @ g
     h = 1e-6
     for k in range(6):
         e = np.zeros(6)
         e[k] = h
-        _, cp, _ = full(se3.plus(x, e), want_grad=False)
-        _, cm, _ = full(se3.plus(x, -e), want_grad=False)
+        _, cp, _ = full(se3.plus(xs, e), want_grad=False)
+        _, cm, _ = full(se3.plus(xs, -e), want_grad=False)
         fd = (cp - cm) / (2 * h)
-        assert abs(fd - gt[k]) <= 2e-4 * max(1.0, abs(gt[k])), (k, fd, gt[k])
+        assert abs(fd - gt[k]) <= 1e-4 * max(1.0, abs(gt[k])), (k, fd, gt[k])
     full.close()

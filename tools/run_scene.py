@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""torch-free driver: load a cached scene (.npz), run K cost+Jacobian evaluations through the C ABI and
+print per-kernel HIP-event times.  Meant to be wrapped by rocprofv3 (--kernel-trace / --pmc).
+Usage: run_scene.py scene.npz [steps] [precision] [bins] [gw] [target_blocks]"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from direct_visual_lidar_calibration_amd import nid, se3  # noqa: E402
+
+z = np.load(sys.argv[1])
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+prec = sys.argv[3] if len(sys.argv) > 3 else "fp64"
+bins = int(sys.argv[4]) if len(sys.argv) > 4 else 256
+gw = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+tb = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+pts = z["points"].astype(np.float64)
+ints = z["intensities"].astype(np.float64)
+proj = nid.create_camera(str(z["model"]), list(z["intrinsics"]), list(z["distortion"]))
+img64 = z["image_u8"].astype(np.float64) * (1.0 / 255.0)
+cost = nid.NIDCost(proj, img64, pts, ints, bins, precision=prec, columns_per_group=gw, target_blocks=tb)
+cost.set_timing(True)
+rng = np.random.default_rng(1)
+acc = {}
+for k in range(steps):
+    d = rng.uniform(-1, 1, 6) * np.array([0.05, 0.05, 0.05, np.radians(0.5), np.radians(0.5), np.radians(0.5)])
+    ok, c, g = cost(se3.plus(z["T_true"], d))
+    if k >= 2:
+        for key, v in cost.timing_ms().items():
+            acc.setdefault(key, []).append(v)
+print(json.dumps({"prec": prec, "bins": bins, "info": cost.info(), "kernel_ms": {k: round(float(np.mean(v)), 4) for k, v in acc.items()}, "last_cost": c}))
