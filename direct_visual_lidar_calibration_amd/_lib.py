@@ -47,6 +47,7 @@ class NidregDesc(ctypes.Structure):
         ("max_fov", ctypes.c_double),
         ("columns_per_group", ctypes.c_int32),
         ("target_blocks", ctypes.c_int32),
+        ("scale_points", ctypes.c_int64),
         ("ext_stream", ctypes.c_void_p),
         ("ext_hist", ctypes.c_void_p),
         ("ext_out", ctypes.c_void_p),

@@ -374,8 +374,9 @@ int nidreg_create(const nidreg_desc* d, nidreg_handle** out) {
   h->lds_entropy = size_t(B) * 8 + size_t(GW) * 8 + size_t(kWaves) * 8;
 
   // ---- fixed point: sum over a bin <= N * 2^frac must stay below 2^63
+  const int64_t scaleN = std::max<int64_t>(N, d->scale_points);
   int nbits = 1;
-  while ((int64_t(1) << nbits) <= N) nbits++;
+  while ((int64_t(1) << nbits) <= scaleN) nbits++;
   h->frac_bits = d->mode == NIDREG_MODE_NEAREST ? 0 : std::min(40, 62 - nbits);
 
   // ---- bin image, padded by 1 (left/top) and >= 2 (right/bottom), edge replicated:

@@ -93,7 +93,7 @@ def _prec(precision):
 class _Handle:
     """RAII owner of one ``nidreg_handle`` (device residency of one LiDAR-camera pair)."""
 
-    def __init__(self, proj, image, points, intensities, bins, mode, precision, device, max_fov=0.0, columns_per_group=0, target_blocks=0, ext_stream=None, ext_hist=None, ext_out=None):
+    def __init__(self, proj, image, points, intensities, bins, mode, precision, device, max_fov=0.0, columns_per_group=0, target_blocks=0, scale_points=0, ext_stream=None, ext_hist=None, ext_out=None):
         if proj is None:
             raise ValueError("camera is None (create_camera failed)")
         lib = _lib.load()
@@ -132,6 +132,7 @@ class _Handle:
         d.max_fov = float(max_fov)
         d.columns_per_group = int(columns_per_group)
         d.target_blocks = int(target_blocks)
+        d.scale_points = int(scale_points)
         d.ext_stream = ext_stream
         d.ext_hist = ext_hist
         d.ext_out = ext_out

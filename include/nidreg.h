@@ -96,6 +96,8 @@ typedef struct nidreg_desc {
   /* tuning (0 = default) */
   int32_t columns_per_group;/* histogram columns (bin_points values) a workgroup owns in LDS */
   int32_t target_blocks;    /* approximate number of point chunks = workgroups per pass */
+  int64_t scale_points;     /* points the fixed-point scale must hold (0 = num_points); shards of one
+                               pair pass the TOTAL so that every rank uses the same 2^-frac unit */
   /* optional externally owned device resources (sharded multi-GPU use); NULL = internal */
   void* ext_stream;         /* hipStream_t the handle launches on */
   void* ext_hist;           /* device buffer of nidreg_hist_words(bins) 64-bit words */

@@ -1,0 +1,75 @@
+// camera.hpp -- camera::create_camera / camera::GenericCameraBase with the reference's interface
+// (include/camera/generic_camera_base.hpp:18-41, include/camera/create_camera.hpp:14,
+// src/camera/create_camera.cpp:17-51), extended by the three accessors a GPU cost function needs
+// (the reference hides model and parameters inside GenericCamera<Projection>, generic_camera.hpp:35-37).
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#ifdef NIDREG_WITH_REFERENCE_DEPS
+#include <Eigen/Core>
+#include <ceres/jet.h>
+#else
+#include "standins.hpp"
+#endif
+#include "../nidreg.h"
+
+namespace camera {
+
+class GenericCameraBase {
+public:
+  using Ptr = std::shared_ptr<GenericCameraBase>;
+  using ConstPtr = std::shared_ptr<const GenericCameraBase>;
+  virtual ~GenericCameraBase() {}
+
+  // generic_camera_base.hpp:29,34 -- evaluated by the device projection code (one call = one
+  // kernel launch: fine for set-up code such as estimate_camera_fov, not for per-point loops)
+  virtual Eigen::Vector2d project(const Eigen::Vector3d& point_3d) const = 0;
+  virtual Eigen::Vector2d operator()(const Eigen::Vector3d& point_3d) const = 0;
+
+  // additions
+  virtual int nidreg_model_id() const = 0;
+  virtual const double* nidreg_intrinsics() const = 0;  // 5 doubles, zero padded
+  virtual const double* nidreg_distortion() const = 0;  // 8 doubles, zero padded
+};
+
+class NidregCamera : public GenericCameraBase {
+public:
+  NidregCamera(int model_id, const std::vector<double>& intrinsics, const std::vector<double>& distortion) : model_id(model_id) {
+    for (int i = 0; i < 5; i++) intr[i] = i < int(intrinsics.size()) ? intrinsics[i] : 0.0;
+    for (int i = 0; i < 8; i++) dist[i] = i < int(distortion.size()) ? distortion[i] : 0.0;
+  }
+  Eigen::Vector2d project(const Eigen::Vector3d& p) const override { return (*this)(p); }
+  Eigen::Vector2d operator()(const Eigen::Vector3d& p) const override {
+    const double p3[3] = {p[0], p[1], p[2]};
+    double uv[2] = {0.0, 0.0};
+    nidreg_project_model(model_id, intr, dist, 0, NIDREG_PREC_FP64, p3, 1, uv, nullptr);
+    Eigen::Vector2d r;
+    r[0] = uv[0];
+    r[1] = uv[1];
+    return r;
+  }
+  int nidreg_model_id() const override { return model_id; }
+  const double* nidreg_intrinsics() const override { return intr; }
+  const double* nidreg_distortion() const override { return dist; }
+
+private:
+  int model_id;
+  double intr[5];
+  double dist[8];
+};
+
+// create_camera.cpp:34-51: nullptr on unknown model or intrinsic-count mismatch (:19-22); distortion
+// zero-padded / truncated to the model's count (:24-27)
+inline GenericCameraBase::ConstPtr create_camera(const std::string& camera_model, const std::vector<double>& intrinsics, const std::vector<double>& distortion_coeffs) {
+  int ni = 0, nd = 0;
+  const int id = nidreg_model_from_name(camera_model.c_str(), &ni, &nd);
+  if (id < 0) return nullptr;
+  if (int(intrinsics.size()) != ni) return nullptr;
+  std::vector<double> dist(nd, 0.0);
+  for (int i = 0; i < nd && i < int(distortion_coeffs.size()); i++) dist[i] = distortion_coeffs[i];
+  return std::make_shared<NidregCamera>(id, intrinsics, dist);
+}
+
+}  // namespace camera

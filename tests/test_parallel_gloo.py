@@ -1,0 +1,143 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU protocol: the all-reduce of per-shard FIXED-POINT
+histograms + the entropy tail on the sum reproduces the unsharded evaluation exactly, and the
+pair-parallel sum matches MultiNIDCost.  The compute backend here is a stand-in built on the CPU
+oracle (test infrastructure) -- the collectives, slicing and protocol are the product code."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FRAC = 38
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class OracleShardBackend:
+    """Stand-in for one GPU shard: histogram partial from the oracle, quantised to the same 2^-FRAC
+    fixed point the kernels use; entropy tail and dNID/dh in numpy (DESIGN.md formulas)."""
+
+    def __init__(self, scene, lo, hi, bins):
+        import oracle_lib
+
+        self.ol = oracle_lib
+        self.s = scene
+        self.lo, self.hi, self.B = lo, hi, bins
+        self.hist_tensor = torch.zeros(bins * bins + 8, dtype=torch.int64)
+        self.grad_tensor = torch.zeros(7, dtype=torch.float64)
+
+    def shard_hist(self, x):
+        s = self.s
+        r = self.ol.nid_cost(s.model, s.intrinsics, s.distortion, s.image_f64, s.points[self.lo:self.hi], s.intensities[self.lo:self.hi], self.B, x, want_hist=True,
+                             want_hist_grad=True)
+        self.hist_grad = r["hist_grad"]
+        fx = np.rint(r["hist"] * 2.0**FRAC).astype(np.int64)
+        self.hist_tensor[: self.B * self.B] = torch.from_numpy(fx.reshape(-1))
+        self.hist_tensor[self.B * self.B] = int(r["hist_points"].sum())
+
+    def shard_entropy(self):
+        B = self.B
+        h = self.hist_tensor[: B * B].numpy().reshape(B, B).astype(np.float64) / 2.0**FRAC
+        S = float(self.hist_tensor[B * B])
+        pj, pi = h / S, h.sum(1) / S
+        pp = np.rint(h.sum(0)) / S
+        eps = 1e-6
+        Hi, Hp, Hj = -(pi * np.log(pi + eps)).sum(), -(pp * np.log(pp + eps)).sum(), -(pj * np.log(pj + eps)).sum()
+        self.cost = (Hj - (Hi + Hp - Hj)) / Hj
+        phi = lambda p: np.log(p + eps) + p / (p + eps)  # noqa: E731
+        self.G = (-(Hi + Hp) / Hj**2 * phi(pj) + phi(pi)[:, None] / Hj) / S
+
+    def shard_grad(self):
+        self.grad_tensor[:] = torch.from_numpy((self.hist_grad * self.G[None]).sum((1, 2)))
+
+    def shard_finish(self, want_grad):
+        return bool(np.isfinite(self.cost)), float(self.cost), (self.grad_tensor.numpy().copy() if want_grad else None)
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)  # two workers sharing the host: avoid OpenMP oversubscription
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle_lib
+        from direct_visual_lidar_calibration_amd import parallel, synth
+        from test_gpu_parity import CAMERAS
+
+        s = synth.make_scene(CAMERAS["plumb_bob"], num_points=9001, seed=77)  # odd size: ragged shards
+        x = s.T_camera_lidar_init
+        B = 32
+        lo, hi = parallel.shard_slice(s.points.shape[0], rank, world)
+        ev = parallel.ShardedEvaluator(OracleShardBackend(s, lo, hi, B))
+        ok, c, g = ev(x)
+        ref = oracle_lib.nid_cost(s.model, s.intrinsics, s.distortion, s.image_f64, s.points, s.intensities, B, x)
+        ok2, c2, g2 = ev(x, want_grad=False)
+
+        # pair-parallel: two different pairs, one per rank
+        class OneOraclePair:
+            def __init__(self, seed):
+                self.s = synth.make_scene(CAMERAS["plumb_bob"], num_points=3000, seed=seed)
+
+            def __call__(self, xx, want_grad=True):
+                r = oracle_lib.nid_cost(self.s.model, self.s.intrinsics, self.s.distortion, self.s.image_f64, self.s.points, self.s.intensities, 16, xx, want_grad=want_grad)
+                return r["ok"], r["cost"], r["grad"]
+
+        pp = parallel.PairParallelNIDCost(OneOraclePair(500 + rank), 1)
+        okp, cp, gp = pp(x)
+        tot_c, tot_g = 0.0, np.zeros(7)
+        for k in range(world):
+            okk, ck, gk = OneOraclePair(500 + k)(x)
+            tot_c += ck
+            tot_g += gk
+        q.put((rank, lo, hi, ok, c, g, ref["cost"], ref["grad"], c2, g2 is None, cp, gp, tot_c, tot_g))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_protocol_world2():
+    world = 2
+    os.environ["OMP_NUM_THREADS"] = "1"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    res.sort(key=lambda t: t[0])
+    assert res[0][1] == 0 and res[0][2] == res[1][1] and res[1][2] == 9001  # disjoint, exhaustive
+    for rank, lo, hi, ok, c, g, rc, rg, c2, g2none, cp, gp, tot_c, tot_g in res:
+        assert ok
+        assert abs(c - rc) < 1e-9  # fixed-point quantisation only
+        assert np.allclose(g, rg, rtol=1e-6, atol=1e-9)
+        assert c2 == c and g2none
+        assert abs(cp - tot_c) < 1e-12 and np.allclose(gp, tot_g, rtol=1e-12, atol=1e-14)
+    # every rank computed bit-identical results from the same all-reduced integers
+    assert res[0][4] == res[1][4] and np.array_equal(res[0][5], res[1][5])
+
+
+def test_shard_slices_cover_everything():
+    from direct_visual_lidar_calibration_amd import parallel
+
+    for n in (0, 1, 7, 1000, 10_000_001):
+        for w in (1, 2, 3, 8):
+            sl = [parallel.shard_slice(n, r, w) for r in range(w)]
+            assert sl[0][0] == 0 and sl[-1][1] == n
+            assert all(sl[i][1] == sl[i + 1][0] for i in range(w - 1))
+            assert max(b - a for a, b in sl) - min(b - a for a, b in sl) <= 1
