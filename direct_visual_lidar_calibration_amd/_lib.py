@@ -18,6 +18,7 @@ NIDREG_OUT_DOUBLES = 16
 MODE_SPLINE, MODE_NEAREST = 0, 1
 PREC_FP64, PREC_FP32 = 0, 1
 IMAGE_F64, IMAGE_U8 = 0, 1
+FLAG_SPATIAL_ORDER = 1
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int64_p = ctypes.POINTER(ctypes.c_int64)
@@ -37,7 +38,7 @@ class NidregDesc(ctypes.Structure):
         ("width", ctypes.c_int32),
         ("height", ctypes.c_int32),
         ("image_dtype", ctypes.c_int32),
-        ("reserved0", ctypes.c_int32),
+        ("flags", ctypes.c_int32),
         ("image", ctypes.c_void_p),
         ("image_row_stride", ctypes.c_int64),
         ("num_points", ctypes.c_int64),
@@ -47,6 +48,8 @@ class NidregDesc(ctypes.Structure):
         ("max_fov", ctypes.c_double),
         ("columns_per_group", ctypes.c_int32),
         ("target_blocks", ctypes.c_int32),
+        ("lds_copies", ctypes.c_int32),
+        ("reserved1", ctypes.c_int32),
         ("scale_points", ctypes.c_int64),
         ("ext_stream", ctypes.c_void_p),
         ("ext_hist", ctypes.c_void_p),

@@ -64,14 +64,14 @@ template <typename real> __device__ __forceinline__ NID_D operator-(const NID_D&
 template <typename real> __device__ __forceinline__ NID_D operator-(real s, const NID_D& f) { return NID_D(s - f.a, -f.d0, -f.d1, -f.d2); }
 template <typename real> __device__ __forceinline__ NID_D operator-(const NID_D& f) { return NID_D(-f.a, -f.d0, -f.d1, -f.d2); }
 template <typename real> __device__ __forceinline__ NID_D operator*(const NID_D& f, const NID_D& g) {
-  return NID_D(f.a * g.a, f.a * g.d0 + f.d0 * g.a, f.a * g.d1 + f.d1 * g.a, f.a * g.d2 + f.d2 * g.a);
+  return NID_D(f.a * g.a, fma(f.a, g.d0, f.d0 * g.a), fma(f.a, g.d1, f.d1 * g.a), fma(f.a, g.d2, f.d2 * g.a));
 }
 template <typename real> __device__ __forceinline__ NID_D operator*(const NID_D& f, real s) { return NID_D(f.a * s, f.d0 * s, f.d1 * s, f.d2 * s); }
 template <typename real> __device__ __forceinline__ NID_D operator*(real s, const NID_D& f) { return NID_D(f.a * s, f.d0 * s, f.d1 * s, f.d2 * s); }
 template <typename real> __device__ __forceinline__ NID_D operator/(const NID_D& f, const NID_D& g) {
   const real gi = real(1) / g.a;
   const real q = f.a * gi;
-  return NID_D(q, (f.d0 - q * g.d0) * gi, (f.d1 - q * g.d1) * gi, (f.d2 - q * g.d2) * gi);
+  return NID_D(q, fma(-q, g.d0, f.d0) * gi, fma(-q, g.d1, f.d1) * gi, fma(-q, g.d2, f.d2) * gi);
 }
 template <typename real> __device__ __forceinline__ NID_D operator/(const NID_D& f, real s) {
   const real si = real(1) / s;
@@ -85,8 +85,8 @@ template <typename real> __device__ __forceinline__ NID_D m_sqrt(const NID_D& f)
   return NID_D(t, f.d0 * k, f.d1 * k, f.d2 * k);
 }
 template <typename real> __device__ __forceinline__ NID_D m_atan2(const NID_D& g, const NID_D& f) {
-  const real k = real(1) / (f.a * f.a + g.a * g.a);
-  return NID_D(m_atan2(g.a, f.a), k * (-g.a * f.d0 + f.a * g.d0), k * (-g.a * f.d1 + f.a * g.d1), k * (-g.a * f.d2 + f.a * g.d2));
+  const real k = real(1) / fma(f.a, f.a, g.a * g.a);
+  return NID_D(m_atan2(g.a, f.a), k * fma(-g.a, f.d0, f.a * g.d0), k * fma(-g.a, f.d1, f.a * g.d1), k * fma(-g.a, f.d2, f.a * g.d2));
 }
 template <typename real> __device__ __forceinline__ NID_D m_asin(const NID_D& f) {
   const real k = real(1) / m_sqrt(real(1) - f.a * f.a);
@@ -268,36 +268,50 @@ struct Chunk {  // one workgroup's slice of the bucketed cloud
 // evaluated as C * [1 s s^2 s^3]^T in the same term order
 template <typename real>
 __device__ __forceinline__ void bspline(real s, real* b) {
+  // explicit fma: all translation units are built with -ffp-contract=off so that every point gets
+  // the same arithmetic no matter which unrolled slot / chunk / GPU processes it (the histogram is
+  // bit-identical across tilings); the fusions we want are therefore written out
   const real s2 = s * s, s3 = s2 * s;
-  const real k16 = real(1.0 / 6.0), k36 = real(3.0 / 6.0), k46 = real(4.0 / 6.0), k66 = real(6.0 / 6.0);
-  b[0] = ((k16 - k36 * s) + k36 * s2) - k16 * s3;
-  b[1] = (k46 - k66 * s2) + k36 * s3;
-  b[2] = ((k16 + k36 * s) + k36 * s2) - k36 * s3;
+  const real k16 = real(1.0 / 6.0), k36 = real(3.0 / 6.0), k46 = real(4.0 / 6.0);
+  b[0] = fma(-k16, s3, fma(k36, s2, fma(-k36, s, k16)));
+  b[1] = fma(k36, s3, k46 - s2);
+  b[2] = fma(-k36, s3, fma(k36, s2, fma(k36, s, k16)));
   b[3] = k16 * s3;
 }
 template <typename real>
 __device__ __forceinline__ void bspline_deriv(real s, real* d) {
   const real s2 = s * s;
-  d[0] = (real(-0.5) + s) - real(0.5) * s2;
-  d[1] = real(-2) * s + real(1.5) * s2;
-  d[2] = (real(0.5) + s) - real(1.5) * s2;
+  d[0] = fma(real(-0.5), s2, s - real(0.5));
+  d[1] = fma(real(1.5), s2, real(-2) * s);
+  d[2] = fma(real(-1.5), s2, s + real(0.5));
   d[3] = real(0.5) * s2;
+}
+
+// p_cam = R p + t with fused multiply-adds (SPLINE kernels)
+template <typename real>
+__device__ __forceinline__ void transform_fma(const PoseParams<real>& pose, real x, real y, real z, real& cx, real& cy, real& cz) {
+  cx = fma(pose.R[2], z, fma(pose.R[1], y, fma(pose.R[0], x, pose.t[0])));
+  cy = fma(pose.R[5], z, fma(pose.R[4], y, fma(pose.R[3], x, pose.t[1])));
+  cz = fma(pose.R[8], z, fma(pose.R[7], y, fma(pose.R[6], x, pose.t[2])));
 }
 
 // weight in [0,1] -> unsigned fixed point with `frac` fractional bits via the magic-constant
 // trick: magic = 2^(52-frac); the low mantissa bits of (w + magic) are round-to-nearest(w * 2^frac)
-__device__ __forceinline__ u64 to_fixed(double w, double magic) {
-  const double d = fmax(w, 0.0) + magic;
+// The weight is the product wa * wb; the product and the magic add are one fma.  wa * wb >= -1e-15
+// always (B-spline values), which rounds to the integer 0, so no clamp is needed.
+__device__ __forceinline__ u64 to_fixed(double wa, double wb, double magic) {
+  const double d = fma(wa, wb, magic);
   return u64(__double_as_longlong(d)) & 0x000FFFFFFFFFFFFFull;
 }
 
-// 4 consecutive bytes at an arbitrary byte address, as two aligned dword loads + funnel shift
-__device__ __forceinline__ uint32_t load_u8x4(const uint8_t* p) {
-  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-  const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~uintptr_t(3));
+// 4 consecutive bytes at byte offset `off` of a 4-byte-aligned global array: two aligned dword
+// loads + v_alignbyte.  Offset arithmetic (not pointer-to-integer casts) keeps the pointer in the
+// global address space, so the loads are global_load (vmcnt only) instead of flat_load, which would
+// also count on lgkmcnt and serialise behind the LDS atomics.
+__device__ __forceinline__ uint32_t load_u8x4(const uint8_t* __restrict__ base, uint32_t off) {
+  const uint32_t* __restrict__ q = reinterpret_cast<const uint32_t*>(base + (off & ~3u));
   const uint32_t lo = q[0], hi = q[1];
-  const uint32_t sh = uint32_t(a & 3u) * 8u;
-  return uint32_t(((uint64_t(hi) << 32) | uint64_t(lo)) >> sh);
+  return __builtin_amdgcn_alignbyte(hi, lo, off & 3u);
 }
 
 }  // namespace nidreg

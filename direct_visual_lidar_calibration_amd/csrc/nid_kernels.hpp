@@ -43,21 +43,27 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // ------------------------------------------------------------------------------------------
 // pass A (SPLINE): joint histogram with bicubic B-spline soft assignment.
-// LDS: tile[GW*B] u64 (this workgroup's GW histogram columns) + 1 u32 inlier counter.
+// LDS: tile[GW*B << cshift] u64 (this workgroup's GW histogram columns, 2^cshift copies) + 1 u32 inlier counter.
 // ABL (development builds only, -DNID_ABLATE): bit0 = no LDS atomics, bit1 = no image loads,
 // bit2 = no projection, bit3 = no flush -- phase ablation for profiling (cdna_hip_programming.md 5.4).
 template <int MODEL, typename Rec, typename real, int ABL = 0>
 __global__ __launch_bounds__(kThreads) void k_spline_hist(
   const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint8_t* __restrict__ img, int pitch, int W, int H, PoseParams<real> pose, CamParams<real> cam, int B,
-  int GW, double magic, u64* __restrict__ hist) {
+  int GW, int cshift, double magic, u64* __restrict__ hist) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u64* tile = reinterpret_cast<u64*>(smem);
   const int tile_n = GW * B;
-  unsigned int* s_inl = reinterpret_cast<unsigned int*>(tile + tile_n);
+  // every histogram cell has 2^cshift lane-private copies, interleaved so that lane l only ever
+  // touches copy (l mod 2^cshift): with 16 copies the 16 lanes the LDS services per cycle hit 16
+  // different 8-byte bank pairs -> ds_add_u64 is conflict free by construction (measured before:
+  // 80 % of LDS cycles were bank-conflict cycles)
+  const int tile_w = tile_n << cshift;
+  const uint32_t cmask = (1u << cshift) - 1u;
+  unsigned int* s_inl = reinterpret_cast<unsigned int*>(tile + tile_w);
 
   const int tid = threadIdx.x;
   const Chunk ch = chunks[blockIdx.x];
-  for (int k = tid; k < tile_n; k += kThreads) tile[k] = 0;
+  for (int k = tid; k < tile_w; k += kThreads) tile[k] = 0;
   if (tid == 0) *s_inl = 0;
   __syncthreads();
 
@@ -82,9 +88,8 @@ __global__ __launch_bounds__(kThreads) void k_spline_hist(
     if (i >= ch.count) break;
     const real x = xs[k], y = ys[k], z = zs[k];
     const uint32_t bin = bins_[k];
-    const real cx = ((pose.R[0] * x + pose.R[1] * y) + pose.R[2] * z) + pose.t[0];
-    const real cy = ((pose.R[3] * x + pose.R[4] * y) + pose.R[5] * z) + pose.t[1];
-    const real cz = ((pose.R[6] * x + pose.R[7] * y) + pose.R[8] * z) + pose.t[2];
+    real cx, cy, cz;
+    transform_fma<real>(pose, x, y, z, cx, cy, cz);
     real u, v;
     if (ABL & 4) {
       u = real((bin * 7919u + i * 31u) % uint32_t(W)) + real(0.37) + cx * real(1e-9);
@@ -102,21 +107,23 @@ __global__ __launch_bounds__(kThreads) void k_spline_hist(
       real bx[4], by[4];
       bspline<real>(u - fu, bx);
       bspline<real>(v - fv, by);
-      u64* col = tile + (bin - col0) * uint32_t(B);
+      u64* col = tile + ((((bin - col0) * uint32_t(B)) << cshift) + (uint32_t(tid) & cmask));
       // padded bin image: tap (a,b) of knot (kx,ky) lives at [ky + b][kx + a] (edge-replicated,
       // which is the reference's clamp of knots_x / knots_y, nid_cost.hpp:70-73)
-      const uint8_t* p0 = img + size_t(ky) * size_t(pitch) + size_t(kx);
+      const uint32_t off0 = uint32_t(ky) * uint32_t(pitch) + uint32_t(kx);
+      uint32_t rows[4];  // all four row gathers are issued before the first LDS atomic
+#pragma unroll
+      for (int b = 0; b < 4; b++) rows[b] = (ABL & 2) ? (uint32_t(kx + b) * 2654435761u) ^ (uint32_t(ky) * 40503u) : load_u8x4(img, off0 + uint32_t(b) * uint32_t(pitch));
 #pragma unroll
       for (int b = 0; b < 4; b++) {
-        const uint32_t px4 = (ABL & 2) ? (uint32_t(kx + b) * 2654435761u) ^ (uint32_t(ky) * 40503u) : load_u8x4(p0 + size_t(b) * size_t(pitch));
+        const uint32_t px4 = rows[b];
 #pragma unroll
         for (int a = 0; a < 4; a++) {
-          const uint32_t r = ((px4 >> (8 * a)) & 0xffu) % uint32_t((ABL & 2) ? B : 256);
-          const real w = bx[a] * by[b];
+          const uint32_t r = (ABL & 2) ? ((px4 >> (8 * a)) & 0xffu) % uint32_t(B) : ((px4 >> (8 * a)) & 0xffu);
           if (ABL & 1)
-            abl_acc += to_fixed(double(w), magic) + r;
+            abl_acc += to_fixed(double(bx[a]), double(by[b]), magic) + r;
           else
-            atomicAdd(&col[r], to_fixed(double(w), magic));  // ds_add_u64
+            atomicAdd(&col[r << cshift], to_fixed(double(bx[a]), double(by[b]), magic));  // ds_add_u64
         }
       }
     }
@@ -134,7 +141,8 @@ __global__ __launch_bounds__(kThreads) void k_spline_hist(
   u64* dst = hist + size_t(ch.group) * size_t(tile_n);
   if (!(ABL & 8)) {
     for (int k = tid; k < tile_n; k += kThreads) {
-      const u64 vv = tile[k];
+      u64 vv = 0;
+      for (uint32_t j = 0; j <= cmask; j++) vv += tile[(uint32_t(k) << cshift) + ((j + uint32_t(k)) & cmask)];  // rotated: conflict-free reads
       if (vv) atomicAdd(&dst[k], vv);
     }
   }
@@ -150,15 +158,17 @@ __global__ __launch_bounds__(kThreads) void k_spline_hist(
 template <int MODEL, typename Rec, typename real>
 __global__ __launch_bounds__(kThreads) void k_nearest_hist(
   const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint8_t* __restrict__ img, int pitch, int W, int H, IsoParams<real> iso, CamParams<real> cam, int B,
-  int GW, real cos_fov, u64* __restrict__ hist) {
+  int GW, int cshift, real cos_fov, u64* __restrict__ hist) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u64* tile = reinterpret_cast<u64*>(smem);
   const int tile_n = GW * B;
-  unsigned int* s_inl = reinterpret_cast<unsigned int*>(tile + tile_n);
+  const int tile_w = tile_n << cshift;
+  const uint32_t cmask = (1u << cshift) - 1u;
+  unsigned int* s_inl = reinterpret_cast<unsigned int*>(tile + tile_w);
 
   const int tid = threadIdx.x;
   const Chunk ch = chunks[blockIdx.x];
-  for (int k = tid; k < tile_n; k += kThreads) tile[k] = 0;
+  for (int k = tid; k < tile_w; k += kThreads) tile[k] = 0;
   if (tid == 0) *s_inl = 0;
   __syncthreads();
 
@@ -197,7 +207,7 @@ __global__ __launch_bounds__(kThreads) void k_nearest_hist(
       inl++;
       const int px = int(u), py = int(v);  // truncation toward zero
       const uint32_t r = img[size_t(py + 1) * size_t(pitch) + size_t(px + 1)];
-      atomicAdd(&tile[(bin - col0) * uint32_t(B) + r], u64(1));
+      atomicAdd(&tile[((((bin - col0) * uint32_t(B)) + r) << cshift) + (uint32_t(tid) & cmask)], u64(1));
     }
     }
   }
@@ -210,7 +220,8 @@ __global__ __launch_bounds__(kThreads) void k_nearest_hist(
 
   u64* dst = hist + size_t(ch.group) * size_t(tile_n);
   for (int k = tid; k < tile_n; k += kThreads) {
-    const u64 vv = tile[k];
+    u64 vv = 0;
+    for (uint32_t j = 0; j <= cmask; j++) vv += tile[(uint32_t(k) << cshift) + ((j + uint32_t(k)) & cmask)];
     if (vv) atomicAdd(&dst[k], vv);
   }
   if (tid == 0 && *s_inl) atomicAdd(&hist[size_t(B) * size_t(B) + kTailInliers], u64(*s_inl));
@@ -218,47 +229,49 @@ __global__ __launch_bounds__(kThreads) void k_nearest_hist(
 
 #ifdef NID_COMMON_KERNELS
 // ------------------------------------------------------------------------------------------
-// entropy, part 1: one workgroup per column group.  hist layout [c][r] (c = bin_points,
-// r = bin_image).  Writes  part_hj[g] = sum p log(p + 1e-6) over the group's bins,
-// row_part[g][r] = sum_c h[c][r] (fixed point), col_sum[c] = sum_r h[c][r] (fixed point).
-__global__ __launch_bounds__(kThreads) void k_entropy_partial(const u64* __restrict__ hist, int B, int GW, double inv_unit, double* __restrict__ part_hj, u64* __restrict__ row_part, u64* __restrict__ col_sum) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  u64* s_row = reinterpret_cast<u64*>(smem);  // B
-  u64* s_col = s_row + B;                     // GW
-  double* s_red = reinterpret_cast<double*>(s_col + GW);  // kWaves
-
+// entropy, part 1: one workgroup per block of CB histogram columns (independent of the point
+// kernels' tiling).  hist layout [c][r] (c = bin_points, r = bin_image); thread r walks the block's
+// columns (coalesced).  Writes part_hj[j] = sum p log(p + 1e-6) over the block, row_part[j][r] =
+// sum_c h[c][r] (fixed point), col_sum[c] = sum_r h[c][r] (fixed point).
+__global__ __launch_bounds__(kThreads) void k_entropy_partial(const u64* __restrict__ hist, int B, int CB, double inv_unit, double* __restrict__ part_hj, u64* __restrict__ row_part, u64* __restrict__ col_sum) {
+  __shared__ u64 s_col[kWaves];
+  __shared__ double s_red[kWaves];
   const int tid = threadIdx.x;
-  const int g = blockIdx.x;
-  const int c0 = g * GW;
-  const int ncols = min(GW, B - c0);
-  for (int k = tid; k < B; k += kThreads) s_row[k] = 0;
-  for (int k = tid; k < GW; k += kThreads) s_col[k] = 0;
-  __syncthreads();
-
+  const int j = blockIdx.x;
+  const int c0 = j * CB;
+  const int ncols = min(CB, B - c0);
   const double S = double(hist[size_t(B) * size_t(B) + kTailInliers]);
   const double scale = inv_unit / S;  // fixed-point word -> probability
-  const u64* src = hist + size_t(c0) * size_t(B);
   double acc = 0.0;
-  const int n = ncols * B;
-  for (int k = tid; k < n; k += kThreads) {
-    const u64 v = src[k];
+  u64 row = 0;
+  for (int c = 0; c < ncols; c++) {
+    const u64 v = tid < B ? hist[size_t(c0 + c) * size_t(B) + tid] : 0;
     if (v) {
       const double p = double(v) * scale;
       acc += p * log(p + 1e-6);
-      atomicAdd(&s_row[k % B], v);
-      atomicAdd(&s_col[k / B], v);
     }
+    row += v;
+    u64 w = v;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) w += __shfl_down(w, off, 64);
+    if ((tid & 63) == 0) s_col[tid >> 6] = w;
+    __syncthreads();
+    if (tid == 0) {
+      u64 t = 0;
+      for (int k = 0; k < kWaves; k++) t += s_col[k];
+      col_sum[c0 + c] = t;
+    }
+    __syncthreads();
   }
+  if (tid < B) row_part[size_t(j) * size_t(B) + tid] = row;
   acc = wave_sum(acc);
   if ((tid & 63) == 0) s_red[tid >> 6] = acc;
   __syncthreads();
   if (tid == 0) {
     double t = 0.0;
     for (int w = 0; w < kWaves; w++) t += s_red[w];
-    part_hj[g] = t;
+    part_hj[j] = t;
   }
-  for (int k = tid; k < B; k += kThreads) row_part[size_t(g) * size_t(B) + k] = s_row[k];
-  for (int k = tid; k < ncols; k += kThreads) col_sum[c0 + k] = s_col[k];
 }
 
 // entropy, part 2: single workgroup.  hist_image = row sums, hist_points = column sums / unit
@@ -334,11 +347,12 @@ __global__ __launch_bounds__(kThreads) void k_entropy_final(
 template <int MODEL, typename Rec, typename real, int ABL = 0>
 __global__ __launch_bounds__(kThreads) void k_spline_grad(
   const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint8_t* __restrict__ img, int pitch, int W, int H, PoseParams<real> pose, CamParams<real> cam, int B,
-  int GW, double inv_unit, const u64* __restrict__ hist, const double* __restrict__ phi_q, const EntropyScalars* __restrict__ scal, double* __restrict__ partials) {
+  int GW, int cshift, double inv_unit, const u64* __restrict__ hist, const double* __restrict__ phi_q, const EntropyScalars* __restrict__ scal, double* __restrict__ partials) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* gtile = reinterpret_cast<double*>(smem);
   const int tile_n = GW * B;
-  double* s_red = gtile + tile_n;
+  const uint32_t cmask = (1u << cshift) - 1u;  // G is replicated like the histogram tile: lane-private copies, conflict-free ds_read_b64
+  double* s_red = gtile + (tile_n << cshift);
 
   const int tid = threadIdx.x;
   const Chunk ch = chunks[blockIdx.x];
@@ -350,7 +364,8 @@ __global__ __launch_bounds__(kThreads) void k_spline_grad(
     const int n = ncols * B;
     for (int k = tid; k < n; k += kThreads) {
       const double p = double(src[k]) * scale;
-      gtile[k] = coefA * (log(p + 1e-6) + p / (p + 1e-6)) + coefB * phi_q[k % B];
+      const double gval = coefA * (log(p + 1e-6) + p / (p + 1e-6)) + coefB * phi_q[k % B];
+      for (uint32_t j = 0; j <= cmask; j++) gtile[(uint32_t(k) << cshift) + ((j + uint32_t(k)) & cmask)] = gval;
     }
   }
   __syncthreads();
@@ -378,9 +393,8 @@ __global__ __launch_bounds__(kThreads) void k_spline_grad(
     if (i >= ch.count) break;
     const real x = xs[k], y = ys[k], z = zs[k];
     const uint32_t bin = bins_[k];
-    const real cx = ((pose.R[0] * x + pose.R[1] * y) + pose.R[2] * z) + pose.t[0];
-    const real cy = ((pose.R[3] * x + pose.R[4] * y) + pose.R[5] * z) + pose.t[1];
-    const real cz = ((pose.R[6] * x + pose.R[7] * y) + pose.R[8] * z) + pose.t[2];
+    real cx, cy, cz;
+    transform_fma<real>(pose, x, y, z, cx, cy, cz);
     D u, v;
     if (ABL & 4) {
       u = D(real((bin * 7919u + i * 31u) % uint32_t(W)) + real(0.37) + cx * real(1e-9), real(1), real(0.5), real(0.25));
@@ -397,36 +411,39 @@ __global__ __launch_bounds__(kThreads) void k_spline_grad(
       bspline<real>(v.a - fv, by);
       bspline_deriv<real>(u.a - fu, dbx);
       bspline_deriv<real>(v.a - fv, dby);
-      const double* gcol = gtile + (bin - col0) * uint32_t(B);
-      const uint8_t* p0 = img + size_t(ky) * size_t(pitch) + size_t(kx);
+      const double* gcol = gtile + ((((bin - col0) * uint32_t(B)) << cshift) + (uint32_t(tid) & cmask));
+      const uint32_t off0 = uint32_t(ky) * uint32_t(pitch) + uint32_t(kx);
+      uint32_t rows[4];
+#pragma unroll
+      for (int b = 0; b < 4; b++) rows[b] = (ABL & 2) ? (uint32_t(kx + b) * 2654435761u) ^ (uint32_t(ky) * 40503u) : load_u8x4(img, off0 + uint32_t(b) * uint32_t(pitch));
       real gx = real(0), gy = real(0);
 #pragma unroll
       for (int b = 0; b < 4; b++) {
-        const uint32_t px4 = (ABL & 2) ? (uint32_t(kx + b) * 2654435761u) ^ (uint32_t(ky) * 40503u) : load_u8x4(p0 + size_t(b) * size_t(pitch));
+        const uint32_t px4 = rows[b];
         real sa = real(0), sb = real(0);
 #pragma unroll
         for (int a = 0; a < 4; a++) {
-          const uint32_t r = ((px4 >> (8 * a)) & 0xffu) % uint32_t((ABL & 2) ? B : 256);
-          const real g = (ABL & 1) ? real(r) * real(1e-3) : real(gcol[r]);
-          sa += g * dbx[a];
-          sb += g * bx[a];
+          const uint32_t r = (ABL & 2) ? ((px4 >> (8 * a)) & 0xffu) % uint32_t(B) : ((px4 >> (8 * a)) & 0xffu);
+          const real g = (ABL & 1) ? real(r) * real(1e-3) : real(gcol[r << cshift]);
+          sa = fma(g, dbx[a], sa);
+          sb = fma(g, bx[a], sb);
         }
-        gx += sa * by[b];
-        gy += sb * dby[b];
+        gx = fma(sa, by[b], gx);
+        gy = fma(sb, dby[b], gy);
       }
-      const double gp0 = double(gx * u.d0 + gy * v.d0);
-      const double gp1 = double(gx * u.d1 + gy * v.d1);
-      const double gp2 = double(gx * u.d2 + gy * v.d2);
+      const double gp0 = double(fma(gx, u.d0, gy * v.d0));
+      const double gp1 = double(fma(gx, u.d1, gy * v.d1));
+      const double gp2 = double(fma(gx, u.d2, gy * v.d2));
       const double dx = double(x), dy = double(y), dz = double(z);
-      acc[0] += gp0 * dx;
-      acc[1] += gp0 * dy;
-      acc[2] += gp0 * dz;
-      acc[3] += gp1 * dx;
-      acc[4] += gp1 * dy;
-      acc[5] += gp1 * dz;
-      acc[6] += gp2 * dx;
-      acc[7] += gp2 * dy;
-      acc[8] += gp2 * dz;
+      acc[0] = fma(gp0, dx, acc[0]);
+      acc[1] = fma(gp0, dy, acc[1]);
+      acc[2] = fma(gp0, dz, acc[2]);
+      acc[3] = fma(gp1, dx, acc[3]);
+      acc[4] = fma(gp1, dy, acc[4]);
+      acc[5] = fma(gp1, dz, acc[5]);
+      acc[6] = fma(gp2, dx, acc[6]);
+      acc[7] = fma(gp2, dy, acc[7]);
+      acc[8] = fma(gp2, dz, acc[8]);
       acc[9] += gp0;
       acc[10] += gp1;
       acc[11] += gp2;

@@ -1,4 +1,5 @@
-// double-precision instantiations (parity mode).  Build with -ffp-contract=off.
+// double-precision SPLINE (NIDCost) kernels + projection utility.  Contraction allowed: parity here is a
+// tolerance (NID 1e-10), and fused multiply-adds cut the fp64 VALU work that bounds both passes.
 #include "nid_launch_impl.hpp"
 
 namespace nidreg {
@@ -10,10 +11,6 @@ template <> hipError_t launch_spline_hist<double>(const PassArgs& a) {
 template <> hipError_t launch_spline_grad<double>(const PassArgs& a) {
   if (a.nchunks == 0) return hipSuccess;
   return a.rec64 ? launch_spline_grad_rec<double, Rec64>(a) : launch_spline_grad_rec<double, Rec32>(a);
-}
-template <> hipError_t launch_nearest_hist<double>(const PassArgs& a) {
-  if (a.nchunks == 0) return hipSuccess;
-  return a.rec64 ? launch_nearest_hist_rec<double, Rec64>(a) : launch_nearest_hist_rec<double, Rec32>(a);
 }
 template <> hipError_t launch_project<double>(int model, const double* intr, const double* dist, const double* p3, long long n, double* uv, double* jac, hipStream_t stream) {
   if (n == 0) return hipSuccess;

@@ -18,7 +18,7 @@ struct PassArgs {
   const Chunk* chunks;
   int nchunks;
   const uint8_t* img;  // padded, edge-replicated bin image
-  int pitch, W, H, B, GW;
+  int pitch, W, H, B, GW, cshift;
   double R[9], t[3];  // SPLINE pose
   double iso[12];     // NEAREST pose (rows 0..2 of the 4x4)
   double intr[5], dist[8];

@@ -64,7 +64,7 @@ static hipError_t launch_spline_hist_rec(const PassArgs& a) {
 #ifdef NID_ABLATE
   if (a.model == MODEL_PLUMB_BOB) {
     switch (ablate_mask("NIDREG_ABLATE_HIST")) {
-#define NID_A(K) NID_ABL_CASE(K, k_spline_hist, a.lds_hist, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, pose, cam, a.B, a.GW, a.magic, a.hist)
+#define NID_A(K) NID_ABL_CASE(K, k_spline_hist, a.lds_hist, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, pose, cam, a.B, a.GW, a.cshift, a.magic, a.hist)
       NID_A(1) NID_A(2) NID_A(3) NID_A(4) NID_A(5) NID_A(6) NID_A(7) NID_A(8) NID_A(9) NID_A(15)
 #undef NID_A
       default: break;
@@ -77,7 +77,7 @@ static hipError_t launch_spline_hist_rec(const PassArgs& a) {
     hipError_t e = ensure_lds(k, a.lds_hist);                                                                                                          \
     if (e != hipSuccess) return e;                                                                                                                     \
     hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(kThreads), a.lds_hist, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, pose, cam, \
-                       a.B, a.GW, a.magic, a.hist);                                                                                                    \
+                       a.B, a.GW, a.cshift, a.magic, a.hist);                                                                                                    \
   }
   NID_MODEL_SWITCH(NID_LAUNCH)
 #undef NID_LAUNCH
@@ -91,7 +91,7 @@ static hipError_t launch_spline_grad_rec(const PassArgs& a) {
 #ifdef NID_ABLATE
   if (a.model == MODEL_PLUMB_BOB) {
     switch (ablate_mask("NIDREG_ABLATE_GRAD")) {
-#define NID_A(K) NID_ABL_CASE(K, k_spline_grad, a.lds_grad, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, pose, cam, a.B, a.GW, a.inv_unit, a.hist, a.phi_q, a.scal, a.partials)
+#define NID_A(K) NID_ABL_CASE(K, k_spline_grad, a.lds_grad, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, pose, cam, a.B, a.GW, a.cshift, a.inv_unit, a.hist, a.phi_q, a.scal, a.partials)
       NID_A(1) NID_A(2) NID_A(3) NID_A(4) NID_A(5) NID_A(6) NID_A(7)
 #undef NID_A
       default: break;
@@ -104,7 +104,7 @@ static hipError_t launch_spline_grad_rec(const PassArgs& a) {
     hipError_t e = ensure_lds(k, a.lds_grad);                                                                                                          \
     if (e != hipSuccess) return e;                                                                                                                     \
     hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(kThreads), a.lds_grad, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, pose, cam, \
-                       a.B, a.GW, a.inv_unit, a.hist, a.phi_q, a.scal, a.partials);                                                                    \
+                       a.B, a.GW, a.cshift, a.inv_unit, a.hist, a.phi_q, a.scal, a.partials);                                                                    \
   }
   NID_MODEL_SWITCH(NID_LAUNCH)
 #undef NID_LAUNCH
@@ -121,7 +121,7 @@ static hipError_t launch_nearest_hist_rec(const PassArgs& a) {
     hipError_t e = ensure_lds(k, a.lds_hist);                                                                                                          \
     if (e != hipSuccess) return e;                                                                                                                     \
     hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(kThreads), a.lds_hist, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, iso, cam,  \
-                       a.B, a.GW, real(a.cos_fov), a.hist);                                                                                            \
+                       a.B, a.GW, a.cshift, real(a.cos_fov), a.hist);                                                                                            \
   }
   NID_MODEL_SWITCH(NID_LAUNCH)
 #undef NID_LAUNCH

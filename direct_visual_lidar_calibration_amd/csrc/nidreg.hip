@@ -41,6 +41,7 @@ inline int cast_int(double d) {
   return static_cast<int>(d);
 }
 
+constexpr int kEntropyCols = 16;  // histogram columns per k_entropy_partial workgroup
 const int kNumIntr[6] = {4, 4, 5, 2, 4, 4};
 const int kNumDist[6] = {5, 4, 4, 0, 1, 8};
 
@@ -50,7 +51,8 @@ struct nidreg_handle {
   int device = 0;
   int model = 0, mode = 0, precision = 0, bins = 0;
   int W = 0, H = 0, pitch = 0;
-  int GW = 0, NG = 0;
+  int GW = 0, NG = 0, cshift = 0;
+  int NEB = 0;  // entropy column blocks
   int frac_bits = 0;
   int rec64 = 0;
   int64_t num_points = 0;
@@ -126,6 +128,7 @@ void fill_pass_args(const nidreg_handle* h, PassArgs& a) {
   a.H = h->H;
   a.B = h->bins;
   a.GW = h->GW;
+  a.cshift = h->cshift;
   std::memcpy(a.intr, h->intr, sizeof(a.intr));
   std::memcpy(a.dist, h->dist, sizeof(a.dist));
   a.magic = std::ldexp(1.0, 52 - h->frac_bits);
@@ -190,10 +193,10 @@ int launch_hist_nearest(nidreg_handle* h, const double* T) {
 
 int launch_entropy(nidreg_handle* h) {
   const double inv_unit = std::ldexp(1.0, -h->frac_bits);
-  hipLaunchKernelGGL(k_entropy_partial, dim3(h->NG), dim3(kThreads), h->lds_entropy, h->stream, h->d_hist, h->bins, h->GW, inv_unit, h->d_part_hj, h->d_row_part, h->d_col_sum);
+  hipLaunchKernelGGL(k_entropy_partial, dim3(h->NEB), dim3(kThreads), 0, h->stream, h->d_hist, h->bins, kEntropyCols, inv_unit, h->d_part_hj, h->d_row_part, h->d_col_sum);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(
-    k_entropy_final, dim3(1), dim3(kThreads), 0, h->stream, h->d_hist, h->bins, h->NG, inv_unit, h->d_part_hj, h->d_row_part, h->d_col_sum, h->d_phi_q, h->d_hist_image,
+    k_entropy_final, dim3(1), dim3(kThreads), 0, h->stream, h->d_hist, h->bins, h->NEB, inv_unit, h->d_part_hj, h->d_row_part, h->d_col_sum, h->d_phi_q, h->d_hist_image,
     h->d_hist_points, h->d_scal, h->d_out);
   HIP_TRY(hipGetLastError());
   return NIDREG_OK;
@@ -363,14 +366,21 @@ int nidreg_create(const nidreg_desc* d, nidreg_handle** out) {
     }                                                                                        \
   } while (0)
 
-  // ---- tiling: GW histogram columns per workgroup (LDS tile = GW * B 64-bit words)
-  int GW = d->columns_per_group > 0 ? d->columns_per_group : 16;
+  // ---- tiling: a workgroup owns GW histogram columns (= GW * B cells) in LDS, each cell replicated
+  // 2^cshift times (lane-private copies, see k_spline_hist).  Default: ~256 cells x 16 copies = 32 KB.
+  int GW = d->columns_per_group > 0 ? d->columns_per_group : std::max(1, 256 / B);
   GW = std::min(GW, B);
+  int copies = d->lds_copies > 0 ? d->lds_copies : 16;
+  int cshift = 0;
+  while ((2 << cshift) <= copies && cshift < 4) cshift++;
   while (size_t(GW) * B * 8 > 128 * 1024 && GW > 1) GW /= 2;
+  while ((size_t(GW) * B * 8 << cshift) > 64 * 1024 && cshift > 0) cshift--;
   h->GW = GW;
+  h->cshift = cshift;
   h->NG = (B + GW - 1) / GW;
-  h->lds_hist = size_t(GW) * B * 8 + 16;
-  h->lds_grad = size_t(GW) * B * 8 + size_t(kWaves) * 12 * 8;
+  h->NEB = (B + kEntropyCols - 1) / kEntropyCols;
+  h->lds_hist = (size_t(GW) * B * 8 << cshift) + 16;
+  h->lds_grad = (size_t(GW) * B * 8 << cshift) + size_t(kWaves) * 12 * 8;
   h->lds_entropy = size_t(B) * 8 + size_t(GW) * 8 + size_t(kWaves) * 8;
 
   // ---- fixed point: sum over a bin <= N * 2^frac must stay below 2^63
@@ -434,11 +444,36 @@ int nidreg_create(const nidreg_desc* d, nidreg_handle** out) {
   h->rec64 = (d->precision == NIDREG_PREC_FP64 && !lossless) ? 1 : 0;
   const size_t rec_bytes = h->rec64 ? sizeof(Rec64) : sizeof(Rec32);
   {
-    std::vector<int64_t> cursor(gcount.begin(), gcount.end() - 1);
+    // order[k] = source index of the k-th device record.  Default: stable bucketing by column group.
+    // NIDREG_FLAG_SPATIAL_ORDER: inside each group, order by a Morton code of the LiDAR-frame bearing
+    // (azimuth, elevation).  The sums are order independent (fixed point), so any order gives the
+    // same bits; a spatially coherent one makes the 64 lanes of a wave gather from neighbouring
+    // image rows/lines for ANY pose (camera and LiDAR are rigidly mounted, so a compact patch of
+    // bearings stays a compact patch of pixels).
+    std::vector<uint32_t> order(N);
+    if (d->flags & NIDREG_FLAG_SPATIAL_ORDER) {
+      std::vector<std::pair<uint64_t, uint32_t>> keyed(N);
+      for (int64_t i = 0; i < N; i++) {
+        const double* p = reinterpret_cast<const double*>(pbase + i * pstride);
+        const double az = std::atan2(p[1], p[0]);
+        const double el = std::atan2(p[2], std::sqrt(p[0] * p[0] + p[1] * p[1]));
+        uint32_t qa = uint32_t(std::min(65535.0, std::max(0.0, (az + M_PI) * (65535.0 / (2.0 * M_PI)))));
+        uint32_t qe = uint32_t(std::min(65535.0, std::max(0.0, (el + 0.5 * M_PI) * (65535.0 / M_PI))));
+        if (!(az == az) || !(el == el)) qa = qe = 0;
+        uint64_t m = 0;
+        for (int b = 0; b < 16; b++) m |= (uint64_t((qa >> b) & 1u) << (2 * b)) | (uint64_t((qe >> b) & 1u) << (2 * b + 1));
+        keyed[i] = std::make_pair((uint64_t(bin[i] / GW) << 32) | m, uint32_t(i));
+      }
+      std::sort(keyed.begin(), keyed.end());
+      for (int64_t i = 0; i < N; i++) order[i] = keyed[i].second;
+    } else {
+      std::vector<int64_t> cursor(gcount.begin(), gcount.end() - 1);
+      for (int64_t i = 0; i < N; i++) order[cursor[bin[i] / GW]++] = uint32_t(i);
+    }
     std::vector<unsigned char> recs(size_t(std::max<int64_t>(N, 1)) * rec_bytes);
-    for (int64_t i = 0; i < N; i++) {
+    for (int64_t dst = 0; dst < N; dst++) {
+      const int64_t i = order[dst];
       const double* p = reinterpret_cast<const double*>(pbase + i * pstride);
-      const int64_t dst = cursor[bin[i] / GW]++;
       if (h->rec64) {
         Rec64 r;
         r.x = p[0];
@@ -502,8 +537,8 @@ int nidreg_create(const nidreg_desc* d, nidreg_handle** out) {
   }
   CREATE_TRY(hipMemset(h->d_out, 0, NIDREG_OUT_DOUBLES * sizeof(double)));
   CREATE_TRY(hipMemset(h->d_hist, 0, size_t(h->hist_words) * sizeof(u64)));
-  CREATE_TRY(hipMalloc(&h->d_part_hj, size_t(h->NG) * sizeof(double)));
-  CREATE_TRY(hipMalloc(&h->d_row_part, size_t(h->NG) * B * sizeof(u64)));
+  CREATE_TRY(hipMalloc(&h->d_part_hj, size_t(h->NEB) * sizeof(double)));
+  CREATE_TRY(hipMalloc(&h->d_row_part, size_t(h->NEB) * B * sizeof(u64)));
   CREATE_TRY(hipMalloc(&h->d_col_sum, size_t(B) * sizeof(u64)));
   CREATE_TRY(hipMalloc(&h->d_phi_q, size_t(B) * sizeof(double)));
   CREATE_TRY(hipMalloc(&h->d_hist_image, size_t(B) * sizeof(double)));
@@ -695,7 +730,7 @@ int nidreg_get_info(nidreg_handle* h, int64_t* info8) {
   info8[4] = int64_t(h->lds_hist);
   info8[5] = h->pitch;
   info8[6] = h->num_points;
-  info8[7] = h->rec64 ? 0 : 1;
+  info8[7] = (h->rec64 ? 0 : 1) | (int64_t(1 << h->cshift) << 8);
   return NIDREG_OK;
 }
 

@@ -93,7 +93,7 @@ def _prec(precision):
 class _Handle:
     """RAII owner of one ``nidreg_handle`` (device residency of one LiDAR-camera pair)."""
 
-    def __init__(self, proj, image, points, intensities, bins, mode, precision, device, max_fov=0.0, columns_per_group=0, target_blocks=0, scale_points=0, ext_stream=None, ext_hist=None, ext_out=None):
+    def __init__(self, proj, image, points, intensities, bins, mode, precision, device, max_fov=0.0, columns_per_group=0, target_blocks=0, scale_points=0, flags=0, lds_copies=0, ext_stream=None, ext_hist=None, ext_out=None):
         if proj is None:
             raise ValueError("camera is None (create_camera failed)")
         lib = _lib.load()
@@ -133,6 +133,8 @@ class _Handle:
         d.columns_per_group = int(columns_per_group)
         d.target_blocks = int(target_blocks)
         d.scale_points = int(scale_points)
+        d.flags = int(flags)
+        d.lds_copies = int(lds_copies)
         d.ext_stream = ext_stream
         d.ext_hist = ext_hist
         d.ext_out = ext_out
@@ -183,7 +185,10 @@ class _Handle:
         v = (ctypes.c_int64 * 8)()
         _lib.check(self._lib.nidreg_get_info(self.h, v), "nidreg_get_info")
         keys = ["record_bytes", "num_chunks", "columns_per_group", "frac_bits", "lds_bytes", "image_pitch", "num_points", "float32_records"]
-        return dict(zip(keys, [int(x) for x in v]))
+        out = dict(zip(keys, [int(x) for x in v]))
+        out["lds_copies"] = out["float32_records"] >> 8
+        out["float32_records"] &= 1
+        return out
 
 
 class NIDCost(_Handle):

@@ -72,6 +72,10 @@ extern "C" {
 
 #define NIDREG_MAX_BINS 256
 
+/* nidreg_desc.flags */
+#define NIDREG_FLAG_SPATIAL_ORDER 1 /* order records inside each column group along a Morton curve of
+                                       the LiDAR-frame bearing (results are bit-identical either way) */
+
 typedef struct nidreg_handle nidreg_handle;
 
 typedef struct nidreg_desc {
@@ -85,7 +89,7 @@ typedef struct nidreg_desc {
   double distortion[8];     /* already zero-padded / truncated like create_camera.cpp:24-27 */
   int32_t width, height;    /* image cols, rows */
   int32_t image_dtype;      /* NIDREG_IMAGE_* */
-  int32_t reserved0;
+  int32_t flags;            /* NIDREG_FLAG_* */
   const void* image;        /* host pointer, rows x cols */
   int64_t image_row_stride; /* bytes between rows (cv::Mat::step) */
   int64_t num_points;       /* Frame::size() */
@@ -96,6 +100,8 @@ typedef struct nidreg_desc {
   /* tuning (0 = default) */
   int32_t columns_per_group;/* histogram columns (bin_points values) a workgroup owns in LDS */
   int32_t target_blocks;    /* approximate number of point chunks = workgroups per pass */
+  int32_t lds_copies;       /* lane-private copies of each histogram cell in LDS (1,2,4,8,16) */
+  int32_t reserved1;
   int64_t scale_points;     /* points the fixed-point scale must hold (0 = num_points); shards of one
                                pair pass the TOTAL so that every rank uses the same 2^-frac unit */
   /* optional externally owned device resources (sharded multi-GPU use); NULL = internal */
@@ -167,7 +173,7 @@ int nidreg_get_timing(nidreg_handle* h, float* ms6);
 
 /* layout facts for DESIGN.md / bench: [0]=record bytes per point on device, [1]=number of chunks,
  * [2]=columns per group, [3]=fixed-point fraction bits, [4]=LDS bytes per workgroup,
- * [5]=padded image pitch, [6]=points stored (after dropping none), [7]=1 if float32 records */
+ * [5]=padded image pitch, [6]=points stored, [7]=bit0: float32 records, bits 8..: LDS copies per histogram cell */
 int nidreg_get_info(nidreg_handle* h, int64_t* info8);
 
 const char* nidreg_last_error(void);

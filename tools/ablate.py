@@ -18,11 +18,12 @@ prec = sys.argv[2] if len(sys.argv) > 2 else "fp64"
 bins = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 gw = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 tb = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+flags = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 pts = z["points"].astype(np.float64)
 ints = z["intensities"].astype(np.float64)
 proj = nid.create_camera(str(z["model"]), list(z["intrinsics"]), list(z["distortion"]))
 img64 = z["image_u8"].astype(np.float64) * (1.0 / 255.0)
-cost = nid.NIDCost(proj, img64, pts, ints, bins, precision=prec, columns_per_group=gw, target_blocks=tb)
+cost = nid.NIDCost(proj, img64, pts, ints, bins, precision=prec, columns_per_group=gw, target_blocks=tb, flags=flags)
 cost.set_timing(True)
 rng = np.random.default_rng(1)
 poses = [se3.plus(z["T_true"], rng.uniform(-1, 1, 6) * np.array([0.05, 0.05, 0.05, 0.0087, 0.0087, 0.0087])) for _ in range(8)]

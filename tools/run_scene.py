@@ -18,11 +18,12 @@ prec = sys.argv[3] if len(sys.argv) > 3 else "fp64"
 bins = int(sys.argv[4]) if len(sys.argv) > 4 else 256
 gw = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 tb = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+flags = int(sys.argv[7]) if len(sys.argv) > 7 else 0
 pts = z["points"].astype(np.float64)
 ints = z["intensities"].astype(np.float64)
 proj = nid.create_camera(str(z["model"]), list(z["intrinsics"]), list(z["distortion"]))
 img64 = z["image_u8"].astype(np.float64) * (1.0 / 255.0)
-cost = nid.NIDCost(proj, img64, pts, ints, bins, precision=prec, columns_per_group=gw, target_blocks=tb)
+cost = nid.NIDCost(proj, img64, pts, ints, bins, precision=prec, columns_per_group=gw, target_blocks=tb, flags=flags)
 cost.set_timing(True)
 rng = np.random.default_rng(1)
 acc = {}
