@@ -130,11 +130,31 @@ enum { MODEL_PLUMB_BOB = 0, MODEL_FISHEYE = 1, MODEL_OMNIDIR = 2, MODEL_EQUIRECT
 // ------------------------------------------------------------------------------------------
 // projection models (reference: include/camera/{pinhole,fisheye,omnidir,equirectangular,atan,
 // rational_polynomial}.hpp), T = real or Dual3<real>.
-template <int MODEL, typename T, typename real>
+// perspective division: exact x/z, y/z (NEAREST path: bit-identical to the CPU) or one reciprocal and
+// two multiplies (SPLINE kernels; both passes use the same form, so they agree on every knot)
+template <bool RCP, typename real>
+__device__ __forceinline__ void persp(real x, real y, real z, real& px, real& py) {
+  if (RCP) {
+    const real iz = real(1) / z;
+    px = x * iz;
+    py = y * iz;
+  } else {
+    px = x / z;
+    py = y / z;
+  }
+}
+template <bool RCP, typename real>
+__device__ __forceinline__ void persp(const Dual3<real>& x, const Dual3<real>& y, const Dual3<real>& z, Dual3<real>& px, Dual3<real>& py) {
+  px = x / z;  // Dual3 division is reciprocal-multiply already
+  py = y / z;
+}
+
+template <int MODEL, typename T, typename real, bool RCP = false>
 __device__ __forceinline__ void project(const CamParams<real>& c, const T& x, const T& y, const T& z, T& u, T& v) {
   if (MODEL == MODEL_PLUMB_BOB) {  // pinhole.hpp:13-51, distortion k1 k2 p1 p2 k3
     const real k1 = c.dist[0], k2 = c.dist[1], p1 = c.dist[2], p2 = c.dist[3], k3 = c.dist[4];
-    const T px = x / z, py = y / z;
+    T px, py;
+    persp<RCP>(x, y, z, px, py);
     const T x2 = px * px, y2 = py * py;
     const T r2 = x2 + y2;
     const T r4 = r2 * r2;
@@ -195,7 +215,8 @@ __device__ __forceinline__ void project(const CamParams<real>& c, const T& x, co
     }
   } else if (MODEL == MODEL_ATAN) {  // atan.hpp:14-39
     const real d0 = c.dist[0];
-    const T px = x / z, py = y / z;
+    T px, py;
+    persp<RCP>(x, y, z, px, py);
     const T r = m_sqrt(px * px + py * py);
     T dx = px, dy = py;
     if (!(r < real(1e-3) || d0 < real(1e-7))) {
@@ -210,7 +231,8 @@ __device__ __forceinline__ void project(const CamParams<real>& c, const T& x, co
   } else {  // rational_polynomial.hpp:11-58, k1 k2 p1 p2 k3 k4 k5 k6
     const real k1 = c.dist[0], k2 = c.dist[1], p1 = c.dist[2], p2 = c.dist[3];
     const real k3 = c.dist[4], k4 = c.dist[5], k5 = c.dist[6], k6 = c.dist[7];
-    const T px = x / z, py = y / z;
+    T px, py;
+    persp<RCP>(x, y, z, px, py);
     const T x2 = px * px, y2 = py * py;
     const T r2 = x2 + y2;
     const T r4 = r2 * r2;
@@ -225,6 +247,71 @@ __device__ __forceinline__ void project(const CamParams<real>& c, const T& x, co
     const T dy = rc * py + p1 * t3 + p2 * t1;
     u = c.intr[0] * dx + c.intr[2];
     v = c.intr[1] * dy + c.intr[3];
+  }
+}
+
+// projection value + 2x3 Jacobian d(u,v)/d(x,y,z) for the gradient pass.  Generic route: Dual3
+// forward mode (3 partials through every operation).  plumb_bob / rational_polynomial: the Jacobian of
+// the distortion polynomial is written out by hand (it is symmetric) and chained with the closed-form
+// Jacobian of the perspective division, ~2.5x fewer fp64 operations than Dual3.
+template <int MODEL, typename real>
+__device__ __forceinline__ void project_jac(const CamParams<real>& c, real x, real y, real z, real& u, real& v, real* du, real* dv) {
+  if (MODEL == MODEL_PLUMB_BOB || MODEL == MODEL_RATIONAL) {
+    project<MODEL, real, real, true>(c, x, y, z, u, v);  // value: identical expression to the histogram pass
+    const real iz = real(1) / z;
+    const real px = x * iz, py = y * iz;
+    const real x2 = px * px, y2 = py * py, xy = px * py;
+    const real r2 = x2 + y2;
+    const real r4 = r2 * r2;
+    real rc, rcp, p1, p2;  // radial factor and d(rc)/d(r2)
+    if (MODEL == MODEL_PLUMB_BOB) {
+      const real k1 = c.dist[0], k2 = c.dist[1], k3 = c.dist[4];
+      p1 = c.dist[2];
+      p2 = c.dist[3];
+      const real r6 = r2 * r4;
+      rc = real(1) + k1 * r2 + k2 * r4 + k3 * r6;
+      rcp = fma(real(3) * k3, r4, fma(real(2) * k2, r2, k1));
+    } else {
+      const real k1 = c.dist[0], k2 = c.dist[1], k3 = c.dist[4], k4 = c.dist[5], k5 = c.dist[6], k6 = c.dist[7];
+      p1 = c.dist[2];
+      p2 = c.dist[3];
+      const real r6 = r2 * r4;
+      const real num = real(1) + k1 * r2 + k2 * r4 + k3 * r6;
+      const real den = real(1) + k4 * r2 + k5 * r4 + k6 * r6;
+      const real nump = fma(real(3) * k3, r4, fma(real(2) * k2, r2, k1));
+      const real denp = fma(real(3) * k6, r4, fma(real(2) * k5, r2, k4));
+      if (den > real(1e-8)) {
+        const real id = real(1) / den;
+        rc = num * id;
+        rcp = (nump - rc * denp) * id;
+      } else {
+        rc = num;
+        rcp = nump;
+      }
+    }
+    const real off = fma(real(2) * xy, rcp, real(2) * fma(p1, px, p2 * py));  // d(dx)/d(py) = d(dy)/d(px)
+    const real a00 = c.intr[0] * fma(real(2) * x2, rcp, rc + real(2) * fma(p1, py, real(3) * p2 * px));
+    const real a01 = c.intr[0] * off;
+    const real a10 = c.intr[1] * off;
+    const real a11 = c.intr[1] * fma(real(2) * y2, rcp, rc + real(2) * fma(real(3) * p1, py, p2 * px));
+    du[0] = a00 * iz;
+    du[1] = a01 * iz;
+    du[2] = -fma(du[0], px, du[1] * py);
+    dv[0] = a10 * iz;
+    dv[1] = a11 * iz;
+    dv[2] = -fma(dv[0], px, dv[1] * py);
+  } else {
+    typedef Dual3<real> D;
+    D uu, vv;
+    project<MODEL, D, real, true>(c, D(x, real(1), real(0), real(0)), D(y, real(0), real(1), real(0)), D(z, real(0), real(0), real(1)), uu, vv);
+    u = uu.a;
+    v = vv.a;
+    du[0] = uu.d0;
+    du[1] = uu.d1;
+    du[2] = uu.d2;
+    dv[0] = vv.d0;
+    dv[1] = vv.d1;
+    dv[2] = vv.d2;
   }
 }
 

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(kThreads) void k_spline_hist(
       u = real((bin * 7919u + i * 31u) % uint32_t(W)) + real(0.37) + cx * real(1e-9);
       v = real((bin * 104729u + i * 17u) % uint32_t(H)) + real(0.61) + cy * real(1e-9) + cz * real(1e-9);
     } else {
-      project<MODEL, real, real>(cam, cx, cy, cz, u, v);
+      project<MODEL, real, real, true>(cam, cx, cy, cz, u, v);
     }
     // floor(u) in [0,W) and floor(v) in [0,H); NaN / inf / overflow compare false -> outlier
     // (the reference's int conversion sends those to INT_MIN, nid_cost.hpp:52-58)
@@ -233,40 +233,42 @@ __global__ __launch_bounds__(kThreads) void k_nearest_hist(
 // kernels' tiling).  hist layout [c][r] (c = bin_points, r = bin_image); thread r walks the block's
 // columns (coalesced).  Writes part_hj[j] = sum p log(p + 1e-6) over the block, row_part[j][r] =
 // sum_c h[c][r] (fixed point), col_sum[c] = sum_r h[c][r] (fixed point).
+constexpr int kEntropyColsMax = 16;
 __global__ __launch_bounds__(kThreads) void k_entropy_partial(const u64* __restrict__ hist, int B, int CB, double inv_unit, double* __restrict__ part_hj, u64* __restrict__ row_part, u64* __restrict__ col_sum) {
-  __shared__ u64 s_col[kWaves];
+  __shared__ u64 s_col[kEntropyColsMax][kWaves];
   __shared__ double s_red[kWaves];
   const int tid = threadIdx.x;
   const int j = blockIdx.x;
   const int c0 = j * CB;
   const int ncols = min(CB, B - c0);
+  u64 v[kEntropyColsMax];
+#pragma unroll
+  for (int c = 0; c < kEntropyColsMax; c++) v[c] = (tid < B && c < ncols) ? hist[size_t(c0 + c) * size_t(B) + tid] : 0;  // independent loads
   const double S = double(hist[size_t(B) * size_t(B) + kTailInliers]);
   const double scale = inv_unit / S;  // fixed-point word -> probability
   double acc = 0.0;
   u64 row = 0;
-  for (int c = 0; c < ncols; c++) {
-    const u64 v = tid < B ? hist[size_t(c0 + c) * size_t(B) + tid] : 0;
-    if (v) {
-      const double p = double(v) * scale;
+#pragma unroll
+  for (int c = 0; c < kEntropyColsMax; c++) {
+    if (v[c]) {
+      const double p = double(v[c]) * scale;
       acc += p * log(p + 1e-6);
     }
-    row += v;
-    u64 w = v;
+    row += v[c];
+    u64 w = v[c];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) w += __shfl_down(w, off, 64);
-    if ((tid & 63) == 0) s_col[tid >> 6] = w;
-    __syncthreads();
-    if (tid == 0) {
-      u64 t = 0;
-      for (int k = 0; k < kWaves; k++) t += s_col[k];
-      col_sum[c0 + c] = t;
-    }
-    __syncthreads();
+    if ((tid & 63) == 0) s_col[c][tid >> 6] = w;
   }
   if (tid < B) row_part[size_t(j) * size_t(B) + tid] = row;
   acc = wave_sum(acc);
   if ((tid & 63) == 0) s_red[tid >> 6] = acc;
   __syncthreads();
+  if (tid < ncols) {
+    u64 t = 0;
+    for (int k = 0; k < kWaves; k++) t += s_col[tid][k];
+    col_sum[c0 + tid] = t;
+  }
   if (tid == 0) {
     double t = 0.0;
     for (int w = 0; w < kWaves; w++) t += s_red[w];
@@ -376,7 +378,6 @@ __global__ __launch_bounds__(kThreads) void k_spline_grad(
 #pragma unroll
   for (int k = 0; k < 12; k++) acc[k] = 0.0;
 
-  typedef Dual3<real> D;
   // kUnroll records per thread are fetched before any of them is processed: one 16-B load per wave
   // in flight is latency bound (measured 1.45 TB/s); four keep ~64 KB per CU outstanding
   for (uint32_t base = 0; base < ch.count; base += kThreads * kUnroll) {
@@ -395,22 +396,24 @@ __global__ __launch_bounds__(kThreads) void k_spline_grad(
     const uint32_t bin = bins_[k];
     real cx, cy, cz;
     transform_fma<real>(pose, x, y, z, cx, cy, cz);
-    D u, v;
+    real uu, vv, du[3], dv[3];
     if (ABL & 4) {
-      u = D(real((bin * 7919u + i * 31u) % uint32_t(W)) + real(0.37) + cx * real(1e-9), real(1), real(0.5), real(0.25));
-      v = D(real((bin * 104729u + i * 17u) % uint32_t(H)) + real(0.61) + cy * real(1e-9) + cz * real(1e-9), real(0.5), real(1), real(0.25));
+      uu = real((bin * 7919u + i * 31u) % uint32_t(W)) + real(0.37) + cx * real(1e-9);
+      vv = real((bin * 104729u + i * 17u) % uint32_t(H)) + real(0.61) + cy * real(1e-9) + cz * real(1e-9);
+      du[0] = real(1), du[1] = real(0.5), du[2] = real(0.25);
+      dv[0] = real(0.5), dv[1] = real(1), dv[2] = real(0.25);
     } else {
-      project<MODEL, D, real>(cam, D(cx, real(1), real(0), real(0)), D(cy, real(0), real(1), real(0)), D(cz, real(0), real(0), real(1)), u, v);
+      project_jac<MODEL, real>(cam, cx, cy, cz, uu, vv, du, dv);
     }
-    const bool in = (u.a >= real(0)) && (u.a < fW) && (v.a >= real(0)) && (v.a < fH);
+    const bool in = (uu >= real(0)) && (uu < fW) && (vv >= real(0)) && (vv < fH);
     if (in) {
-      const real fu = m_floor(u.a), fv = m_floor(v.a);
+      const real fu = m_floor(uu), fv = m_floor(vv);
       const int kx = int(fu), ky = int(fv);
       real bx[4], by[4], dbx[4], dby[4];
-      bspline<real>(u.a - fu, bx);
-      bspline<real>(v.a - fv, by);
-      bspline_deriv<real>(u.a - fu, dbx);
-      bspline_deriv<real>(v.a - fv, dby);
+      bspline<real>(uu - fu, bx);
+      bspline<real>(vv - fv, by);
+      bspline_deriv<real>(uu - fu, dbx);
+      bspline_deriv<real>(vv - fv, dby);
       const double* gcol = gtile + ((((bin - col0) * uint32_t(B)) << cshift) + (uint32_t(tid) & cmask));
       const uint32_t off0 = uint32_t(ky) * uint32_t(pitch) + uint32_t(kx);
       uint32_t rows[4];
@@ -431,9 +434,9 @@ __global__ __launch_bounds__(kThreads) void k_spline_grad(
         gx = fma(sa, by[b], gx);
         gy = fma(sb, dby[b], gy);
       }
-      const double gp0 = double(fma(gx, u.d0, gy * v.d0));
-      const double gp1 = double(fma(gx, u.d1, gy * v.d1));
-      const double gp2 = double(fma(gx, u.d2, gy * v.d2));
+      const double gp0 = double(fma(gx, du[0], gy * dv[0]));
+      const double gp1 = double(fma(gx, du[1], gy * dv[1]));
+      const double gp2 = double(fma(gx, du[2], gy * dv[2]));
       const double dx = double(x), dy = double(y), dz = double(z);
       acc[0] = fma(gp0, dx, acc[0]);
       acc[1] = fma(gp0, dy, acc[1]);
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(kThreads) void k_spline_grad(
   if (tid < 12) {
     double t = 0.0;
     for (int w = 0; w < kWaves; w++) t += s_red[w * 12 + tid];
-    partials[size_t(blockIdx.x) * 12 + tid] = t;
+    partials[size_t(tid) * gridDim.x + blockIdx.x] = t;  // [12][nchunks]: coalesced for k_grad_final
   }
 }
 
@@ -478,7 +481,7 @@ __global__ __launch_bounds__(kThreads) void k_grad_final(const double* __restric
   for (int k = 0; k < 12; k++) acc[k] = 0.0;
   for (int b = tid; b < nblocks; b += kThreads) {
 #pragma unroll
-    for (int k = 0; k < 12; k++) acc[k] += partials[size_t(b) * 12 + k];
+    for (int k = 0; k < 12; k++) acc[k] += partials[size_t(k) * nblocks + b];
   }
 #pragma unroll
   for (int k = 0; k < 12; k++) {
@@ -518,18 +521,17 @@ template <int MODEL, typename real>
 __global__ void k_project(const double* __restrict__ p3, long long n, CamParams<real> cam, double* __restrict__ uv, double* __restrict__ jac) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  typedef Dual3<real> D;
-  D u, v;
-  project<MODEL, D, real>(cam, D(real(p3[3 * i]), real(1), real(0), real(0)), D(real(p3[3 * i + 1]), real(0), real(1), real(0)), D(real(p3[3 * i + 2]), real(0), real(0), real(1)), u, v);
-  uv[2 * i] = double(u.a);
-  uv[2 * i + 1] = double(v.a);
+  real u, v, du[3], dv[3];
+  project_jac<MODEL, real>(cam, real(p3[3 * i]), real(p3[3 * i + 1]), real(p3[3 * i + 2]), u, v, du, dv);
+  uv[2 * i] = double(u);
+  uv[2 * i + 1] = double(v);
   if (jac) {
-    jac[6 * i + 0] = double(u.d0);
-    jac[6 * i + 1] = double(u.d1);
-    jac[6 * i + 2] = double(u.d2);
-    jac[6 * i + 3] = double(v.d0);
-    jac[6 * i + 4] = double(v.d1);
-    jac[6 * i + 5] = double(v.d2);
+    jac[6 * i + 0] = double(du[0]);
+    jac[6 * i + 1] = double(du[1]);
+    jac[6 * i + 2] = double(du[2]);
+    jac[6 * i + 3] = double(dv[0]);
+    jac[6 * i + 4] = double(dv[1]);
+    jac[6 * i + 5] = double(dv[2]);
   }
 }
 

@@ -9,11 +9,14 @@
 #include "nid_launch.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/nidreg.h"
@@ -427,69 +430,115 @@ int nidreg_create(const nidreg_desc* d, nidreg_handle** out) {
   // caller asked for FP32 geometry; otherwise double.
   const char* pbase = reinterpret_cast<const char*>(d->points);
   const int64_t pstride = d->point_stride > 0 ? d->point_stride : 32;
-  bool lossless = true;
-  std::vector<uint32_t> bin(N);
-  std::vector<int64_t> gcount(h->NG + 1, 0);
-  for (int64_t i = 0; i < N; i++) {
-    const double* p = reinterpret_cast<const double*>(pbase + i * pstride);
-    if (lossless) {
-      for (int k = 0; k < 3; k++)
-        if (double(float(p[k])) != p[k] && p[k] == p[k]) lossless = false;
+  const bool spatial = !(d->flags & NIDREG_FLAG_INPUT_ORDER);
+  const int nthreads = int(std::max(1u, std::min(32u, std::thread::hardware_concurrency())));
+  auto parallel_for = [&](int64_t n, const std::function<void(int64_t, int64_t, int)>& fn) {
+    const int T = int(std::min<int64_t>(nthreads, std::max<int64_t>(1, n / 65536)));
+    if (T <= 1) {
+      fn(0, n, 0);
+      return;
     }
-    const int b = std::max(0, std::min(B - 1, cast_int(d->intensities[i] * B)));
-    bin[i] = uint32_t(b);
-    gcount[b / GW + 1]++;
-  }
-  for (int g = 0; g < h->NG; g++) gcount[g + 1] += gcount[g];
-  h->rec64 = (d->precision == NIDREG_PREC_FP64 && !lossless) ? 1 : 0;
-  const size_t rec_bytes = h->rec64 ? sizeof(Rec64) : sizeof(Rec32);
-  {
-    // order[k] = source index of the k-th device record.  Default: stable bucketing by column group.
-    // NIDREG_FLAG_SPATIAL_ORDER: inside each group, order by a Morton code of the LiDAR-frame bearing
-    // (azimuth, elevation).  The sums are order independent (fixed point), so any order gives the
-    // same bits; a spatially coherent one makes the 64 lanes of a wave gather from neighbouring
-    // image rows/lines for ANY pose (camera and LiDAR are rigidly mounted, so a compact patch of
-    // bearings stays a compact patch of pixels).
-    std::vector<uint32_t> order(N);
-    if (d->flags & NIDREG_FLAG_SPATIAL_ORDER) {
-      std::vector<std::pair<uint64_t, uint32_t>> keyed(N);
-      for (int64_t i = 0; i < N; i++) {
-        const double* p = reinterpret_cast<const double*>(pbase + i * pstride);
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++) th.emplace_back([&, t]() { fn(n * t / T, n * (t + 1) / T, t); });
+    for (auto& x : th) x.join();
+  };
+
+  // pass 1 (parallel): histogram column, float-representability, Morton code of the bearing
+  std::vector<uint32_t> bin(N), mort(spatial ? N : 0);
+  std::vector<int> lossless_t(nthreads, 1);
+  std::vector<std::vector<int64_t>> gcount_t(nthreads, std::vector<int64_t>(h->NG, 0));
+  parallel_for(N, [&](int64_t lo, int64_t hi, int t) {
+    bool ll = true;
+    std::vector<int64_t>& gc = gcount_t[t];
+    for (int64_t i = lo; i < hi; i++) {
+      const double* p = reinterpret_cast<const double*>(pbase + i * pstride);
+      if (ll) {
+        for (int k = 0; k < 3; k++)
+          if (double(float(p[k])) != p[k] && p[k] == p[k]) ll = false;
+      }
+      const int b = std::max(0, std::min(B - 1, cast_int(d->intensities[i] * B)));
+      bin[i] = uint32_t(b);
+      gc[b / GW]++;
+      if (spatial) {
+        // bearing cell: the sums are order independent (fixed point), so any order gives the same
+        // bits; a spatially coherent one makes the 64 lanes of a wave gather from neighbouring image
+        // lines for ANY pose (camera and LiDAR are rigidly mounted: a compact patch of bearings stays a
+        // compact patch of pixels)
         const double az = std::atan2(p[1], p[0]);
         const double el = std::atan2(p[2], std::sqrt(p[0] * p[0] + p[1] * p[1]));
         uint32_t qa = uint32_t(std::min(65535.0, std::max(0.0, (az + M_PI) * (65535.0 / (2.0 * M_PI)))));
         uint32_t qe = uint32_t(std::min(65535.0, std::max(0.0, (el + 0.5 * M_PI) * (65535.0 / M_PI))));
         if (!(az == az) || !(el == el)) qa = qe = 0;
-        uint64_t m = 0;
-        for (int b = 0; b < 16; b++) m |= (uint64_t((qa >> b) & 1u) << (2 * b)) | (uint64_t((qe >> b) & 1u) << (2 * b + 1));
-        keyed[i] = std::make_pair((uint64_t(bin[i] / GW) << 32) | m, uint32_t(i));
+        uint32_t m = 0;
+        for (int bb = 0; bb < 16; bb++) m |= (((qa >> bb) & 1u) << (2 * bb)) | (((qe >> bb) & 1u) << (2 * bb + 1));
+        mort[i] = m;
       }
-      std::sort(keyed.begin(), keyed.end());
-      for (int64_t i = 0; i < N; i++) order[i] = keyed[i].second;
-    } else {
+    }
+    lossless_t[t] = ll ? 1 : 0;
+  });
+  bool lossless = true;
+  for (int t = 0; t < nthreads; t++) lossless = lossless && lossless_t[t];
+  std::vector<int64_t> gcount(h->NG + 1, 0);
+  for (int g = 0; g < h->NG; g++) {
+    int64_t c = 0;
+    for (int t = 0; t < nthreads; t++) c += gcount_t[t][g];
+    gcount[g + 1] = gcount[g] + c;
+  }
+  h->rec64 = (d->precision == NIDREG_PREC_FP64 && !lossless) ? 1 : 0;
+  const size_t rec_bytes = h->rec64 ? sizeof(Rec64) : sizeof(Rec32);
+  {
+    // order[k] = source index of the k-th device record: stable bucketing by column group, then (default)
+    // each group sorted by Morton code; NIDREG_FLAG_INPUT_ORDER keeps the caller's order inside groups.
+    std::vector<uint32_t> order(N);
+    {
       std::vector<int64_t> cursor(gcount.begin(), gcount.end() - 1);
       for (int64_t i = 0; i < N; i++) order[cursor[bin[i] / GW]++] = uint32_t(i);
     }
-    std::vector<unsigned char> recs(size_t(std::max<int64_t>(N, 1)) * rec_bytes);
-    for (int64_t dst = 0; dst < N; dst++) {
-      const int64_t i = order[dst];
-      const double* p = reinterpret_cast<const double*>(pbase + i * pstride);
-      if (h->rec64) {
-        Rec64 r;
-        r.x = p[0];
-        r.y = p[1];
-        r.z = p[2];
-        r.bin = bin[i];
-        std::memcpy(recs.data() + size_t(dst) * rec_bytes, &r, rec_bytes);
+    if (spatial) {
+      std::atomic<int> next_group(0);
+      auto worker = [&]() {
+        std::vector<std::pair<uint32_t, uint32_t>> tmp;
+        for (;;) {
+          const int g = next_group.fetch_add(1);
+          if (g >= h->NG) break;
+          const int64_t lo = gcount[g], hi = gcount[g + 1];
+          tmp.resize(size_t(hi - lo));
+          for (int64_t k = lo; k < hi; k++) tmp[size_t(k - lo)] = std::make_pair(mort[order[k]], order[k]);
+          std::sort(tmp.begin(), tmp.end());
+          for (int64_t k = lo; k < hi; k++) order[k] = tmp[size_t(k - lo)].second;
+        }
+      };
+      const int T = N > 200000 ? std::min(nthreads, h->NG) : 1;
+      if (T <= 1) {
+        worker();
       } else {
-        Rec32 r;
-        r.x = float(p[0]);
-        r.y = float(p[1]);
-        r.z = float(p[2]);
-        r.bin = bin[i];
-        std::memcpy(recs.data() + size_t(dst) * rec_bytes, &r, rec_bytes);
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++) th.emplace_back(worker);
+        for (auto& x : th) x.join();
       }
     }
+    std::vector<unsigned char> recs(size_t(std::max<int64_t>(N, 1)) * rec_bytes);
+    parallel_for(N, [&](int64_t lo, int64_t hi, int) {
+      for (int64_t dst = lo; dst < hi; dst++) {
+        const int64_t i = order[dst];
+        const double* p = reinterpret_cast<const double*>(pbase + i * pstride);
+        if (h->rec64) {
+          Rec64 r;
+          r.x = p[0];
+          r.y = p[1];
+          r.z = p[2];
+          r.bin = bin[i];
+          std::memcpy(recs.data() + size_t(dst) * rec_bytes, &r, rec_bytes);
+        } else {
+          Rec32 r;
+          r.x = float(p[0]);
+          r.y = float(p[1]);
+          r.z = float(p[2]);
+          r.bin = bin[i];
+          std::memcpy(recs.data() + size_t(dst) * rec_bytes, &r, rec_bytes);
+        }
+      }
+    });
     CREATE_TRY(hipMalloc(&h->d_pts, recs.size() + 64));
     CREATE_TRY(hipMemcpy(h->d_pts, recs.data(), recs.size(), hipMemcpyHostToDevice));
   }
