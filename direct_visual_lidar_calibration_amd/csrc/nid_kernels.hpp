@@ -42,11 +42,89 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // ------------------------------------------------------------------------------------------
+// "last workgroup finalises" hand-off (cdna_hip_programming.md Guideline 16): every workgroup's
+// stores -> __syncthreads -> one lane: agent-scope release, drained vmcnt, relaxed agent-scope ticket.
+// The workgroup that draws the last ticket does one agent-scope acquire (invalidates its L1) and may
+// then read everybody's partials with plain loads.  The counter is reset for the next launch.
+// s_flag must be an LDS word owned by the caller.
+// WRITE_THROUGH = the payload was stored by wave 0 with agent-scope (sc1, write-through) stores, so
+// no release fence is needed -- a buffer_wbl2 per workgroup costs ~2 us and, with thousands of
+// workgroups, made the fused gradient kernel 50 % slower than a separate finalisation launch.
+template <bool WRITE_THROUGH>
+__device__ __forceinline__ bool last_workgroup_arrives(unsigned int* counter, unsigned int nblocks, int* s_flag) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (!WRITE_THROUGH) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned int t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (t == nblocks - 1u) ? 1 : 0;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    *s_flag = last;
+  }
+  __syncthreads();
+  return *s_flag != 0;
+}
+
+// reduce workgroup partials ([12][nblocks], fixed order -> run-to-run reproducible) and chain M, gt to
+// the ambient 7-gradient of p_cam = p + 2 w (v x p) + 2 v x (v x p) + t  (SURVEY.md Appendix C):
+//   A = (M21 - M12, M02 - M20, M10 - M01);  grad_w = 2 v.A;
+//   grad_v = 2 w A + 2 (M v + M^T v - 2 tr(M) v);  grad_t = gt.
+// out[1..7] = d NID / d [qx qy qz qw tx ty tz]; out_host (nullable) = host-mapped mirror.
+// s_red: kWaves * 12 doubles of LDS.
+__device__ __forceinline__ void grad_final_body(const double* partials, int nblocks, double qx, double qy, double qz, double qw, double* out, double* out_host, double* s_red) {
+  const int tid = threadIdx.x;
+  double acc[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) acc[k] = 0.0;
+  for (int b = tid; b < nblocks; b += kThreads) {
+#pragma unroll
+    for (int k = 0; k < 12; k++) acc[k] += partials[size_t(k) * nblocks + b];
+  }
+  __syncthreads();  // s_red may still be in use by the caller's own reduction
+#pragma unroll
+  for (int k = 0; k < 12; k++) {
+    const double t = wave_sum(acc[k]);
+    if ((tid & 63) == 0) s_red[(tid >> 6) * 12 + k] = t;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double M[12];
+    for (int k = 0; k < 12; k++) {
+      double t = 0.0;
+      for (int w = 0; w < kWaves; w++) t += s_red[w * 12 + k];
+      M[k] = t;
+    }
+    const double A0 = M[7] - M[5], A1 = M[2] - M[6], A2 = M[3] - M[1];
+    const double tr = M[0] + M[4] + M[8];
+    const double Mv0 = M[0] * qx + M[1] * qy + M[2] * qz;
+    const double Mv1 = M[3] * qx + M[4] * qy + M[5] * qz;
+    const double Mv2 = M[6] * qx + M[7] * qy + M[8] * qz;
+    const double Mtv0 = M[0] * qx + M[3] * qy + M[6] * qz;
+    const double Mtv1 = M[1] * qx + M[4] * qy + M[7] * qz;
+    const double Mtv2 = M[2] * qx + M[5] * qy + M[8] * qz;
+    double g[7];
+    g[0] = 2.0 * qw * A0 + 2.0 * (Mv0 + Mtv0 - 2.0 * tr * qx);
+    g[1] = 2.0 * qw * A1 + 2.0 * (Mv1 + Mtv1 - 2.0 * tr * qy);
+    g[2] = 2.0 * qw * A2 + 2.0 * (Mv2 + Mtv2 - 2.0 * tr * qz);
+    g[3] = 2.0 * (qx * A0 + qy * A1 + qz * A2);
+    g[4] = M[9];
+    g[5] = M[10];
+    g[6] = M[11];
+    for (int k = 0; k < 7; k++) out[1 + k] = g[k];
+    if (out_host) {
+      for (int k = 0; k < 7; k++) out_host[1 + k] = g[k];
+      __threadfence_system();
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // pass A (SPLINE): joint histogram with bicubic B-spline soft assignment.
 // LDS: tile[GW*B << cshift] u64 (this workgroup's GW histogram columns, 2^cshift copies) + 1 u32 inlier counter.
-// ABL (development builds only, -DNID_ABLATE): bit0 = no LDS atomics, bit1 = no image loads,
-// bit2 = no projection, bit3 = no flush -- phase ablation for profiling (cdna_hip_programming.md 5.4).
-template <int MODEL, typename Rec, typename real, int ABL = 0>
+template <int MODEL, typename Rec, typename real>
 __global__ __launch_bounds__(kThreads) void k_spline_hist(
   const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint8_t* __restrict__ img, int pitch, int W, int H, PoseParams<real> pose, CamParams<real> cam, int B,
   int GW, int cshift, double magic, u64* __restrict__ hist) {
@@ -69,11 +147,13 @@ __global__ __launch_bounds__(kThreads) void k_spline_hist(
 
   const real fW = real(W), fH = real(H);
   const uint32_t col0 = ch.group * uint32_t(GW);
+  const uint32_t lane_copy = uint32_t(tid) & cmask;
   unsigned int inl = 0;
-  u64 abl_acc = 0;
 
-  // kUnroll records per thread are fetched before any of them is processed: one 16-B load per wave
-  // in flight is latency bound (measured 1.45 TB/s); four keep ~64 KB per CU outstanding
+  // kUnroll records per thread are fetched before any of them is processed (memory-level
+  // parallelism), and the per-point body is branch-free: an outlier (or a slot past the end of the
+  // chunk) runs the same instructions with its knot clamped into the image and its x-weights zeroed,
+  // so it adds exact zeros.  That lets the scheduler interleave the kUnroll independent points.
   for (uint32_t base = 0; base < ch.count; base += kThreads * kUnroll) {
     real xs[kUnroll], ys[kUnroll], zs[kUnroll];
     uint32_t bins_[kUnroll];
@@ -84,49 +164,39 @@ __global__ __launch_bounds__(kThreads) void k_spline_hist(
     }
 #pragma unroll
     for (int k = 0; k < kUnroll; k++) {
-    const uint32_t i = base + uint32_t(k) * kThreads + tid;
-    if (i >= ch.count) break;
-    const real x = xs[k], y = ys[k], z = zs[k];
-    const uint32_t bin = bins_[k];
-    real cx, cy, cz;
-    transform_fma<real>(pose, x, y, z, cx, cy, cz);
-    real u, v;
-    if (ABL & 4) {
-      u = real((bin * 7919u + i * 31u) % uint32_t(W)) + real(0.37) + cx * real(1e-9);
-      v = real((bin * 104729u + i * 17u) % uint32_t(H)) + real(0.61) + cy * real(1e-9) + cz * real(1e-9);
-    } else {
+      const bool valid = base + uint32_t(k) * kThreads + tid < ch.count;
+      real cx, cy, cz;
+      transform_fma<real>(pose, xs[k], ys[k], zs[k], cx, cy, cz);
+      real u, v;
       project<MODEL, real, real, true>(cam, cx, cy, cz, u, v);
-    }
-    // floor(u) in [0,W) and floor(v) in [0,H); NaN / inf / overflow compare false -> outlier
-    // (the reference's int conversion sends those to INT_MIN, nid_cost.hpp:52-58)
-    const bool in = (u >= real(0)) && (u < fW) && (v >= real(0)) && (v < fH);
-    if (in) {
-      inl++;
-      const real fu = m_floor(u), fv = m_floor(v);
+      // floor(u) in [0,W) and floor(v) in [0,H); NaN / inf / overflow compare false -> outlier
+      // (the reference's int conversion sends those to INT_MIN, nid_cost.hpp:52-58)
+      const bool in = valid && (u >= real(0)) && (u < fW) && (v >= real(0)) && (v < fH);
+      inl += in ? 1u : 0u;
+      const real uc = in ? u : real(0), vc = in ? v : real(0);
+      const real fu = m_floor(uc), fv = m_floor(vc);
       const int kx = int(fu), ky = int(fv);
       real bx[4], by[4];
-      bspline<real>(u - fu, bx);
-      bspline<real>(v - fv, by);
-      u64* col = tile + ((((bin - col0) * uint32_t(B)) << cshift) + (uint32_t(tid) & cmask));
+      bspline<real>(uc - fu, bx);
+      bspline<real>(vc - fv, by);
+      const real keep = in ? real(1) : real(0);
+#pragma unroll
+      for (int a = 0; a < 4; a++) bx[a] *= keep;
+      u64* col = tile + ((((bins_[k] - col0) * uint32_t(B)) << cshift) + lane_copy);
       // padded bin image: tap (a,b) of knot (kx,ky) lives at [ky + b][kx + a] (edge-replicated,
       // which is the reference's clamp of knots_x / knots_y, nid_cost.hpp:70-73)
       const uint32_t off0 = uint32_t(ky) * uint32_t(pitch) + uint32_t(kx);
       uint32_t rows[4];  // all four row gathers are issued before the first LDS atomic
 #pragma unroll
-      for (int b = 0; b < 4; b++) rows[b] = (ABL & 2) ? (uint32_t(kx + b) * 2654435761u) ^ (uint32_t(ky) * 40503u) : load_u8x4(img, off0 + uint32_t(b) * uint32_t(pitch));
+      for (int b = 0; b < 4; b++) rows[b] = load_u8x4(img, off0 + uint32_t(b) * uint32_t(pitch));
 #pragma unroll
       for (int b = 0; b < 4; b++) {
-        const uint32_t px4 = rows[b];
 #pragma unroll
         for (int a = 0; a < 4; a++) {
-          const uint32_t r = (ABL & 2) ? ((px4 >> (8 * a)) & 0xffu) % uint32_t(B) : ((px4 >> (8 * a)) & 0xffu);
-          if (ABL & 1)
-            abl_acc += to_fixed(double(bx[a]), double(by[b]), magic) + r;
-          else
-            atomicAdd(&col[r << cshift], to_fixed(double(bx[a]), double(by[b]), magic));  // ds_add_u64
+          const uint32_t r = (rows[b] >> (8 * a)) & 0xffu;
+          atomicAdd(&col[r << cshift], to_fixed(double(bx[a]), double(by[b]), magic));  // ds_add_u64
         }
       }
-    }
     }
   }
 
@@ -139,14 +209,11 @@ __global__ __launch_bounds__(kThreads) void k_spline_hist(
 
   // flush the tile: contiguous in the [bin_points][bin_image] device layout
   u64* dst = hist + size_t(ch.group) * size_t(tile_n);
-  if (!(ABL & 8)) {
-    for (int k = tid; k < tile_n; k += kThreads) {
-      u64 vv = 0;
-      for (uint32_t j = 0; j <= cmask; j++) vv += tile[(uint32_t(k) << cshift) + ((j + uint32_t(k)) & cmask)];  // rotated: conflict-free reads
-      if (vv) atomicAdd(&dst[k], vv);
-    }
+  for (int k = tid; k < tile_n; k += kThreads) {
+    u64 vv = 0;
+    for (uint32_t j = 0; j <= cmask; j++) vv += tile[(uint32_t(k) << cshift) + ((j + uint32_t(k)) & cmask)];  // rotated: conflict-free reads
+    if (vv) atomicAdd(&dst[k], vv);
   }
-  if (ABL && abl_acc == 0x123456789abcull) dst[0] = abl_acc;  // keeps ablated values live
   if (tid == 0 && *s_inl) atomicAdd(&hist[size_t(B) * size_t(B) + kTailInliers], u64(*s_inl));
 }
 
@@ -229,60 +296,16 @@ __global__ __launch_bounds__(kThreads) void k_nearest_hist(
 
 #ifdef NID_COMMON_KERNELS
 // ------------------------------------------------------------------------------------------
-// entropy, part 1: one workgroup per block of CB histogram columns (independent of the point
+// entropy: one workgroup per block of CB histogram columns, the last one to finish runs the tail (independent of the point
 // kernels' tiling).  hist layout [c][r] (c = bin_points, r = bin_image); thread r walks the block's
 // columns (coalesced).  Writes part_hj[j] = sum p log(p + 1e-6) over the block, row_part[j][r] =
 // sum_c h[c][r] (fixed point), col_sum[c] = sum_r h[c][r] (fixed point).
-constexpr int kEntropyColsMax = 16;
-__global__ __launch_bounds__(kThreads) void k_entropy_partial(const u64* __restrict__ hist, int B, int CB, double inv_unit, double* __restrict__ part_hj, u64* __restrict__ row_part, u64* __restrict__ col_sum) {
-  __shared__ u64 s_col[kEntropyColsMax][kWaves];
-  __shared__ double s_red[kWaves];
-  const int tid = threadIdx.x;
-  const int j = blockIdx.x;
-  const int c0 = j * CB;
-  const int ncols = min(CB, B - c0);
-  u64 v[kEntropyColsMax];
-#pragma unroll
-  for (int c = 0; c < kEntropyColsMax; c++) v[c] = (tid < B && c < ncols) ? hist[size_t(c0 + c) * size_t(B) + tid] : 0;  // independent loads
-  const double S = double(hist[size_t(B) * size_t(B) + kTailInliers]);
-  const double scale = inv_unit / S;  // fixed-point word -> probability
-  double acc = 0.0;
-  u64 row = 0;
-#pragma unroll
-  for (int c = 0; c < kEntropyColsMax; c++) {
-    if (v[c]) {
-      const double p = double(v[c]) * scale;
-      acc += p * log(p + 1e-6);
-    }
-    row += v[c];
-    u64 w = v[c];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) w += __shfl_down(w, off, 64);
-    if ((tid & 63) == 0) s_col[c][tid >> 6] = w;
-  }
-  if (tid < B) row_part[size_t(j) * size_t(B) + tid] = row;
-  acc = wave_sum(acc);
-  if ((tid & 63) == 0) s_red[tid >> 6] = acc;
-  __syncthreads();
-  if (tid < ncols) {
-    u64 t = 0;
-    for (int k = 0; k < kWaves; k++) t += s_col[tid][k];
-    col_sum[c0 + tid] = t;
-  }
-  if (tid == 0) {
-    double t = 0.0;
-    for (int w = 0; w < kWaves; w++) t += s_red[w];
-    part_hj[j] = t;
-  }
-}
-
-// entropy, part 2: single workgroup.  hist_image = row sums, hist_points = column sums / unit
+// entropy, part 2 (run by the last workgroup of k_entropy):   hist_image = row sums, hist_points = column sums / unit
 // (partition of unity: the 16 weights of an inlier sum to 1), S = inlier count.
 // nid_cost.hpp:86-104: NID = (Hj - MI) / Hj, MI = Hi + Hp - Hj.
-__global__ __launch_bounds__(kThreads) void k_entropy_final(
-  const u64* __restrict__ hist, int B, int NG, double inv_unit, const double* __restrict__ part_hj, const u64* __restrict__ row_part, const u64* __restrict__ col_sum,
-  double* __restrict__ phi_q, double* __restrict__ hist_image_out, double* __restrict__ hist_points_out, EntropyScalars* __restrict__ scal, double* __restrict__ out) {
-  __shared__ double s_red[3 * kWaves];
+__device__ __forceinline__ void entropy_final_body(
+  const u64* hist, int B, int NG, double inv_unit, const double* part_hj, const u64* row_part, const u64* col_sum, double* phi_q, double* hist_image_out, double* hist_points_out,
+  EntropyScalars* scal, double* out, double* out_host, double* s_red) {
   const int tid = threadIdx.x;
   const double S = double(hist[size_t(B) * size_t(B) + kTailInliers]);
   double hi_acc = 0.0, hp_acc = 0.0, hj_acc = 0.0;
@@ -334,7 +357,61 @@ __global__ __launch_bounds__(kThreads) void k_entropy_final(
     out[0] = nid;
     out[8] = e.status;
     out[9] = S;
+    if (out_host) {
+      out_host[0] = nid;
+      out_host[8] = e.status;
+      out_host[9] = S;
+      __threadfence_system();
+    }
   }
+}
+
+constexpr int kEntropyColsMax = 16;
+__global__ __launch_bounds__(kThreads) void k_entropy(
+  const u64* __restrict__ hist, int B, int CB, double inv_unit, double* part_hj, u64* row_part, u64* col_sum, double* phi_q, double* hist_image_out, double* hist_points_out,
+  EntropyScalars* scal, double* out, double* out_host, unsigned int* counter) {
+  __shared__ u64 s_col[kEntropyColsMax][kWaves];
+  __shared__ double s_red[3 * kWaves];
+  __shared__ int s_flag;
+  const int tid = threadIdx.x;
+  const int j = blockIdx.x;
+  const int c0 = j * CB;
+  const int ncols = min(CB, B - c0);
+  u64 v[kEntropyColsMax];
+#pragma unroll
+  for (int c = 0; c < kEntropyColsMax; c++) v[c] = (tid < B && c < ncols) ? hist[size_t(c0 + c) * size_t(B) + tid] : 0;  // independent loads
+  const double S = double(hist[size_t(B) * size_t(B) + kTailInliers]);
+  const double scale = inv_unit / S;  // fixed-point word -> probability
+  double acc = 0.0;
+  u64 row = 0;
+#pragma unroll
+  for (int c = 0; c < kEntropyColsMax; c++) {
+    if (v[c]) {
+      const double p = double(v[c]) * scale;
+      acc += p * log(p + 1e-6);
+    }
+    row += v[c];
+    u64 w = v[c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) w += __shfl_down(w, off, 64);
+    if ((tid & 63) == 0) s_col[c][tid >> 6] = w;
+  }
+  if (tid < B) row_part[size_t(j) * size_t(B) + tid] = row;
+  acc = wave_sum(acc);
+  if ((tid & 63) == 0) s_red[tid >> 6] = acc;
+  __syncthreads();
+  if (tid < ncols) {
+    u64 t = 0;
+    for (int k = 0; k < kWaves; k++) t += s_col[tid][k];
+    col_sum[c0 + tid] = t;
+  }
+  if (tid == 0) {
+    double t = 0.0;
+    for (int w = 0; w < kWaves; w++) t += s_red[w];
+    part_hj[j] = t;
+  }
+  if (last_workgroup_arrives<false>(counter, gridDim.x, &s_flag))
+    entropy_final_body(hist, B, int(gridDim.x), inv_unit, part_hj, row_part, col_sum, phi_q, hist_image_out, hist_points_out, scal, out, out_host, s_red);
 }
 
 #endif  // NID_COMMON_KERNELS
@@ -345,16 +422,17 @@ __global__ __launch_bounds__(kThreads) void k_entropy_final(
 // Per point: (gx, gy) = sum_taps G * d(w_tap)/d(u, v); gp = (gx gy) * d(uv)/d(p_cam) (Dual3
 // projection); accumulate M += gp p^T (3x3) and gt += gp (3).  One 12-double partial per workgroup.
 // LDS: gtile[GW*B] doubles + kWaves*12 doubles.
-// ABL bits (development builds): bit0 = no G-tile LDS reads, bit1 = no image loads, bit2 = no projection.
-template <int MODEL, typename Rec, typename real, int ABL = 0>
+template <int MODEL, typename Rec, typename real>
 __global__ __launch_bounds__(kThreads) void k_spline_grad(
   const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint8_t* __restrict__ img, int pitch, int W, int H, PoseParams<real> pose, CamParams<real> cam, int B,
-  int GW, int cshift, double inv_unit, const u64* __restrict__ hist, const double* __restrict__ phi_q, const EntropyScalars* __restrict__ scal, double* __restrict__ partials) {
+  int GW, int cshift, double inv_unit, const u64* __restrict__ hist, const double* __restrict__ phi_q, const EntropyScalars* __restrict__ scal, double* partials, double qx,
+  double qy, double qz, double qw, double* out, double* out_host, unsigned int* counter) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* gtile = reinterpret_cast<double*>(smem);
   const int tile_n = GW * B;
   const uint32_t cmask = (1u << cshift) - 1u;  // G is replicated like the histogram tile: lane-private copies, conflict-free ds_read_b64
   double* s_red = gtile + (tile_n << cshift);
+  int* s_flag = reinterpret_cast<int*>(s_red + kWaves * 12);
 
   const int tid = threadIdx.x;
   const Chunk ch = chunks[blockIdx.x];
@@ -374,12 +452,11 @@ __global__ __launch_bounds__(kThreads) void k_spline_grad(
 
   const real fW = real(W), fH = real(H);
   const uint32_t col0 = ch.group * uint32_t(GW);
+  const uint32_t lane_copy = uint32_t(tid) & cmask;
   double acc[12];
 #pragma unroll
   for (int k = 0; k < 12; k++) acc[k] = 0.0;
 
-  // kUnroll records per thread are fetched before any of them is processed: one 16-B load per wave
-  // in flight is latency bound (measured 1.45 TB/s); four keep ~64 KB per CU outstanding
   for (uint32_t base = 0; base < ch.count; base += kThreads * kUnroll) {
     real xs[kUnroll], ys[kUnroll], zs[kUnroll];
     uint32_t bins_[kUnroll];
@@ -390,67 +467,57 @@ __global__ __launch_bounds__(kThreads) void k_spline_grad(
     }
 #pragma unroll
     for (int k = 0; k < kUnroll; k++) {
-    const uint32_t i = base + uint32_t(k) * kThreads + tid;
-    if (i >= ch.count) break;
-    const real x = xs[k], y = ys[k], z = zs[k];
-    const uint32_t bin = bins_[k];
-    real cx, cy, cz;
-    transform_fma<real>(pose, x, y, z, cx, cy, cz);
-    real uu, vv, du[3], dv[3];
-    if (ABL & 4) {
-      uu = real((bin * 7919u + i * 31u) % uint32_t(W)) + real(0.37) + cx * real(1e-9);
-      vv = real((bin * 104729u + i * 17u) % uint32_t(H)) + real(0.61) + cy * real(1e-9) + cz * real(1e-9);
-      du[0] = real(1), du[1] = real(0.5), du[2] = real(0.25);
-      dv[0] = real(0.5), dv[1] = real(1), dv[2] = real(0.25);
-    } else {
+      // (a branch-free body like k_spline_hist's was measured 15 % slower here: 173 VGPRs, 2 waves/SIMD)
+      if (base + uint32_t(k) * kThreads + tid >= ch.count) break;
+      const real x = xs[k], y = ys[k], z = zs[k];
+      real cx, cy, cz;
+      transform_fma<real>(pose, x, y, z, cx, cy, cz);
+      real uu, vv, du[3], dv[3];
       project_jac<MODEL, real>(cam, cx, cy, cz, uu, vv, du, dv);
-    }
-    const bool in = (uu >= real(0)) && (uu < fW) && (vv >= real(0)) && (vv < fH);
-    if (in) {
-      const real fu = m_floor(uu), fv = m_floor(vv);
-      const int kx = int(fu), ky = int(fv);
-      real bx[4], by[4], dbx[4], dby[4];
-      bspline<real>(uu - fu, bx);
-      bspline<real>(vv - fv, by);
-      bspline_deriv<real>(uu - fu, dbx);
-      bspline_deriv<real>(vv - fv, dby);
-      const double* gcol = gtile + ((((bin - col0) * uint32_t(B)) << cshift) + (uint32_t(tid) & cmask));
-      const uint32_t off0 = uint32_t(ky) * uint32_t(pitch) + uint32_t(kx);
-      uint32_t rows[4];
+      const bool in = (uu >= real(0)) && (uu < fW) && (vv >= real(0)) && (vv < fH);
+      if (in) {
+        const real fu = m_floor(uu), fv = m_floor(vv);
+        const int kx = int(fu), ky = int(fv);
+        real bx[4], by[4], dbx[4], dby[4];
+        bspline<real>(uu - fu, bx);
+        bspline<real>(vv - fv, by);
+        bspline_deriv<real>(uu - fu, dbx);
+        bspline_deriv<real>(vv - fv, dby);
+        const double* gcol = gtile + ((((bins_[k] - col0) * uint32_t(B)) << cshift) + lane_copy);
+        const uint32_t off0 = uint32_t(ky) * uint32_t(pitch) + uint32_t(kx);
+        uint32_t rows[4];
 #pragma unroll
-      for (int b = 0; b < 4; b++) rows[b] = (ABL & 2) ? (uint32_t(kx + b) * 2654435761u) ^ (uint32_t(ky) * 40503u) : load_u8x4(img, off0 + uint32_t(b) * uint32_t(pitch));
-      real gx = real(0), gy = real(0);
+        for (int b = 0; b < 4; b++) rows[b] = load_u8x4(img, off0 + uint32_t(b) * uint32_t(pitch));
+        real gx = real(0), gy = real(0);
 #pragma unroll
-      for (int b = 0; b < 4; b++) {
-        const uint32_t px4 = rows[b];
-        real sa = real(0), sb = real(0);
+        for (int b = 0; b < 4; b++) {
+          real sa = real(0), sb = real(0);
 #pragma unroll
-        for (int a = 0; a < 4; a++) {
-          const uint32_t r = (ABL & 2) ? ((px4 >> (8 * a)) & 0xffu) % uint32_t(B) : ((px4 >> (8 * a)) & 0xffu);
-          const real g = (ABL & 1) ? real(r) * real(1e-3) : real(gcol[r << cshift]);
-          sa = fma(g, dbx[a], sa);
-          sb = fma(g, bx[a], sb);
+          for (int a = 0; a < 4; a++) {
+            const real g = real(gcol[((rows[b] >> (8 * a)) & 0xffu) << cshift]);
+            sa = fma(g, dbx[a], sa);
+            sb = fma(g, bx[a], sb);
+          }
+          gx = fma(sa, by[b], gx);
+          gy = fma(sb, dby[b], gy);
         }
-        gx = fma(sa, by[b], gx);
-        gy = fma(sb, dby[b], gy);
+        const double gp0 = double(fma(gx, du[0], gy * dv[0]));
+        const double gp1 = double(fma(gx, du[1], gy * dv[1]));
+        const double gp2 = double(fma(gx, du[2], gy * dv[2]));
+        const double dx = double(x), dy = double(y), dz = double(z);
+        acc[0] = fma(gp0, dx, acc[0]);
+        acc[1] = fma(gp0, dy, acc[1]);
+        acc[2] = fma(gp0, dz, acc[2]);
+        acc[3] = fma(gp1, dx, acc[3]);
+        acc[4] = fma(gp1, dy, acc[4]);
+        acc[5] = fma(gp1, dz, acc[5]);
+        acc[6] = fma(gp2, dx, acc[6]);
+        acc[7] = fma(gp2, dy, acc[7]);
+        acc[8] = fma(gp2, dz, acc[8]);
+        acc[9] += gp0;
+        acc[10] += gp1;
+        acc[11] += gp2;
       }
-      const double gp0 = double(fma(gx, du[0], gy * dv[0]));
-      const double gp1 = double(fma(gx, du[1], gy * dv[1]));
-      const double gp2 = double(fma(gx, du[2], gy * dv[2]));
-      const double dx = double(x), dy = double(y), dz = double(z);
-      acc[0] = fma(gp0, dx, acc[0]);
-      acc[1] = fma(gp0, dy, acc[1]);
-      acc[2] = fma(gp0, dz, acc[2]);
-      acc[3] = fma(gp1, dx, acc[3]);
-      acc[4] = fma(gp1, dy, acc[4]);
-      acc[5] = fma(gp1, dz, acc[5]);
-      acc[6] = fma(gp2, dx, acc[6]);
-      acc[7] = fma(gp2, dy, acc[7]);
-      acc[8] = fma(gp2, dz, acc[8]);
-      acc[9] += gp0;
-      acc[10] += gp1;
-      acc[11] += gp2;
-    }
     }
   }
 
@@ -463,57 +530,18 @@ __global__ __launch_bounds__(kThreads) void k_spline_grad(
   if (tid < 12) {
     double t = 0.0;
     for (int w = 0; w < kWaves; w++) t += s_red[w * 12 + tid];
-    partials[size_t(tid) * gridDim.x + blockIdx.x] = t;  // [12][nchunks]: coalesced for k_grad_final
+    // [12][nchunks] (coalesced for the final reduction), stored write-through at agent scope
+    __hip_atomic_store(&partials[size_t(tid) * gridDim.x + blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  if (last_workgroup_arrives<true>(counter, gridDim.x, s_flag)) grad_final_body(partials, int(gridDim.x), qx, qy, qz, qw, out, out_host, s_red);
 }
 
 #ifdef NID_COMMON_KERNELS
-// reduce workgroup partials (fixed order -> run-to-run reproducible) and chain M, gt to the ambient
-// 7-gradient of p_cam = p + 2 w (v x p) + 2 v x (v x p) + t  (SURVEY.md Appendix C):
-//   A = (M21 - M12, M02 - M20, M10 - M01);  grad_w = 2 v.A;
-//   grad_v = 2 w A + 2 (M v + M^T v - 2 tr(M) v);  grad_t = gt.
-// out[1..7] = d NID / d [qx qy qz qw tx ty tz]
-__global__ __launch_bounds__(kThreads) void k_grad_final(const double* __restrict__ partials, int nblocks, double qx, double qy, double qz, double qw, double* __restrict__ out) {
+// standalone finalisation (only launched for an empty cloud, where k_spline_grad has no workgroups)
+__global__ __launch_bounds__(kThreads) void k_grad_final(const double* partials, int nblocks, double qx, double qy, double qz, double qw, double* out, double* out_host) {
   __shared__ double s_red[kWaves * 12];
-  const int tid = threadIdx.x;
-  double acc[12];
-#pragma unroll
-  for (int k = 0; k < 12; k++) acc[k] = 0.0;
-  for (int b = tid; b < nblocks; b += kThreads) {
-#pragma unroll
-    for (int k = 0; k < 12; k++) acc[k] += partials[size_t(k) * nblocks + b];
-  }
-#pragma unroll
-  for (int k = 0; k < 12; k++) {
-    const double t = wave_sum(acc[k]);
-    if ((tid & 63) == 0) s_red[(tid >> 6) * 12 + k] = t;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    double M[12];
-    for (int k = 0; k < 12; k++) {
-      double t = 0.0;
-      for (int w = 0; w < kWaves; w++) t += s_red[w * 12 + k];
-      M[k] = t;
-    }
-    const double A0 = M[7] - M[5], A1 = M[2] - M[6], A2 = M[3] - M[1];
-    const double tr = M[0] + M[4] + M[8];
-    const double Mv0 = M[0] * qx + M[1] * qy + M[2] * qz;
-    const double Mv1 = M[3] * qx + M[4] * qy + M[5] * qz;
-    const double Mv2 = M[6] * qx + M[7] * qy + M[8] * qz;
-    const double Mtv0 = M[0] * qx + M[3] * qy + M[6] * qz;
-    const double Mtv1 = M[1] * qx + M[4] * qy + M[7] * qz;
-    const double Mtv2 = M[2] * qx + M[5] * qy + M[8] * qz;
-    out[1] = 2.0 * qw * A0 + 2.0 * (Mv0 + Mtv0 - 2.0 * tr * qx);
-    out[2] = 2.0 * qw * A1 + 2.0 * (Mv1 + Mtv1 - 2.0 * tr * qy);
-    out[3] = 2.0 * qw * A2 + 2.0 * (Mv2 + Mtv2 - 2.0 * tr * qz);
-    out[4] = 2.0 * (qx * A0 + qy * A1 + qz * A2);
-    out[5] = M[9];
-    out[6] = M[10];
-    out[7] = M[11];
-  }
+  grad_final_body(partials, nblocks, qx, qy, qz, qw, out, out_host, s_red);
 }
-
 #endif  // NID_COMMON_KERNELS
 
 // GenericCameraBase::project on the device (test / utility path): uv and the 2x3 Jacobian

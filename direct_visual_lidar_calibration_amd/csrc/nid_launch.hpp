@@ -29,6 +29,10 @@ struct PassArgs {
   const double* phi_q;
   const EntropyScalars* scal;
   double* partials;
+  double q[4];          // quaternion of the pose (gradient chain rule)
+  double* out;          // device result block
+  double* out_host;     // host-mapped mirror (nullable)
+  unsigned int* counter;  // last-workgroup ticket
   hipStream_t stream;
   size_t lds_hist, lds_grad;
 };

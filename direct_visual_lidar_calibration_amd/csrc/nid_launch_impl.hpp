@@ -43,34 +43,10 @@ static hipError_t ensure_lds(K kernel, size_t bytes) {
     default: return hipErrorInvalidValue;             \
   }
 
-#ifdef NID_ABLATE
-#include <cstdlib>
-static int ablate_mask(const char* var) {
-  const char* e = std::getenv(var);
-  return e ? std::atoi(e) : 0;
-}
-#define NID_ABL_CASE(K, KERNEL, LDS, ...)                                                                        \
-  case K: {                                                                                                      \
-    auto k = KERNEL<MODEL_PLUMB_BOB, Rec, real, K>;                                                              \
-    hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(kThreads), LDS, a.stream, __VA_ARGS__);                          \
-    return hipGetLastError();                                                                                    \
-  }
-#endif
-
 template <typename real, typename Rec>
 static hipError_t launch_spline_hist_rec(const PassArgs& a) {
   const PoseParams<real> pose = make_pose<real>(a);
   const CamParams<real> cam = make_cam<real>(a.intr, a.dist);
-#ifdef NID_ABLATE
-  if (a.model == MODEL_PLUMB_BOB) {
-    switch (ablate_mask("NIDREG_ABLATE_HIST")) {
-#define NID_A(K) NID_ABL_CASE(K, k_spline_hist, a.lds_hist, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, pose, cam, a.B, a.GW, a.cshift, a.magic, a.hist)
-      NID_A(1) NID_A(2) NID_A(3) NID_A(4) NID_A(5) NID_A(6) NID_A(7) NID_A(8) NID_A(9) NID_A(15)
-#undef NID_A
-      default: break;
-    }
-  }
-#endif
 #define NID_LAUNCH(M)                                                                                                                                  \
   {                                                                                                                                                    \
     auto k = k_spline_hist<M, Rec, real>;                                                                                                              \
@@ -88,23 +64,13 @@ template <typename real, typename Rec>
 static hipError_t launch_spline_grad_rec(const PassArgs& a) {
   const PoseParams<real> pose = make_pose<real>(a);
   const CamParams<real> cam = make_cam<real>(a.intr, a.dist);
-#ifdef NID_ABLATE
-  if (a.model == MODEL_PLUMB_BOB) {
-    switch (ablate_mask("NIDREG_ABLATE_GRAD")) {
-#define NID_A(K) NID_ABL_CASE(K, k_spline_grad, a.lds_grad, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, pose, cam, a.B, a.GW, a.cshift, a.inv_unit, a.hist, a.phi_q, a.scal, a.partials)
-      NID_A(1) NID_A(2) NID_A(3) NID_A(4) NID_A(5) NID_A(6) NID_A(7)
-#undef NID_A
-      default: break;
-    }
-  }
-#endif
 #define NID_LAUNCH(M)                                                                                                                                  \
   {                                                                                                                                                    \
     auto k = k_spline_grad<M, Rec, real>;                                                                                                              \
     hipError_t e = ensure_lds(k, a.lds_grad);                                                                                                          \
     if (e != hipSuccess) return e;                                                                                                                     \
     hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(kThreads), a.lds_grad, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, pose, cam, \
-                       a.B, a.GW, a.cshift, a.inv_unit, a.hist, a.phi_q, a.scal, a.partials);                                                                    \
+                       a.B, a.GW, a.cshift, a.inv_unit, a.hist, a.phi_q, a.scal, a.partials, a.q[0], a.q[1], a.q[2], a.q[3], a.out, a.out_host, a.counter);                                                                    \
   }
   NID_MODEL_SWITCH(NID_LAUNCH)
 #undef NID_LAUNCH

@@ -80,7 +80,9 @@ struct nidreg_handle {
   double* d_hist_points = nullptr;
   EntropyScalars* d_scal = nullptr;
   double* d_partials = nullptr;
-  double* h_out = nullptr;  // pinned
+  double* h_out = nullptr;       // pinned, host-mapped
+  double* d_out_host = nullptr;  // device address of h_out (NULL when results live in ext_out)
+  unsigned int* d_counters = nullptr;  // [0] entropy ticket, [1] gradient ticket
 
   size_t lds_hist = 0, lds_grad = 0, lds_entropy = 0;
   int64_t hist_words = 0;
@@ -112,6 +114,7 @@ void free_handle(nidreg_handle* h) {
   if (h->d_scal) (void)hipFree(h->d_scal);
   if (h->d_partials) (void)hipFree(h->d_partials);
   if (h->h_out) (void)hipHostFree(h->h_out);
+  if (h->d_counters) (void)hipFree(h->d_counters);
   for (int i = 0; i < 6; i++)
     if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -141,6 +144,10 @@ void fill_pass_args(const nidreg_handle* h, PassArgs& a) {
   a.phi_q = h->d_phi_q;
   a.scal = h->d_scal;
   a.partials = h->d_partials;
+  for (int k = 0; k < 4; k++) a.q[k] = h->last_q[k];
+  a.out = h->d_out;
+  a.out_host = h->d_out_host;
+  a.counter = h->d_counters + 1;
   a.stream = h->stream;
   a.lds_hist = h->lds_hist;
   a.lds_grad = h->lds_grad;
@@ -196,11 +203,9 @@ int launch_hist_nearest(nidreg_handle* h, const double* T) {
 
 int launch_entropy(nidreg_handle* h) {
   const double inv_unit = std::ldexp(1.0, -h->frac_bits);
-  hipLaunchKernelGGL(k_entropy_partial, dim3(h->NEB), dim3(kThreads), 0, h->stream, h->d_hist, h->bins, kEntropyCols, inv_unit, h->d_part_hj, h->d_row_part, h->d_col_sum);
-  HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(
-    k_entropy_final, dim3(1), dim3(kThreads), 0, h->stream, h->d_hist, h->bins, h->NEB, inv_unit, h->d_part_hj, h->d_row_part, h->d_col_sum, h->d_phi_q, h->d_hist_image,
-    h->d_hist_points, h->d_scal, h->d_out);
+    k_entropy, dim3(h->NEB), dim3(kThreads), 0, h->stream, h->d_hist, h->bins, kEntropyCols, inv_unit, h->d_part_hj, h->d_row_part, h->d_col_sum, h->d_phi_q, h->d_hist_image,
+    h->d_hist_points, h->d_scal, h->d_out, h->d_out_host, h->d_counters);
   HIP_TRY(hipGetLastError());
   return NIDREG_OK;
 }
@@ -217,8 +222,10 @@ int launch_grad(nidreg_handle* h) {
     HIP_TRY(launch_spline_grad<double>(a));
   }
   if (h->timing) HIP_TRY(hipEventRecord(h->ev[4], h->stream));
-  hipLaunchKernelGGL(k_grad_final, dim3(1), dim3(kThreads), 0, h->stream, h->d_partials, h->nchunks, h->last_q[0], h->last_q[1], h->last_q[2], h->last_q[3], h->d_out);
-  HIP_TRY(hipGetLastError());
+  if (h->nchunks == 0) {  // empty cloud: no gradient workgroups ran, finalise (zeros) stand-alone
+    hipLaunchKernelGGL(k_grad_final, dim3(1), dim3(kThreads), 0, h->stream, h->d_partials, 0, h->last_q[0], h->last_q[1], h->last_q[2], h->last_q[3], h->d_out, h->d_out_host);
+    HIP_TRY(hipGetLastError());
+  }
   return NIDREG_OK;
 }
 
@@ -241,7 +248,7 @@ int eval_launch(nidreg_handle* h, const double* se3, bool want_grad) {
     HIP_TRY(hipEventRecord(h->ev[4], h->stream));
   }
   if (h->timing) HIP_TRY(hipEventRecord(h->ev[5], h->stream));
-  HIP_TRY(hipMemcpyAsync(h->h_out, h->d_out, NIDREG_OUT_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (!h->d_out_host) HIP_TRY(hipMemcpyAsync(h->h_out, h->d_out, NIDREG_OUT_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   return NIDREG_OK;
 }
 
@@ -269,7 +276,7 @@ int iso_launch(nidreg_handle* h, const double* T) {
     HIP_TRY(hipEventRecord(h->ev[5], h->stream));
   }
   h->ev_grad = false;
-  HIP_TRY(hipMemcpyAsync(h->h_out, h->d_out, NIDREG_OUT_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (!h->d_out_host) HIP_TRY(hipMemcpyAsync(h->h_out, h->d_out, NIDREG_OUT_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   return NIDREG_OK;
 }
 
@@ -383,7 +390,7 @@ int nidreg_create(const nidreg_desc* d, nidreg_handle** out) {
   h->NG = (B + GW - 1) / GW;
   h->NEB = (B + kEntropyCols - 1) / kEntropyCols;
   h->lds_hist = (size_t(GW) * B * 8 << cshift) + 16;
-  h->lds_grad = (size_t(GW) * B * 8 << cshift) + size_t(kWaves) * 12 * 8;
+  h->lds_grad = (size_t(GW) * B * 8 << cshift) + size_t(kWaves) * 12 * 8 + 16;
   h->lds_entropy = size_t(B) * 8 + size_t(GW) * 8 + size_t(kWaves) * 8;
 
   // ---- fixed point: sum over a bin <= N * 2^frac must stay below 2^63
@@ -594,8 +601,16 @@ int nidreg_create(const nidreg_desc* d, nidreg_handle** out) {
   CREATE_TRY(hipMalloc(&h->d_hist_points, size_t(B) * sizeof(double)));
   CREATE_TRY(hipMalloc(&h->d_scal, sizeof(EntropyScalars)));
   CREATE_TRY(hipMalloc(&h->d_partials, std::max<size_t>(h->nchunks, 1) * 12 * sizeof(double)));
-  CREATE_TRY(hipHostMalloc(&h->h_out, NIDREG_OUT_DOUBLES * sizeof(double), hipHostMallocDefault));
+  CREATE_TRY(hipHostMalloc(&h->h_out, NIDREG_OUT_DOUBLES * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
   std::memset(h->h_out, 0, NIDREG_OUT_DOUBLES * sizeof(double));
+  if (!d->ext_out) {
+    // results are written straight into host-mapped memory by the finalising workgroups: no D2H copy
+    void* dp = nullptr;
+    CREATE_TRY(hipHostGetDevicePointer(&dp, h->h_out, 0));
+    h->d_out_host = static_cast<double*>(dp);
+  }
+  CREATE_TRY(hipMalloc(&h->d_counters, 4 * sizeof(unsigned int)));
+  CREATE_TRY(hipMemset(h->d_counters, 0, 4 * sizeof(unsigned int)));
   for (int i = 0; i < 6; i++) CREATE_TRY(hipEventCreate(&h->ev[i]));
 #undef CREATE_TRY
   *out = h;
