@@ -59,7 +59,7 @@ class NidregDesc(ctypes.Structure):
 
 EXPORTS = [
     "nidreg_model_from_name", "nidreg_device_count", "nidreg_create", "nidreg_destroy", "nidreg_eval", "nidreg_eval_iso", "nidreg_eval_multi",
-    "nidreg_eval_iso_multi", "nidreg_get_hist", "nidreg_get_hist_fixed", "nidreg_project", "nidreg_project_model", "nidreg_hist_words", "nidreg_shard_hist",
+    "nidreg_eval_iso_multi", "nidreg_get_hist", "nidreg_get_hist_fixed", "nidreg_project", "nidreg_project_model", "nidreg_view_culling", "nidreg_hist_words", "nidreg_shard_hist",
     "nidreg_shard_entropy", "nidreg_shard_grad", "nidreg_shard_finish", "nidreg_set_timing", "nidreg_get_timing", "nidreg_get_info", "nidreg_last_error",
     "nidreg_version",
 ]
@@ -90,6 +90,9 @@ def load():
     lib.nidreg_get_hist_fixed.argtypes = [ctypes.c_void_p, c_int64_p, c_int64_p, ctypes.POINTER(ctypes.c_int)]
     lib.nidreg_project.argtypes = [ctypes.c_void_p, c_double_p, ctypes.c_int64, c_double_p, c_double_p]
     lib.nidreg_project_model.argtypes = [ctypes.c_int, c_double_p, c_double_p, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_int64, c_double_p, c_double_p]
+    lib.nidreg_view_culling.restype = ctypes.c_int64
+    lib.nidreg_view_culling.argtypes = [ctypes.c_int, c_double_p, c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, c_double_p, ctypes.c_int64,
+                                        ctypes.c_int64, c_double_p, ctypes.POINTER(ctypes.c_int32)]
     lib.nidreg_shard_hist.argtypes = [ctypes.c_void_p, c_double_p]
     lib.nidreg_shard_entropy.argtypes = [ctypes.c_void_p]
     lib.nidreg_shard_grad.argtypes = [ctypes.c_void_p]

@@ -743,6 +743,43 @@ int nidreg_project_model(int model_id, const double* intrinsics, const double* d
   return nidreg_project(&tmp, p3, n, uv, jac);
 }
 
+int64_t nidreg_view_culling(int model_id, const double* intrinsics, const double* distortion, int device_id, int width, int height, double min_z, int enable_depth_buffer_culling,
+                            const double* points, int64_t point_stride, int64_t num_points, const double* T_camera_lidar, int32_t* indices_out) {
+  if (model_id < 0 || model_id > 5 || !intrinsics || !distortion || width < 1 || height < 1 || num_points < 0 || !T_camera_lidar || (num_points > 0 && (!points || !indices_out)))
+    return fail(NIDREG_ERR_INVALID, "nidreg_view_culling: bad argument");
+  if (num_points == 0) return 0;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(NIDREG_ERR_NO_DEVICE, "nidreg_view_culling: no HIP device");
+  HIP_TRY(hipSetDevice(device_id));
+  const int64_t stride = point_stride > 0 ? point_stride : 32;
+  if (stride % 8 != 0) return fail(NIDREG_ERR_INVALID, "nidreg_view_culling: point_stride must be a multiple of 8");
+  double* d_pts = nullptr;
+  int* d_pix = nullptr;
+  unsigned int* d_zbuf = nullptr;
+  unsigned char* d_keep = nullptr;
+  std::vector<unsigned char> keep(static_cast<size_t>(num_points));
+  hipError_t e = hipMalloc(&d_pts, size_t(num_points) * size_t(stride));
+  if (e == hipSuccess) e = hipMalloc(&d_pix, size_t(num_points) * sizeof(int));
+  if (e == hipSuccess) e = hipMalloc(&d_zbuf, size_t(width) * height * sizeof(unsigned int));
+  if (e == hipSuccess) e = hipMalloc(&d_keep, size_t(num_points));
+  if (e == hipSuccess) e = hipMemcpy(d_pts, points, size_t(num_points) * size_t(stride), hipMemcpyHostToDevice);
+  // CV_32FC1 filled with saturate_cast<float>(DBL_MAX) = +inf (view_culling.cpp:40) = 0x7f800000
+  if (e == hipSuccess) e = hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(d_zbuf), 0x7f800000, size_t(width) * height);
+  if (e == hipSuccess)
+    e = launch_cull(model_id, intrinsics, distortion, d_pts, stride / 8, num_points, T_camera_lidar, width, height, min_z, enable_depth_buffer_culling ? 1 : 0, d_pix, d_zbuf, d_keep, nullptr);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(keep.data(), d_keep, size_t(num_points), hipMemcpyDeviceToHost);
+  if (d_pts) (void)hipFree(d_pts);
+  if (d_pix) (void)hipFree(d_pix);
+  if (d_zbuf) (void)hipFree(d_zbuf);
+  if (d_keep) (void)hipFree(d_keep);
+  if (e != hipSuccess) return fail(NIDREG_ERR_HIP, std::string("nidreg_view_culling: ") + hipGetErrorString(e));
+  int64_t m = 0;
+  for (int64_t i = 0; i < num_points; i++)
+    if (keep[size_t(i)]) indices_out[m++] = int32_t(i);
+  return m;
+}
+
 int nidreg_shard_hist(nidreg_handle* h, const double* se3) {
   if (!h || !se3) return fail(NIDREG_ERR_INVALID, "nidreg_shard_hist: null argument");
   if (h->mode != NIDREG_MODE_SPLINE) return fail(NIDREG_ERR_INVALID, "nidreg_shard_hist: SPLINE handles only");

@@ -284,6 +284,38 @@ def estimate_camera_fov(proj, image_size, device=0):
     return max_fov
 
 
+class ViewCullingParams:
+    """view_culling.hpp:8-16"""
+
+    def __init__(self, enable_depth_buffer_culling=True):
+        self.enable_depth_buffer_culling = enable_depth_buffer_culling
+
+
+class ViewCulling:
+    """``vlcal::ViewCulling`` (view_culling.hpp:18-39) on the GPU: ``cull(points, T_camera_lidar)`` returns
+    the indices of the points that survive the FoV gate, the in-image test and the depth buffer --
+    the same list, in the same order, as the reference's sequential loop."""
+
+    def __init__(self, proj, image_size, params=None, device=0, min_z=None):
+        self.proj = proj
+        self.image_size = (int(image_size[0]), int(image_size[1]))
+        self.params = params or ViewCullingParams()
+        self.device = device
+        # view_culling.cpp:17: min_z(cos(estimate_camera_fov(proj, image_size)))
+        self.min_z = math.cos(estimate_camera_fov(proj, image_size, device=device)) if min_z is None else float(min_z)
+
+    def cull(self, points, T_camera_lidar):
+        lib = _lib.load()
+        pts = np.ascontiguousarray(points, dtype=np.float64)
+        T = np.ascontiguousarray(np.asarray(T_camera_lidar, dtype=np.float64).reshape(4, 4))
+        idx = np.empty(pts.shape[0], dtype=np.int32)
+        n = lib.nidreg_view_culling(self.proj.model_id, _dp(self.proj._intr5), _dp(self.proj._dist8), self.device, self.image_size[0], self.image_size[1], self.min_z,
+                                    1 if self.params.enable_depth_buffer_culling else 0, _dp(pts), pts.strides[0] if pts.shape[0] else 32, pts.shape[0], _dp(T),
+                                    idx.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+        _lib.check(n, "nidreg_view_culling")
+        return idx[:n].copy()
+
+
 class NIDCostParams:
     """cost_calculator_nid.cpp:7-9"""
 

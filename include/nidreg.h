@@ -17,6 +17,7 @@
  *   nidreg_eval_iso_multi    the Nelder-Mead objective's sum over pairs
  *                                                              (src/vlcal/calib/visual_camera_calibration.cpp:103-119)
  *   nidreg_project           GenericCameraBase::project        (include/camera/generic_camera_base.hpp:29)
+ *   nidreg_view_culling      ViewCulling::cull                 (src/vlcal/calib/view_culling.cpp:21-92)
  *   nidreg_shard_*           (no reference counterpart) split-phase evaluation of one pair whose
  *                            points are sharded over several GPUs; the caller all-reduces the
  *                            fixed-point histogram (RCCL) between the phases.
@@ -149,6 +150,14 @@ int nidreg_project(nidreg_handle* h, const double* p3, int64_t n, double* uv, do
 /* the same without a handle (used for one-time host set-up such as estimate_camera_fov,
  * src/vlcal/common/estimate_fov.cpp:17-51); intrinsics[5] / distortion[8] as in nidreg_desc */
 int nidreg_project_model(int model_id, const double* intrinsics, const double* distortion, int device_id, int precision, const double* p3, int64_t n, double* uv, double* jac);
+
+/* ViewCulling::cull (src/vlcal/calib/view_culling.cpp:21-92) on the device: FoV gate against
+ * min_z = cos(estimate_camera_fov), in-image test, per-pixel depth buffer (float distance) and the
+ * +0.1 m keep threshold.  points: host, (x y z 1) doubles with the given byte stride; T: row-major 4x4
+ * T_camera_lidar.  Writes the surviving indices (ascending, identical to the reference's) into
+ * indices_out (capacity num_points) and returns their number, or a negative error code. */
+int64_t nidreg_view_culling(int model_id, const double* intrinsics, const double* distortion, int device_id, int width, int height, double min_z, int enable_depth_buffer_culling,
+                            const double* points, int64_t point_stride, int64_t num_points, const double* T_camera_lidar, int32_t* indices_out);
 
 /* ---- split-phase evaluation for a pair whose points are sharded across GPUs --------------
  * rank r:  nidreg_shard_hist(h, se3)      zero + accumulate this shard's fixed-point histogram

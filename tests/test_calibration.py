@@ -58,10 +58,12 @@ def test_final_extrinsics_match_cpu_path(model, reg, bins):
     x_ref, log_ref = run_oracle(s, reg, bins)
     proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
     max_fov = oracle_lib.estimate_camera_fov(s.model, s.intrinsics, s.distortion, s.width, s.height)
+    gpu_cull = nid.ViewCulling(proj, (s.width, s.height), min_z=np.cos(max_fov))  # the whole inner loop on the GPU: culling + cost
     p = calibration.VisualCameraCalibrationParams(nid_bins=bins, registration_type=reg, max_outer_iterations=3)
     cal = calibration.VisualCameraCalibration(
         [(s.image_u8, s.points, s.intensities)], p, nid_cost_factory=lambda i, pt, it, b: nid.NIDCost(proj, i, pt, it, b),
-        nearest_cost_factory=lambda i, pt, it, b: nid.CostCalculatorNID(proj, i, pt, it, nid.NIDCostParams(b), max_fov=max_fov), cull=oracle_cull(s),
+        nearest_cost_factory=lambda i, pt, it, b: nid.CostCalculatorNID(proj, i, pt, it, nid.NIDCostParams(b), max_fov=max_fov),
+        cull=lambda pts, ints, T: gpu_cull.cull(pts, T),
         multi_factory=lambda init, costs: _multi(nid, init, costs))
     x_gpu = cal.calibrate(s.T_camera_lidar_init)
     dt, dr = se3.delta_trans_rot(x_ref, x_gpu)

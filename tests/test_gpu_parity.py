@@ -306,3 +306,31 @@ def test_full_size_properties_cfg2_like():
         fd = (cp - cm) / (2 * h)
         assert abs(fd - gt[k]) <= 1e-4 * max(1.0, abs(gt[k])), (k, fd, gt[k])
     full.close()
+
+
+@pytest.mark.parametrize("model", list(CAMERAS))
+def test_view_culling_indices_identical(model):
+    """ViewCulling::cull on the GPU returns exactly the reference's surviving index list: FoV gate on
+    the normalised 4-vector, in-image test, float depth buffer with the +0.1 m threshold."""
+    s = scene_for(model, n=20000)
+    T = se3.to_matrix(s.T_camera_lidar_init)
+    Tinv = np.linalg.inv(T)
+    pc = s.points[:5000, :3] @ T[:3, :3].T + T[:3, 3]
+    far = pc * (1.0 + 1.0 / np.linalg.norm(pc, axis=1, keepdims=True))  # occluded copies 1 m behind
+    near = pc * (1.0 + 0.05 / np.linalg.norm(pc, axis=1, keepdims=True))  # within the 0.1 m threshold
+    behind = -pc
+    extra = np.concatenate([far, near, behind]) @ Tinv[:3, :3].T + Tinv[:3, 3]
+    pts = np.concatenate([s.points, np.concatenate([extra, np.ones((extra.shape[0], 1))], -1)])
+    pts[7, :3] = np.nan
+    proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
+    min_z = np.cos(oracle_lib.estimate_camera_fov(s.model, s.intrinsics, s.distortion, s.width, s.height))
+    for depth in (True, False):
+        vc = nid.ViewCulling(proj, (s.width, s.height), nid.ViewCullingParams(depth), min_z=min_z)
+        got = vc.cull(pts, T)
+        ref = oracle_lib.view_culling(s.model, s.intrinsics, s.distortion, s.width, s.height, pts, T, depth)
+        assert np.array_equal(got, ref)
+        assert 0 < got.shape[0] < pts.shape[0]
+    # and with min_z estimated on the device-projection path (estimate_camera_fov restated on the host)
+    vc = nid.ViewCulling(proj, (s.width, s.height))
+    assert abs(vc.min_z - min_z) < 1e-6
+    assert vc.cull(np.zeros((0, 4)), T).shape == (0,)
