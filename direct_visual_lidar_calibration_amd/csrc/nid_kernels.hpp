@@ -19,11 +19,14 @@ namespace nidreg {
 
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
-constexpr int kUnroll = 4;  // point records in flight per thread
+#ifndef NID_UNROLL
+#define NID_UNROLL 4
+#endif
+constexpr int kUnroll = NID_UNROLL;  // point records in flight per thread
 
 // tail words behind the B*B joint histogram
 constexpr int kTailInliers = 0;  // number of inlier points (plain count)
-constexpr int kTailWords = 8;
+constexpr int kTailWords = 8;     // followed by B column sums (sum_r h[c][r], fixed point) written by the flush
 
 // scalars written by k_entropy_final for k_spline_grad / the host
 struct EntropyScalars {
@@ -137,12 +140,14 @@ __global__ __launch_bounds__(kThreads) void k_spline_hist(
   // 80 % of LDS cycles were bank-conflict cycles)
   const int tile_w = tile_n << cshift;
   const uint32_t cmask = (1u << cshift) - 1u;
-  unsigned int* s_inl = reinterpret_cast<unsigned int*>(tile + tile_w);
+  u64* s_colsum = tile + tile_w;  // GW words: this workgroup's contribution to each column sum
+  unsigned int* s_inl = reinterpret_cast<unsigned int*>(s_colsum + GW);
 
   const int tid = threadIdx.x;
   const Chunk ch = chunks[blockIdx.x];
   for (int k = tid; k < tile_w; k += kThreads) tile[k] = 0;
   if (tid == 0) *s_inl = 0;
+  if (tid < GW) s_colsum[tid] = 0;
   __syncthreads();
 
   const real fW = real(W), fH = real(H);
@@ -212,8 +217,13 @@ __global__ __launch_bounds__(kThreads) void k_spline_hist(
   for (int k = tid; k < tile_n; k += kThreads) {
     u64 vv = 0;
     for (uint32_t j = 0; j <= cmask; j++) vv += tile[(uint32_t(k) << cshift) + ((j + uint32_t(k)) & cmask)];  // rotated: conflict-free reads
-    if (vv) atomicAdd(&dst[k], vv);
+    if (vv) {
+      atomicAdd(&dst[k], vv);
+      atomicAdd(&s_colsum[k / B], vv);
+    }
   }
+  __syncthreads();
+  if (tid < GW && s_colsum[tid]) atomicAdd(&hist[size_t(B) * size_t(B) + kTailWords + col0 + uint32_t(tid)], s_colsum[tid]);
   if (tid == 0 && *s_inl) atomicAdd(&hist[size_t(B) * size_t(B) + kTailInliers], u64(*s_inl));
 }
 
@@ -231,12 +241,14 @@ __global__ __launch_bounds__(kThreads) void k_nearest_hist(
   const int tile_n = GW * B;
   const int tile_w = tile_n << cshift;
   const uint32_t cmask = (1u << cshift) - 1u;
-  unsigned int* s_inl = reinterpret_cast<unsigned int*>(tile + tile_w);
+  u64* s_colsum = tile + tile_w;  // GW words: this workgroup's contribution to each column sum
+  unsigned int* s_inl = reinterpret_cast<unsigned int*>(s_colsum + GW);
 
   const int tid = threadIdx.x;
   const Chunk ch = chunks[blockIdx.x];
   for (int k = tid; k < tile_w; k += kThreads) tile[k] = 0;
   if (tid == 0) *s_inl = 0;
+  if (tid < GW) s_colsum[tid] = 0;
   __syncthreads();
 
   const real fW = real(W), fH = real(H);
@@ -289,8 +301,13 @@ __global__ __launch_bounds__(kThreads) void k_nearest_hist(
   for (int k = tid; k < tile_n; k += kThreads) {
     u64 vv = 0;
     for (uint32_t j = 0; j <= cmask; j++) vv += tile[(uint32_t(k) << cshift) + ((j + uint32_t(k)) & cmask)];
-    if (vv) atomicAdd(&dst[k], vv);
+    if (vv) {
+      atomicAdd(&dst[k], vv);
+      atomicAdd(&s_colsum[k / B], vv);
+    }
   }
+  __syncthreads();
+  if (tid < GW && s_colsum[tid]) atomicAdd(&hist[size_t(B) * size_t(B) + kTailWords + col0 + uint32_t(tid)], s_colsum[tid]);
   if (tid == 0 && *s_inl) atomicAdd(&hist[size_t(B) * size_t(B) + kTailInliers], u64(*s_inl));
 }
 
@@ -299,7 +316,7 @@ __global__ __launch_bounds__(kThreads) void k_nearest_hist(
 // entropy: one workgroup per block of CB histogram columns, the last one to finish runs the tail (independent of the point
 // kernels' tiling).  hist layout [c][r] (c = bin_points, r = bin_image); thread r walks the block's
 // columns (coalesced).  Writes part_hj[j] = sum p log(p + 1e-6) over the block, row_part[j][r] =
-// sum_c h[c][r] (fixed point), col_sum[c] = sum_r h[c][r] (fixed point).
+// sum_c h[c][r] (fixed point); the column sums sum_r h[c][r] come from the histogram kernels' flush.
 // entropy, part 2 (run by the last workgroup of k_entropy):   hist_image = row sums, hist_points = column sums / unit
 // (partition of unity: the 16 weights of an inlier sum to 1), S = inlier count.
 // nid_cost.hpp:86-104: NID = (Hj - MI) / Hj, MI = Hi + Hp - Hj.
@@ -368,9 +385,8 @@ __device__ __forceinline__ void entropy_final_body(
 
 constexpr int kEntropyColsMax = 16;
 __global__ __launch_bounds__(kThreads) void k_entropy(
-  const u64* __restrict__ hist, int B, int CB, double inv_unit, double* part_hj, u64* row_part, u64* col_sum, double* phi_q, double* hist_image_out, double* hist_points_out,
+  const u64* __restrict__ hist, int B, int CB, double inv_unit, double* part_hj, u64* row_part, double* phi_q, double* hist_image_out, double* hist_points_out,
   EntropyScalars* scal, double* out, double* out_host, unsigned int* counter) {
-  __shared__ u64 s_col[kEntropyColsMax][kWaves];
   __shared__ double s_red[3 * kWaves];
   __shared__ int s_flag;
   const int tid = threadIdx.x;
@@ -391,25 +407,17 @@ __global__ __launch_bounds__(kThreads) void k_entropy(
       acc += p * log(p + 1e-6);
     }
     row += v[c];
-    u64 w = v[c];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) w += __shfl_down(w, off, 64);
-    if ((tid & 63) == 0) s_col[c][tid >> 6] = w;
   }
   if (tid < B) row_part[size_t(j) * size_t(B) + tid] = row;
   acc = wave_sum(acc);
   if ((tid & 63) == 0) s_red[tid >> 6] = acc;
   __syncthreads();
-  if (tid < ncols) {
-    u64 t = 0;
-    for (int k = 0; k < kWaves; k++) t += s_col[tid][k];
-    col_sum[c0 + tid] = t;
-  }
   if (tid == 0) {
     double t = 0.0;
     for (int w = 0; w < kWaves; w++) t += s_red[w];
     part_hj[j] = t;
   }
+  const u64* col_sum = hist + size_t(B) * size_t(B) + kTailWords;  // accumulated by the histogram kernels' flush
   if (last_workgroup_arrives<false>(counter, gridDim.x, &s_flag))
     entropy_final_body(hist, B, int(gridDim.x), inv_unit, part_hj, row_part, col_sum, phi_q, hist_image_out, hist_points_out, scal, out, out_host, s_red);
 }

@@ -74,7 +74,6 @@ struct nidreg_handle {
   bool own_out = false;
   double* d_part_hj = nullptr;
   u64* d_row_part = nullptr;
-  u64* d_col_sum = nullptr;
   double* d_phi_q = nullptr;
   double* d_hist_image = nullptr;
   double* d_hist_points = nullptr;
@@ -107,7 +106,6 @@ void free_handle(nidreg_handle* h) {
   if (h->own_out && h->d_out) (void)hipFree(h->d_out);
   if (h->d_part_hj) (void)hipFree(h->d_part_hj);
   if (h->d_row_part) (void)hipFree(h->d_row_part);
-  if (h->d_col_sum) (void)hipFree(h->d_col_sum);
   if (h->d_phi_q) (void)hipFree(h->d_phi_q);
   if (h->d_hist_image) (void)hipFree(h->d_hist_image);
   if (h->d_hist_points) (void)hipFree(h->d_hist_points);
@@ -204,7 +202,7 @@ int launch_hist_nearest(nidreg_handle* h, const double* T) {
 int launch_entropy(nidreg_handle* h) {
   const double inv_unit = std::ldexp(1.0, -h->frac_bits);
   hipLaunchKernelGGL(
-    k_entropy, dim3(h->NEB), dim3(kThreads), 0, h->stream, h->d_hist, h->bins, kEntropyCols, inv_unit, h->d_part_hj, h->d_row_part, h->d_col_sum, h->d_phi_q, h->d_hist_image,
+    k_entropy, dim3(h->NEB), dim3(kThreads), 0, h->stream, h->d_hist, h->bins, kEntropyCols, inv_unit, h->d_part_hj, h->d_row_part, h->d_phi_q, h->d_hist_image,
     h->d_hist_points, h->d_scal, h->d_out, h->d_out_host, h->d_counters);
   HIP_TRY(hipGetLastError());
   return NIDREG_OK;
@@ -332,7 +330,7 @@ int nidreg_device_count(void) {
 
 int64_t nidreg_hist_words(int bins) {
   // room for a partially filled last column group plus the tail words
-  return int64_t(bins) * bins + kTailWords;
+  return int64_t(bins) * bins + kTailWords + ((bins + 7) & ~7);  // joint histogram, tail, column sums
 }
 
 int nidreg_create(const nidreg_desc* d, nidreg_handle** out) {
@@ -389,7 +387,7 @@ int nidreg_create(const nidreg_desc* d, nidreg_handle** out) {
   h->cshift = cshift;
   h->NG = (B + GW - 1) / GW;
   h->NEB = (B + kEntropyCols - 1) / kEntropyCols;
-  h->lds_hist = (size_t(GW) * B * 8 << cshift) + 16;
+  h->lds_hist = (size_t(GW) * B * 8 << cshift) + size_t(GW) * 8 + 16;
   h->lds_grad = (size_t(GW) * B * 8 << cshift) + size_t(kWaves) * 12 * 8 + 16;
   h->lds_entropy = size_t(B) * 8 + size_t(GW) * 8 + size_t(kWaves) * 8;
 
@@ -595,7 +593,6 @@ int nidreg_create(const nidreg_desc* d, nidreg_handle** out) {
   CREATE_TRY(hipMemset(h->d_hist, 0, size_t(h->hist_words) * sizeof(u64)));
   CREATE_TRY(hipMalloc(&h->d_part_hj, size_t(h->NEB) * sizeof(double)));
   CREATE_TRY(hipMalloc(&h->d_row_part, size_t(h->NEB) * B * sizeof(u64)));
-  CREATE_TRY(hipMalloc(&h->d_col_sum, size_t(B) * sizeof(u64)));
   CREATE_TRY(hipMalloc(&h->d_phi_q, size_t(B) * sizeof(double)));
   CREATE_TRY(hipMalloc(&h->d_hist_image, size_t(B) * sizeof(double)));
   CREATE_TRY(hipMalloc(&h->d_hist_points, size_t(B) * sizeof(double)));

@@ -167,7 +167,7 @@ int64_t nidreg_view_culling(int model_id, const double* intrinsics, const double
  *          <caller: all-reduce(sum, f64) of out[1..7]>
  *          nidreg_shard_finish(h, ...)    stream sync + read back
  * All shard calls are asynchronous on the handle's stream except nidreg_shard_finish. */
-int64_t nidreg_hist_words(int bins); /* 64-bit words in the histogram buffer (bins*bins + tail) */
+int64_t nidreg_hist_words(int bins); /* 64-bit words in the histogram buffer (bins*bins + 8 tail words + column sums) */
 int nidreg_shard_hist(nidreg_handle* h, const double* se3);
 int nidreg_shard_entropy(nidreg_handle* h);
 int nidreg_shard_grad(nidreg_handle* h);

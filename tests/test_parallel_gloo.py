@@ -34,7 +34,7 @@ class OracleShardBackend:
         self.ol = oracle_lib
         self.s = scene
         self.lo, self.hi, self.B = lo, hi, bins
-        self.hist_tensor = torch.zeros(bins * bins + 8, dtype=torch.int64)
+        self.hist_tensor = torch.zeros(bins * bins + 8 + bins, dtype=torch.int64)
         self.grad_tensor = torch.zeros(7, dtype=torch.float64)
 
     def shard_hist(self, x):
