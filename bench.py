@@ -35,6 +35,25 @@ def algorithmic_bytes(n_points, width, height, bins):
     return 16 * n_points + width * height + 8 * (bins * bins + 2 * bins) + 64
 
 
+def pmc_traffic(kernel, n_points, width, height, bins, precision):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_traffic.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of the same workload, FETCH_SIZE doubled
+    for the 16 B/lane point stream as MI355X_MICROARCH.md prescribes).  None when no pass matches."""
+    import glob
+
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
+        try:
+            with open(path) as f:
+                t = json.load(f)
+        except (OSError, ValueError):
+            continue
+        w = t.get("workload", {})
+        if (w.get("points"), w.get("width"), w.get("height"), w.get("bins"), w.get("precision")) == (n_points, width, height, bins, precision) and kernel in t.get("kernels", {}):
+            best = t["kernels"][kernel]["hbm_bytes_corrected"]
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -151,7 +170,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None,
+            "traffic": pmc_traffic(dom, n_local, scene.width, scene.height, args.bins, args.precision),
             "launch_bytes": launch_bytes,
             "kernel_ms": {k_: round(v, 4) for k_, v in kt.items()},
             "eval_bytes": eval_bytes,

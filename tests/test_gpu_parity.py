@@ -334,3 +334,50 @@ def test_view_culling_indices_identical(model):
     vc = nid.ViewCulling(proj, (s.width, s.height))
     assert abs(vc.min_z - min_z) < 1e-6
     assert vc.cull(np.zeros((0, 4)), T).shape == (0,)
+
+
+def test_sharded_cost_single_process_matches_plain():
+    """ShardedNIDCost's device plumbing (torch-owned histogram / result buffers, torch's current
+    stream, split-phase calls) on one GPU: two shards evaluated back to back into the SAME histogram
+    buffer reproduce the unsharded result bit for bit (what the RCCL all-reduce does across ranks)."""
+    import torch
+
+    from direct_visual_lidar_calibration_amd import _lib, parallel
+
+    s = scene_for("plumb_bob", n=30000)
+    proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
+    x = s.T_camera_lidar_init
+    plain = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, 64)
+    ok, c, g = plain(x)
+    fx, inl, frac = plain.histogram_fixed()
+    # world-size-1 path of the product class
+    sh = parallel.ShardedNIDCost(proj, s.image_f64, s.points, s.intensities, 64, device=0)
+    ok1, c1, g1 = sh(x)
+    assert ok1 and c1 == c and np.array_equal(g1, g)
+    ok2, c2, g2 = sh(x, want_grad=False)
+    assert ok2 and c2 == c and g2 is None
+    sh.close()
+    # two shards, manual "all-reduce" = sum of the two fixed-point buffers on the device
+    n = s.points.shape[0]
+    lo, hi = parallel.shard_slice(n, 0, 2), parallel.shard_slice(n, 1, 2)
+    backs = [parallel._GpuShardBackend(proj, s.image_f64, s.points[a:b], s.intensities[a:b], 64, n, 0, "fp64") for a, b in (lo, hi)]
+    for b in backs:
+        b.shard_hist(x)
+    total = backs[0].hist_tensor + backs[1].hist_tensor
+    torch.cuda.synchronize()
+    B = 64
+    assert int(total[B * B].item()) == inl
+    assert np.array_equal(total[: B * B].cpu().numpy().reshape(B, B).T, fx)  # device layout [bin_points][bin_image]
+    grads = []
+    for b in backs:
+        b.hist_tensor.copy_(total)
+        b.shard_entropy()
+        b.shard_grad()
+    torch.cuda.synchronize()
+    gsum = (backs[0].grad_tensor + backs[1].grad_tensor).cpu().numpy()
+    oks = [b.shard_finish(True) for b in backs]
+    assert all(o[0] for o in oks) and oks[0][1] == c and oks[1][1] == c
+    assert np.allclose(gsum, g, rtol=1e-12, atol=1e-15)
+    for b in backs:
+        b.cost.close()
+    plain.close()
