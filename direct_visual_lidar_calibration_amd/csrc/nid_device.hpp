@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace nidreg {
 
 typedef unsigned long long u64;
@@ -128,13 +130,24 @@ struct IsoParams {
 enum { MODEL_PLUMB_BOB = 0, MODEL_FISHEYE = 1, MODEL_OMNIDIR = 2, MODEL_EQUIRECT = 3, MODEL_ATAN = 4, MODEL_RATIONAL = 5 };
 
 // ------------------------------------------------------------------------------------------
-// projection models (reference: include/camera/{pinhole,fisheye,omnidir,equirectangular,atan,
-// rational_polynomial}.hpp), T = real or Dual3<real>.
-// perspective division: exact x/z, y/z (NEAREST path: bit-identical to the CPU) or one reciprocal and
-// two multiplies (SPLINE kernels; both passes use the same form, so they agree on every knot)
-template <bool RCP, typename real>
+// a*b + c: one fused multiply-add in the FAST (SPLINE) instantiation when all operands are plain
+// scalars, an unfused multiply then add otherwise (NEAREST path: bit-identical to the CPU, which has
+// no fma; Dual3 operands: their operators).  Every use below nests the terms so that the unfused
+// form reproduces the reference's left-to-right association exactly (fp addition is commutative).
+template <bool FAST, typename A, typename B, typename C>
+__device__ __forceinline__ auto mad(const A& a, const B& b, const C& c) -> decltype(a * b + c) {
+  if constexpr (FAST && std::is_floating_point<A>::value && std::is_floating_point<B>::value && std::is_floating_point<C>::value) {
+    return fma(a, b, c);
+  } else {
+    return a * b + c;
+  }
+}
+
+// perspective division: exact x/z, y/z (NEAREST path) or one reciprocal and two multiplies (SPLINE
+// kernels; both passes use the same form, so they agree on every knot)
+template <bool FAST, typename real>
 __device__ __forceinline__ void persp(real x, real y, real z, real& px, real& py) {
-  if (RCP) {
+  if (FAST) {
     const real iz = real(1) / z;
     px = x * iz;
     py = y * iz;
@@ -143,46 +156,48 @@ __device__ __forceinline__ void persp(real x, real y, real z, real& px, real& py
     py = y / z;
   }
 }
-template <bool RCP, typename real>
+template <bool FAST, typename real>
 __device__ __forceinline__ void persp(const Dual3<real>& x, const Dual3<real>& y, const Dual3<real>& z, Dual3<real>& px, Dual3<real>& py) {
   px = x / z;  // Dual3 division is reciprocal-multiply already
   py = y / z;
 }
 
-template <int MODEL, typename T, typename real, bool RCP = false>
+// projection models (reference: include/camera/{pinhole,fisheye,omnidir,equirectangular,atan,
+// rational_polynomial}.hpp), T = real or Dual3<real>.
+template <int MODEL, typename T, typename real, bool FAST = false>
 __device__ __forceinline__ void project(const CamParams<real>& c, const T& x, const T& y, const T& z, T& u, T& v) {
   if (MODEL == MODEL_PLUMB_BOB) {  // pinhole.hpp:13-51, distortion k1 k2 p1 p2 k3
     const real k1 = c.dist[0], k2 = c.dist[1], p1 = c.dist[2], p2 = c.dist[3], k3 = c.dist[4];
     T px, py;
-    persp<RCP>(x, y, z, px, py);
+    persp<FAST>(x, y, z, px, py);
     const T x2 = px * px, y2 = py * py;
-    const T r2 = x2 + y2;
+    const T r2 = mad<FAST>(px, px, y2);                                   // x2 + y2
     const T r4 = r2 * r2;
     const T r6 = r2 * r4;
-    const T rc = real(1) + k1 * r2 + k2 * r4 + k3 * r6;
+    const T rc = mad<FAST>(k3, r6, mad<FAST>(k2, r4, mad<FAST>(k1, r2, real(1))));  // 1 + k1 r2 + k2 r4 + k3 r6
     const T t1 = real(2) * px * py;
-    const T t2 = r2 + real(2) * x2;
-    const T t3 = r2 + real(2) * y2;
-    const T dx = rc * px + p1 * t1 + p2 * t2;
-    const T dy = rc * py + p1 * t3 + p2 * t1;
-    u = c.intr[0] * dx + c.intr[2];
-    v = c.intr[1] * dy + c.intr[3];
+    const T t2 = mad<FAST>(real(2), x2, r2);                              // r2 + 2 x2
+    const T t3 = mad<FAST>(real(2), y2, r2);
+    const T dx = mad<FAST>(p2, t2, mad<FAST>(p1, t1, rc * px));           // rc px + p1 t1 + p2 t2
+    const T dy = mad<FAST>(p2, t1, mad<FAST>(p1, t3, rc * py));           // rc py + p1 t3 + p2 t1
+    u = mad<FAST>(c.intr[0], dx, c.intr[2]);
+    v = mad<FAST>(c.intr[1], dy, c.intr[3]);
   } else if (MODEL == MODEL_FISHEYE) {  // fisheye.hpp:14-36 (abs(z) at :16)
     const real k1 = c.dist[0], k2 = c.dist[1], k3 = c.dist[2], k4 = c.dist[3];
-    const T r = m_sqrt(x * x + y * y);
+    const T r = m_sqrt(mad<FAST>(x, x, y * y));
     const T theta = m_atan2(r, m_abs(z));
     const T th2 = theta * theta;
     const T th4 = th2 * th2;
     const T th6 = th4 * th2;
     const T th8 = th4 * th4;
-    const T theta_d = theta * (real(1) + k1 * th2 + k2 * th4 + k3 * th6 + k4 * th8);
+    const T theta_d = theta * mad<FAST>(k4, th8, mad<FAST>(k3, th6, mad<FAST>(k2, th4, mad<FAST>(k1, th2, real(1)))));
     const T s = theta_d / r;
-    u = c.intr[0] * (s * x) + c.intr[2];
-    v = c.intr[1] * (s * y) + c.intr[3];
+    u = mad<FAST>(c.intr[0], s * x, c.intr[2]);
+    v = mad<FAST>(c.intr[1], s * y, c.intr[3]);
   } else if (MODEL == MODEL_OMNIDIR) {  // omnidir.hpp:14-41
     const real xi = c.intr[4];
     const real k1 = c.dist[0], k2 = c.dist[1], p1 = c.dist[2], p2 = c.dist[3];
-    const T n2 = x * x + y * y + z * z;
+    const T n2 = mad<FAST>(z, z, mad<FAST>(y, y, x * x));                 // x x + y y + z z
     T sx = x, sy = y, sz = z;
     if (n2 > real(0)) {
       const T n = m_sqrt(n2);
@@ -192,16 +207,16 @@ __device__ __forceinline__ void project(const CamParams<real>& c, const T& x, co
     }
     const T den = sz + xi;
     const T ux = sx / den, uy = sy / den;
-    const T r2 = ux * ux + uy * uy;
-    const T r4 = r2 * r2;
-    const T dr = real(1) + k1 * r2 + k2 * r4;
     const T x2 = ux * ux, y2 = uy * uy, xy = ux * uy;
-    const T nx = ux * dr + (real(2) * p1) * xy + p2 * (r2 + real(2) * x2);
-    const T ny = uy * dr + p1 * (r2 + real(2) * y2) + (real(2) * p2) * xy;
-    u = c.intr[0] * nx + c.intr[2];
-    v = c.intr[1] * ny + c.intr[3];
+    const T r2 = mad<FAST>(ux, ux, y2);
+    const T r4 = r2 * r2;
+    const T dr = mad<FAST>(k2, r4, mad<FAST>(k1, r2, real(1)));
+    const T nx = mad<FAST>(p2, mad<FAST>(real(2), x2, r2), mad<FAST>(real(2) * p1, xy, ux * dr));
+    const T ny = mad<FAST>(real(2) * p2, xy, mad<FAST>(p1, mad<FAST>(real(2), y2, r2), uy * dr));
+    u = mad<FAST>(c.intr[0], nx, c.intr[2]);
+    v = mad<FAST>(c.intr[1], ny, c.intr[3]);
   } else if (MODEL == MODEL_EQUIRECT) {  // equirectangular.hpp:14-28, intr = [W H]
-    const T n2 = x * x + y * y + z * z;
+    const T n2 = mad<FAST>(z, z, mad<FAST>(y, y, x * x));
     if (n2 < real(1e-3)) {
       u = T(c.intr[0] / real(2));
       v = T(c.intr[1] / real(2));
@@ -216,8 +231,8 @@ __device__ __forceinline__ void project(const CamParams<real>& c, const T& x, co
   } else if (MODEL == MODEL_ATAN) {  // atan.hpp:14-39
     const real d0 = c.dist[0];
     T px, py;
-    persp<RCP>(x, y, z, px, py);
-    const T r = m_sqrt(px * px + py * py);
+    persp<FAST>(x, y, z, px, py);
+    const T r = m_sqrt(mad<FAST>(px, px, py * py));
     T dx = px, dy = py;
     if (!(r < real(1e-3) || d0 < real(1e-7))) {
       const real d1 = real(1) / d0;
@@ -226,27 +241,27 @@ __device__ __forceinline__ void project(const CamParams<real>& c, const T& x, co
       dx = factor * px;
       dy = factor * py;
     }
-    u = c.intr[0] * dx + c.intr[2];
-    v = c.intr[1] * dy + c.intr[3];
+    u = mad<FAST>(c.intr[0], dx, c.intr[2]);
+    v = mad<FAST>(c.intr[1], dy, c.intr[3]);
   } else {  // rational_polynomial.hpp:11-58, k1 k2 p1 p2 k3 k4 k5 k6
     const real k1 = c.dist[0], k2 = c.dist[1], p1 = c.dist[2], p2 = c.dist[3];
     const real k3 = c.dist[4], k4 = c.dist[5], k5 = c.dist[6], k6 = c.dist[7];
     T px, py;
-    persp<RCP>(x, y, z, px, py);
+    persp<FAST>(x, y, z, px, py);
     const T x2 = px * px, y2 = py * py;
-    const T r2 = x2 + y2;
+    const T r2 = mad<FAST>(px, px, y2);
     const T r4 = r2 * r2;
     const T r6 = r2 * r4;
-    const T num = real(1) + k1 * r2 + k2 * r4 + k3 * r6;
-    const T den = real(1) + k4 * r2 + k5 * r4 + k6 * r6;
+    const T num = mad<FAST>(k3, r6, mad<FAST>(k2, r4, mad<FAST>(k1, r2, real(1))));
+    const T den = mad<FAST>(k6, r6, mad<FAST>(k5, r4, mad<FAST>(k4, r2, real(1))));
     const T rc = den > real(1e-8) ? num / den : num;
     const T t1 = real(2) * px * py;
-    const T t2 = r2 + real(2) * x2;
-    const T t3 = r2 + real(2) * y2;
-    const T dx = rc * px + p1 * t1 + p2 * t2;
-    const T dy = rc * py + p1 * t3 + p2 * t1;
-    u = c.intr[0] * dx + c.intr[2];
-    v = c.intr[1] * dy + c.intr[3];
+    const T t2 = mad<FAST>(real(2), x2, r2);
+    const T t3 = mad<FAST>(real(2), y2, r2);
+    const T dx = mad<FAST>(p2, t2, mad<FAST>(p1, t1, rc * px));
+    const T dy = mad<FAST>(p2, t1, mad<FAST>(p1, t3, rc * py));
+    u = mad<FAST>(c.intr[0], dx, c.intr[2]);
+    v = mad<FAST>(c.intr[1], dy, c.intr[3]);
   }
 }
 
@@ -261,7 +276,7 @@ __device__ __forceinline__ void project_jac(const CamParams<real>& c, real x, re
     const real iz = real(1) / z;
     const real px = x * iz, py = y * iz;
     const real x2 = px * px, y2 = py * py, xy = px * py;
-    const real r2 = x2 + y2;
+    const real r2 = fma(px, px, y2);
     const real r4 = r2 * r2;
     real rc, rcp, p1, p2;  // radial factor and d(rc)/d(r2)
     if (MODEL == MODEL_PLUMB_BOB) {
@@ -269,15 +284,15 @@ __device__ __forceinline__ void project_jac(const CamParams<real>& c, real x, re
       p1 = c.dist[2];
       p2 = c.dist[3];
       const real r6 = r2 * r4;
-      rc = real(1) + k1 * r2 + k2 * r4 + k3 * r6;
+      rc = fma(k3, r6, fma(k2, r4, fma(k1, r2, real(1))));
       rcp = fma(real(3) * k3, r4, fma(real(2) * k2, r2, k1));
     } else {
       const real k1 = c.dist[0], k2 = c.dist[1], k3 = c.dist[4], k4 = c.dist[5], k5 = c.dist[6], k6 = c.dist[7];
       p1 = c.dist[2];
       p2 = c.dist[3];
       const real r6 = r2 * r4;
-      const real num = real(1) + k1 * r2 + k2 * r4 + k3 * r6;
-      const real den = real(1) + k4 * r2 + k5 * r4 + k6 * r6;
+      const real num = fma(k3, r6, fma(k2, r4, fma(k1, r2, real(1))));
+      const real den = fma(k6, r6, fma(k5, r4, fma(k4, r2, real(1))));
       const real nump = fma(real(3) * k3, r4, fma(real(2) * k2, r2, k1));
       const real denp = fma(real(3) * k6, r4, fma(real(2) * k5, r2, k4));
       if (den > real(1e-8)) {
