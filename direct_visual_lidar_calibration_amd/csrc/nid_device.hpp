@@ -406,14 +406,25 @@ __device__ __forceinline__ u64 to_fixed(double wa, double wb, double magic) {
   return u64(__double_as_longlong(d)) & 0x000FFFFFFFFFFFFFull;
 }
 
-// 4 consecutive bytes at byte offset `off` of a 4-byte-aligned global array: two aligned dword
-// loads + v_alignbyte.  Offset arithmetic (not pointer-to-integer casts) keeps the pointer in the
-// global address space, so the loads are global_load (vmcnt only) instead of flat_load, which would
-// also count on lgkmcnt and serialise behind the LDS atomics.
-__device__ __forceinline__ uint32_t load_u8x4(const uint8_t* __restrict__ base, uint32_t off) {
-  const uint32_t* __restrict__ q = reinterpret_cast<const uint32_t*>(base + (off & ~3u));
-  const uint32_t lo = q[0], hi = q[1];
-  return __builtin_amdgcn_alignbyte(hi, lo, off & 3u);
+// The bin image is stored in STRIPS of four rows with the four vertically adjacent pixels of a
+// column contiguous: byte address of padded pixel (x, y) = (y >> 2) * 4 * pitch + 4 * x + (y & 3).
+// The 4x4 tap patch [kx..kx+3] x [ky..ky+3] is then two 16-byte loads (one per strip it touches)
+// instead of four row gathers -- half the L1 lookups, which co-limited both spline kernels -- and a
+// v_alignbyte per column puts rows ky..ky+3 of column kx+a into the four bytes of cols[a].
+struct __attribute__((aligned(4))) StripQuad {
+  uint32_t c[4];
+};
+__device__ __forceinline__ void load_patch(const uint8_t* __restrict__ img, int pitch, int kx, int ky, uint32_t* cols) {
+  const uint32_t stride = uint32_t(pitch) * 4u;
+  const uint32_t base = (uint32_t(ky) >> 2) * stride + uint32_t(kx) * 4u;
+  const StripQuad s0 = *reinterpret_cast<const StripQuad*>(img + base);
+  const StripQuad s1 = *reinterpret_cast<const StripQuad*>(img + base + stride);
+  const uint32_t sh = uint32_t(ky) & 3u;
+#pragma unroll
+  for (int a = 0; a < 4; a++) cols[a] = __builtin_amdgcn_alignbyte(s1.c[a], s0.c[a], sh);
+}
+__device__ __forceinline__ uint32_t load_pixel(const uint8_t* __restrict__ img, int pitch, int x, int y) {
+  return img[(uint32_t(y) >> 2) * uint32_t(pitch) * 4u + uint32_t(x) * 4u + (uint32_t(y) & 3u)];
 }
 
 }  // namespace nidreg

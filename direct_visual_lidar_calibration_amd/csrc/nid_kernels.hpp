@@ -188,17 +188,15 @@ __global__ __launch_bounds__(kThreads) void k_spline_hist(
 #pragma unroll
       for (int a = 0; a < 4; a++) bx[a] *= keep;
       u64* col = tile + ((((bins_[k] - col0) * uint32_t(B)) << cshift) + lane_copy);
-      // padded bin image: tap (a,b) of knot (kx,ky) lives at [ky + b][kx + a] (edge-replicated,
+      // padded bin image: tap (a,b) of knot (kx,ky) is padded pixel (kx + a, ky + b) (edge-replicated,
       // which is the reference's clamp of knots_x / knots_y, nid_cost.hpp:70-73)
-      const uint32_t off0 = uint32_t(ky) * uint32_t(pitch) + uint32_t(kx);
-      uint32_t rows[4];  // all four row gathers are issued before the first LDS atomic
-#pragma unroll
-      for (int b = 0; b < 4; b++) rows[b] = load_u8x4(img, off0 + uint32_t(b) * uint32_t(pitch));
+      uint32_t cols[4];  // the two strip loads are issued before the first LDS atomic
+      load_patch(img, pitch, kx, ky, cols);
 #pragma unroll
       for (int b = 0; b < 4; b++) {
 #pragma unroll
         for (int a = 0; a < 4; a++) {
-          const uint32_t r = (rows[b] >> (8 * a)) & 0xffu;
+          const uint32_t r = (cols[a] >> (8 * b)) & 0xffu;
           atomicAdd(&col[r << cshift], to_fixed(double(bx[a]), double(by[b]), magic));  // ds_add_u64
         }
       }
@@ -285,7 +283,7 @@ __global__ __launch_bounds__(kThreads) void k_nearest_hist(
     if (in) {
       inl++;
       const int px = int(u), py = int(v);  // truncation toward zero
-      const uint32_t r = img[size_t(py + 1) * size_t(pitch) + size_t(px + 1)];
+      const uint32_t r = load_pixel(img, pitch, px + 1, py + 1);
       atomicAdd(&tile[((((bin - col0) * uint32_t(B)) + r) << cshift) + (uint32_t(tid) & cmask)], u64(1));
     }
     }
@@ -492,17 +490,15 @@ __global__ __launch_bounds__(kThreads) void k_spline_grad(
         bspline_deriv<real>(uu - fu, dbx);
         bspline_deriv<real>(vv - fv, dby);
         const double* gcol = gtile + ((((bins_[k] - col0) * uint32_t(B)) << cshift) + lane_copy);
-        const uint32_t off0 = uint32_t(ky) * uint32_t(pitch) + uint32_t(kx);
-        uint32_t rows[4];
-#pragma unroll
-        for (int b = 0; b < 4; b++) rows[b] = load_u8x4(img, off0 + uint32_t(b) * uint32_t(pitch));
+        uint32_t cols[4];
+        load_patch(img, pitch, kx, ky, cols);
         real gx = real(0), gy = real(0);
 #pragma unroll
         for (int b = 0; b < 4; b++) {
           real sa = real(0), sb = real(0);
 #pragma unroll
           for (int a = 0; a < 4; a++) {
-            const real g = real(gcol[((rows[b] >> (8 * a)) & 0xffu) << cshift]);
+            const real g = real(gcol[((cols[a] >> (8 * b)) & 0xffu) << cshift]);
             sa = fma(g, dbx[a], sa);
             sb = fma(g, bx[a], sb);
           }

@@ -401,27 +401,28 @@ int nidreg_create(const nidreg_desc* d, nidreg_handle** out) {
   // bin_image = min(int(pix * bins), bins - 1) (nid_cost.hpp:78-79) for CV_64FC1 input;
   // max(0, min(bins-1, int(u8 / 255.0 * bins))) (cost_calculator_nid.cpp:43-46) for CV_8UC1 input.
   const int W = h->W, H = h->H;
-  h->pitch = ((W + 8) + 3) & ~3;
+  h->pitch = ((W + 8) + 3) & ~3;  // padded width in pixels
   const int PH = H + 3;
-  std::vector<uint8_t> img(size_t(h->pitch) * PH + 16, 0);
+  const int nstrips = (PH + 3) / 4 + 1;  // rows are stored in strips of four (nid_device.hpp load_patch)
+  std::vector<uint8_t> img(size_t(h->pitch) * 4 * nstrips + 64, 0);
   {
     uint8_t lut[256];
     for (int k = 0; k < 256; k++) lut[k] = uint8_t(std::max(0, std::min(B - 1, cast_int(k / 255.0 * B))));
     const uint8_t* base = static_cast<const uint8_t*>(d->image);
-    for (int py = 0; py < PH; py++) {
+    for (int py = 0; py < nstrips * 4; py++) {
       const int sy = std::min(std::max(py - 1, 0), H - 1);
-      uint8_t* dst = img.data() + size_t(py) * h->pitch;
+      uint8_t* dst = img.data() + size_t(py >> 2) * size_t(h->pitch) * 4 + size_t(py & 3);
       if (d->image_dtype == NIDREG_IMAGE_F64) {
         const double* row = reinterpret_cast<const double*>(base + size_t(sy) * d->image_row_stride);
         for (int px = 0; px < h->pitch; px++) {
           const int sx = std::min(std::max(px - 1, 0), W - 1);
-          dst[px] = uint8_t(std::max(0, std::min(cast_int(row[sx] * B), B - 1)));
+          dst[size_t(px) * 4] = uint8_t(std::max(0, std::min(cast_int(row[sx] * B), B - 1)));
         }
       } else {
         const uint8_t* row = base + size_t(sy) * d->image_row_stride;
         for (int px = 0; px < h->pitch; px++) {
           const int sx = std::min(std::max(px - 1, 0), W - 1);
-          dst[px] = lut[row[sx]];
+          dst[size_t(px) * 4] = lut[row[sx]];
         }
       }
     }
