@@ -19,6 +19,7 @@ MODE_SPLINE, MODE_NEAREST = 0, 1
 PREC_FP64, PREC_FP32 = 0, 1
 IMAGE_F64, IMAGE_U8 = 0, 1
 FLAG_INPUT_ORDER = 1
+FLAG_EXT_STREAM = 2
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int64_p = ctypes.POINTER(ctypes.c_int64)

@@ -572,7 +572,7 @@ int nidreg_create(const nidreg_desc* d, nidreg_handle** out) {
 
   // ---- per-evaluation scratch
   h->hist_words = nidreg_hist_words(B);
-  if (d->ext_stream) {
+  if (d->ext_stream || (d->flags & NIDREG_FLAG_EXT_STREAM)) {
     h->stream = static_cast<hipStream_t>(d->ext_stream);
   } else {
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -711,17 +711,17 @@ int nidreg_project(nidreg_handle* h, const double* p3, int64_t n, double* uv, do
   if (n == 0) return NIDREG_OK;
   HIP_TRY(hipSetDevice(h->device));
   double *d_p = nullptr, *d_uv = nullptr, *d_j = nullptr;
-  HIP_TRY(hipMalloc(&d_p, size_t(n) * 3 * sizeof(double)));
-  HIP_TRY(hipMalloc(&d_uv, size_t(n) * 2 * sizeof(double)));
-  if (jac) HIP_TRY(hipMalloc(&d_j, size_t(n) * 6 * sizeof(double)));
-  HIP_TRY(hipMemcpy(d_p, p3, size_t(n) * 3 * sizeof(double), hipMemcpyHostToDevice));
-  hipError_t e = h->precision == NIDREG_PREC_FP32 ? launch_project<float>(h->model, h->intr, h->dist, d_p, n, d_uv, d_j, h->stream)
-                                                  : launch_project<double>(h->model, h->intr, h->dist, d_p, n, d_uv, d_j, h->stream);
+  hipError_t e = hipMalloc(&d_p, size_t(n) * 3 * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&d_uv, size_t(n) * 2 * sizeof(double));
+  if (e == hipSuccess && jac) e = hipMalloc(&d_j, size_t(n) * 6 * sizeof(double));
+  if (e == hipSuccess) e = hipMemcpy(d_p, p3, size_t(n) * 3 * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess)
+    e = h->precision == NIDREG_PREC_FP32 ? launch_project<float>(h->model, h->intr, h->dist, d_p, n, d_uv, d_j, h->stream) : launch_project<double>(h->model, h->intr, h->dist, d_p, n, d_uv, d_j, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   if (e == hipSuccess) e = hipMemcpy(uv, d_uv, size_t(n) * 2 * sizeof(double), hipMemcpyDeviceToHost);
   if (e == hipSuccess && jac) e = hipMemcpy(jac, d_j, size_t(n) * 6 * sizeof(double), hipMemcpyDeviceToHost);
-  (void)hipFree(d_p);
-  (void)hipFree(d_uv);
+  if (d_p) (void)hipFree(d_p);
+  if (d_uv) (void)hipFree(d_uv);
   if (d_j) (void)hipFree(d_j);
   if (e != hipSuccess) return fail(NIDREG_ERR_HIP, std::string("nidreg_project: ") + hipGetErrorString(e));
   return NIDREG_OK;

@@ -61,9 +61,10 @@ class _GpuShardBackend:
         self._out = torch.zeros(_lib.NIDREG_OUT_DOUBLES, dtype=torch.float64, device=dev)
         self.hist_tensor = self._hist
         self.grad_tensor = self._out[1:8]
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        self.cost = nid.NIDCost(proj, normalized_image, points, intensities, bins, device=device, precision=precision, scale_points=int(total_points),
-                                ext_stream=stream, ext_hist=self._hist.data_ptr(), ext_out=self._out.data_ptr(), **tuning)
+        stream = torch.cuda.current_stream(dev).cuda_stream  # 0 = the default stream: still "external"
+        flags = int(tuning.pop("flags", 0)) | _lib.FLAG_EXT_STREAM
+        self.cost = nid.NIDCost(proj, normalized_image, points, intensities, bins, device=device, precision=precision, scale_points=int(total_points), flags=flags,
+                                ext_stream=stream or None, ext_hist=self._hist.data_ptr(), ext_out=self._out.data_ptr(), **tuning)
 
     def shard_hist(self, x):
         self.cost.shard_hist(x)

@@ -74,6 +74,8 @@ extern "C" {
 #define NIDREG_MAX_BINS 256
 
 /* nidreg_desc.flags */
+#define NIDREG_FLAG_EXT_STREAM 2  /* launch on desc.ext_stream even when it is NULL (= the legacy default
+                                     stream, e.g. torch's current stream); otherwise NULL means "own stream" */
 #define NIDREG_FLAG_INPUT_ORDER 1 /* keep the caller's point order inside each column group instead of the
                                      default Morton order of the LiDAR-frame bearing (results are
                                      bit-identical either way; the default gathers ~2x faster) */
