@@ -59,7 +59,7 @@ class NidregDesc(ctypes.Structure):
 
 
 EXPORTS = [
-    "nidreg_model_from_name", "nidreg_device_count", "nidreg_create", "nidreg_destroy", "nidreg_eval", "nidreg_eval_iso", "nidreg_eval_multi",
+    "nidreg_model_from_name", "nidreg_device_count", "nidreg_create", "nidreg_destroy", "nidreg_cloud_create", "nidreg_cloud_destroy", "nidreg_create_from_cloud", "nidreg_eval", "nidreg_eval_iso", "nidreg_eval_multi",
     "nidreg_eval_iso_multi", "nidreg_get_hist", "nidreg_get_hist_fixed", "nidreg_project", "nidreg_project_model", "nidreg_view_culling", "nidreg_hist_words", "nidreg_shard_hist",
     "nidreg_shard_entropy", "nidreg_shard_grad", "nidreg_shard_finish", "nidreg_set_timing", "nidreg_get_timing", "nidreg_get_info", "nidreg_last_error",
     "nidreg_version",
@@ -83,6 +83,10 @@ def load():
     lib.nidreg_destroy.restype = None
     lib.nidreg_destroy.argtypes = [ctypes.c_void_p]
     lib.nidreg_create.argtypes = [ctypes.POINTER(NidregDesc), ctypes.POINTER(ctypes.c_void_p)]
+    lib.nidreg_cloud_create.argtypes = [ctypes.c_int, c_double_p, ctypes.c_int64, c_double_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p)]
+    lib.nidreg_cloud_destroy.restype = None
+    lib.nidreg_cloud_destroy.argtypes = [ctypes.c_void_p]
+    lib.nidreg_create_from_cloud.argtypes = [ctypes.POINTER(NidregDesc), ctypes.c_void_p, c_double_p, ctypes.c_double, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
     lib.nidreg_eval.argtypes = [ctypes.c_void_p, c_double_p, c_double_p, c_double_p]
     lib.nidreg_eval_iso.argtypes = [ctypes.c_void_p, c_double_p, c_double_p]
     lib.nidreg_eval_multi.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, c_double_p, c_double_p, c_double_p, c_double_p]

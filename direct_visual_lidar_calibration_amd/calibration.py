@@ -154,7 +154,8 @@ class VisualCameraCalibration:
     ``cull(points, intensities, T4x4) -> index array`` is the per-outer-iteration view culling
     (view_culling.cpp:21-32); ``None`` disables culling (the CLI's --disable_culling)."""
 
-    def __init__(self, dataset, params=None, nid_cost_factory=None, nearest_cost_factory=None, cull=None, multi_factory=None, trust_gate=None, callback=None):
+    def __init__(self, dataset, params=None, nid_cost_factory=None, nearest_cost_factory=None, cull=None, multi_factory=None, trust_gate=None, callback=None,
+                 fused_nid_factory=None, fused_nearest_factory=None):
         self.params = params or VisualCameraCalibrationParams()
         self.dataset = dataset
         self.nid_cost_factory = nid_cost_factory
@@ -163,6 +164,10 @@ class VisualCameraCalibration:
         self.multi_factory = multi_factory
         self.trust_gate = trust_gate
         self.callback = callback
+        # optional device-resident route: fused_*_factory(pair_index, T4x4, bins) builds the culled cost
+        # object straight from a GPU-resident cloud (nid.NIDCost.from_cloud), replacing cull + factory
+        self.fused_nid_factory = fused_nid_factory
+        self.fused_nearest_factory = fused_nearest_factory
         self.log = []
 
     # visual_camera_calibration.cpp:35-68
@@ -195,9 +200,13 @@ class VisualCameraCalibration:
     # visual_camera_calibration.cpp:190-238
     def estimate_pose_bfgs(self, init_x):
         costs = []
-        for image, points, intensities in self._culled(init_x):
-            img64 = image.astype(np.float64) * (1.0 / 255.0)  # convertTo(CV_64FC1, 1/255) (:204)
-            costs.append(self.nid_cost_factory(img64, points, intensities, self.params.nid_bins))
+        if self.fused_nid_factory is not None:
+            T = se3.to_matrix(init_x)
+            costs = [self.fused_nid_factory(k, T, self.params.nid_bins) for k in range(len(self.dataset))]
+        else:
+            for image, points, intensities in self._culled(init_x):
+                img64 = image.astype(np.float64) * (1.0 / 255.0)  # convertTo(CV_64FC1, 1/255) (:204)
+                costs.append(self.nid_cost_factory(img64, points, intensities, self.params.nid_bins))
         if self.multi_factory is not None:
             multi = self.multi_factory(init_x, costs)
         else:
@@ -211,8 +220,12 @@ class VisualCameraCalibration:
     # visual_camera_calibration.cpp:70-139
     def estimate_pose_nelder_mead(self, init_x):
         calcs = []
-        for image, points, intensities in self._culled(init_x):
-            calcs.append(self.nearest_cost_factory(image, points, intensities, self.params.nid_bins))
+        if self.fused_nearest_factory is not None:
+            T = se3.to_matrix(init_x)
+            calcs = [self.fused_nearest_factory(k, T, self.params.nid_bins) for k in range(len(self.dataset))]
+        else:
+            for image, points, intensities in self._culled(init_x):
+                calcs.append(self.nearest_cost_factory(image, points, intensities, self.params.nid_bins))
         T0 = se3.to_matrix(init_x)
         best = [math.inf]
 

@@ -1,0 +1,175 @@
+// nid_build.hip -- device-side construction of a handle's point records from a device-resident cloud:
+//   [view culling (nid_cull_kernels.hpp)] -> histogram column + Morton key per surviving point ->
+//   rocPRIM radix sort by (column group, Morton code) -> gather into Rec32 / Rec64.
+// This is the host bucketing of nidreg_create (nidreg.hip) moved onto the GPU, so that the reference's
+// per-outer-iteration sequence  ViewCulling::cull -> new NIDCost  (visual_camera_calibration.cpp:201-206)
+// never round-trips the cloud through the host.  The record ORDER may differ from the host path (device
+// vs host atan2 rounding in the Morton key); the histogram does not (fixed point, order independent).
+// Built with -ffp-contract=off (the culling arithmetic must match the CPU bit for bit).
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include <vector>
+
+#include "nid_device.hpp"
+#include "nid_launch.hpp"
+
+namespace nidreg {
+
+namespace {
+
+__device__ __forceinline__ int cast_int_dev(double d) {  // x86 cvttsd2si semantics: NaN / overflow -> INT_MIN
+  if (!(d > -2147483649.0 && d < 2147483648.0)) return int(0x80000000u);
+  return int(d);
+}
+
+__global__ __launch_bounds__(256) void k_build_keys(
+  const double* __restrict__ pts, const double* __restrict__ intensities, const unsigned char* __restrict__ keep, long long n, int B, int GW, unsigned long long* __restrict__ keys,
+  unsigned int* __restrict__ idx, int* __restrict__ not_lossless) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  idx[i] = (unsigned int)i;
+  if (keep && !keep[i]) {
+    keys[i] = ~0ull;
+    return;
+  }
+  const double x = pts[4 * i], y = pts[4 * i + 1], z = pts[4 * i + 2];
+  if ((double(float(x)) != x && x == x) || (double(float(y)) != y && y == y) || (double(float(z)) != z && z == z)) *not_lossless = 1;
+  const int b = max(0, min(B - 1, cast_int_dev(intensities[i] * double(B))));
+  const double az = atan2(y, x);
+  const double el = atan2(z, sqrt(x * x + y * y));
+  unsigned int qa = (unsigned int)fmin(65535.0, fmax(0.0, (az + 3.14159265358979323846) * (65535.0 / (2.0 * 3.14159265358979323846))));
+  unsigned int qe = (unsigned int)fmin(65535.0, fmax(0.0, (el + 0.5 * 3.14159265358979323846) * (65535.0 / 3.14159265358979323846)));
+  if (!(az == az) || !(el == el)) qa = qe = 0;
+  unsigned int m = 0;
+#pragma unroll
+  for (int bb = 0; bb < 16; bb++) m |= (((qa >> bb) & 1u) << (2 * bb)) | (((qe >> bb) & 1u) << (2 * bb + 1));
+  // low 9 bits of the upper word carry the exact column (B <= 256) so the gather need not recompute it
+  keys[i] = ((unsigned long long)(unsigned int)(b / GW) << 41) | ((unsigned long long)(unsigned int)b << 32) | m;
+}
+
+// first[g] = first sorted position whose column group is g (g == NG: the removed points)
+__global__ __launch_bounds__(256) void k_build_bounds(const unsigned long long* __restrict__ keys, long long n, int NG, int* __restrict__ first) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long k = keys[i];
+  const int g = k == ~0ull ? NG : int(k >> 41);
+  if (i == 0) {
+    first[g] = 0;
+  } else {
+    const unsigned long long kp = keys[i - 1];
+    const int gp = kp == ~0ull ? NG : int(kp >> 41);
+    if (gp != g) first[g] = int(i);
+  }
+}
+
+template <typename Rec>
+__global__ __launch_bounds__(256) void k_build_gather(const double* __restrict__ pts, const unsigned long long* __restrict__ keys, const unsigned int* __restrict__ idx, long long kept, Rec* __restrict__ recs) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= kept) return;
+  const unsigned int s = idx[i];
+  Rec r;
+  r.x = decltype(r.x)(pts[4 * (long long)s]);
+  r.y = decltype(r.y)(pts[4 * (long long)s + 1]);
+  r.z = decltype(r.z)(pts[4 * (long long)s + 2]);
+  r.bin = decltype(r.bin)((keys[i] >> 32) & 0x1ffu);
+  recs[i] = r;
+}
+
+}  // namespace
+
+#define BUILD_TRY(expr)           \
+  do {                            \
+    e = (expr);                   \
+    if (e != hipSuccess) goto done; \
+  } while (0)
+
+hipError_t build_records_device(
+  const double* d_pts, const double* d_intensities, long long n, const CullArgs* cull, int B, int GW, int NG, bool force_rec32, void** d_recs_out, int* rec64_out,
+  std::vector<int64_t>& gcount, hipStream_t stream) {
+  hipError_t e = hipSuccess;
+  unsigned char* d_keep = nullptr;
+  int* d_pix = nullptr;
+  unsigned int* d_zbuf = nullptr;
+  unsigned long long *d_keys = nullptr, *d_keys2 = nullptr;
+  unsigned int *d_idx = nullptr, *d_idx2 = nullptr;
+  int* d_first = nullptr;  // NG + 1 firsts, then the not-lossless flag
+  void* d_tmp = nullptr;
+  size_t tmp_bytes = 0;
+  void* d_recs = nullptr;
+  std::vector<int> first(size_t(NG) + 2, -1);
+  const unsigned grid = unsigned((n + 255) / 256);
+  long long kept = 0;
+  int rec64 = 0;
+  gcount.assign(size_t(NG) + 1, 0);
+  *d_recs_out = nullptr;
+  *rec64_out = 0;
+
+  if (n > 0) {
+    if (cull) {
+      BUILD_TRY(hipMalloc(&d_keep, size_t(n)));
+      BUILD_TRY(hipMalloc(&d_pix, size_t(n) * sizeof(int)));
+      BUILD_TRY(hipMalloc(&d_zbuf, size_t(cull->W) * cull->H * sizeof(unsigned int)));
+      BUILD_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_zbuf), 0x7f800000, size_t(cull->W) * cull->H, stream));
+      BUILD_TRY(launch_cull(cull->model, cull->intr, cull->dist, d_pts, 4, n, cull->T, cull->W, cull->H, cull->min_z, cull->depth, d_pix, d_zbuf, d_keep, stream));
+    }
+    BUILD_TRY(hipMalloc(&d_keys, size_t(n) * 8));
+    BUILD_TRY(hipMalloc(&d_keys2, size_t(n) * 8));
+    BUILD_TRY(hipMalloc(&d_idx, size_t(n) * 4));
+    BUILD_TRY(hipMalloc(&d_idx2, size_t(n) * 4));
+    BUILD_TRY(hipMalloc(&d_first, (size_t(NG) + 2) * sizeof(int)));
+    BUILD_TRY(hipMemsetAsync(d_first, 0xff, (size_t(NG) + 1) * sizeof(int), stream));
+    BUILD_TRY(hipMemsetAsync(d_first + NG + 1, 0, sizeof(int), stream));
+    hipLaunchKernelGGL(k_build_keys, dim3(grid), dim3(256), 0, stream, d_pts, d_intensities, d_keep, n, B, GW, d_keys, d_idx, d_first + NG + 1);
+    BUILD_TRY(hipGetLastError());
+    BUILD_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_keys, d_keys2, d_idx, d_idx2, size_t(n), 0, 64, stream));
+    BUILD_TRY(hipMalloc(&d_tmp, tmp_bytes));
+    BUILD_TRY(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_keys, d_keys2, d_idx, d_idx2, size_t(n), 0, 64, stream));
+    hipLaunchKernelGGL(k_build_bounds, dim3(grid), dim3(256), 0, stream, d_keys2, n, NG, d_first);
+    BUILD_TRY(hipGetLastError());
+    BUILD_TRY(hipMemcpyAsync(first.data(), d_first, (size_t(NG) + 2) * sizeof(int), hipMemcpyDeviceToHost, stream));
+    BUILD_TRY(hipStreamSynchronize(stream));
+    kept = first[size_t(NG)] >= 0 ? first[size_t(NG)] : n;
+    {
+      long long next = kept;
+      for (int g = NG - 1; g >= 0; g--) {
+        if (first[size_t(g)] < 0) first[size_t(g)] = int(next);
+        next = first[size_t(g)];
+      }
+      for (int g = 0; g < NG; g++) gcount[size_t(g)] = first[size_t(g)];
+      gcount[size_t(NG)] = kept;
+    }
+    rec64 = (!force_rec32 && first[size_t(NG) + 1] != 0) ? 1 : 0;
+  }
+  {
+    const size_t rec_bytes = rec64 ? sizeof(Rec64) : sizeof(Rec32);
+    BUILD_TRY(hipMalloc(&d_recs, size_t(kept > 0 ? kept : 1) * rec_bytes + 64));
+    if (kept > 0) {
+      const unsigned g2 = unsigned((kept + 255) / 256);
+      if (rec64)
+        hipLaunchKernelGGL(k_build_gather<Rec64>, dim3(g2), dim3(256), 0, stream, d_pts, d_keys2, d_idx2, kept, static_cast<Rec64*>(d_recs));
+      else
+        hipLaunchKernelGGL(k_build_gather<Rec32>, dim3(g2), dim3(256), 0, stream, d_pts, d_keys2, d_idx2, kept, static_cast<Rec32*>(d_recs));
+      BUILD_TRY(hipGetLastError());
+      BUILD_TRY(hipStreamSynchronize(stream));
+    }
+  }
+  *d_recs_out = d_recs;
+  d_recs = nullptr;
+  *rec64_out = rec64;
+done:
+  if (d_keep) (void)hipFree(d_keep);
+  if (d_pix) (void)hipFree(d_pix);
+  if (d_zbuf) (void)hipFree(d_zbuf);
+  if (d_keys) (void)hipFree(d_keys);
+  if (d_keys2) (void)hipFree(d_keys2);
+  if (d_idx) (void)hipFree(d_idx);
+  if (d_idx2) (void)hipFree(d_idx2);
+  if (d_first) (void)hipFree(d_first);
+  if (d_tmp) (void)hipFree(d_tmp);
+  if (d_recs) (void)hipFree(d_recs);
+  return e;
+}
+
+}  // namespace nidreg

@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 namespace nidreg {
 
 struct Chunk;
@@ -45,5 +47,21 @@ template <typename real> hipError_t launch_project(int model, const double* intr
 // ViewCulling::cull (nid_cull_kernels.hpp); all pointers are device memory
 hipError_t launch_cull(int model, const double* intr, const double* dist, const double* d_pts, long long stride_d, long long n, const double* T, int W, int H, double min_z,
                        int depth, int* d_pix, unsigned int* d_zbuf, unsigned char* d_keep, hipStream_t stream);
+
+// view-culling parameters for the device-side record build (all host values; T = rows of the 4x4)
+struct CullArgs {
+  int model;
+  double intr[5], dist[8];
+  double T[16];
+  int W, H;
+  double min_z;
+  int depth;
+};
+
+// [cull ->] bucket -> Morton sort -> gather on the device (nid_build.hip).  d_pts: n x 4 doubles (x y z 1),
+// cull nullable.  Returns the record buffer (caller owns), its type, and the column-group offsets.
+hipError_t build_records_device(
+  const double* d_pts, const double* d_intensities, long long n, const CullArgs* cull, int B, int GW, int NG, bool force_rec32, void** d_recs_out, int* rec64_out,
+  std::vector<int64_t>& gcount, hipStream_t stream);
 
 }  // namespace nidreg

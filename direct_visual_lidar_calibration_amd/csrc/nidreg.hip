@@ -333,15 +333,29 @@ int64_t nidreg_hist_words(int bins) {
   return int64_t(bins) * bins + kTailWords + ((bins + 7) & ~7);  // joint histogram, tail, column sums
 }
 
-int nidreg_create(const nidreg_desc* d, nidreg_handle** out) {
+}  // extern "C"
+
+// device-resident cloud: uploaded once per pair, re-culled / re-bucketed on the GPU for every handle
+struct nidreg_cloud {
+  int device = 0;
+  int64_t n = 0;
+  double* d_pts = nullptr;  // n x 4 doubles (x y z 1)
+  double* d_int = nullptr;  // n doubles
+};
+
+namespace {
+
+int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T_cull, double min_z, int enable_depth, nidreg_handle** out) {
   if (!d || !out) return fail(NIDREG_ERR_INVALID, "nidreg_create: null argument");
   *out = nullptr;
   if (d->struct_size != int32_t(sizeof(nidreg_desc))) return fail(NIDREG_ERR_INVALID, "nidreg_create: struct_size mismatch");
   if (d->model_id < 0 || d->model_id > 5) return fail(NIDREG_ERR_INVALID, "nidreg_create: unknown camera model");
   if (d->bins < 2 || d->bins > NIDREG_MAX_BINS) return fail(NIDREG_ERR_INVALID, "nidreg_create: bins must be in [2, 256]");
   if (d->width < 1 || d->height < 1 || !d->image) return fail(NIDREG_ERR_INVALID, "nidreg_create: bad image");
-  if (d->num_points < 0 || d->num_points > int64_t(INT_MAX)) return fail(NIDREG_ERR_INVALID, "nidreg_create: bad num_points");
-  if (d->num_points > 0 && (!d->points || !d->intensities)) return fail(NIDREG_ERR_INVALID, "nidreg_create: null points");
+  const int64_t n_in = cloud ? cloud->n : d->num_points;
+  if (n_in < 0 || n_in > int64_t(INT_MAX)) return fail(NIDREG_ERR_INVALID, "nidreg_create: bad num_points");
+  if (!cloud && n_in > 0 && (!d->points || !d->intensities)) return fail(NIDREG_ERR_INVALID, "nidreg_create: null points");
+  if (cloud && cloud->device != d->device_id) return fail(NIDREG_ERR_INVALID, "nidreg_create_from_cloud: cloud lives on another device");
   if (d->mode != NIDREG_MODE_SPLINE && d->mode != NIDREG_MODE_NEAREST) return fail(NIDREG_ERR_INVALID, "nidreg_create: bad mode");
   if (d->precision != NIDREG_PREC_FP64 && d->precision != NIDREG_PREC_FP32) return fail(NIDREG_ERR_INVALID, "nidreg_create: bad precision");
 
@@ -358,12 +372,12 @@ int nidreg_create(const nidreg_desc* d, nidreg_handle** out) {
   h->bins = d->bins;
   h->W = d->width;
   h->H = d->height;
-  h->num_points = d->num_points;
+  h->num_points = n_in;
   h->max_fov = d->max_fov;
   std::memcpy(h->intr, d->intrinsics, sizeof(h->intr));
   std::memcpy(h->dist, d->distortion, sizeof(h->dist));
   const int B = h->bins;
-  const int64_t N = h->num_points;
+  int64_t N = h->num_points;  // becomes the number of records (after culling on the cloud path)
 
 #define CREATE_TRY(expr)                                                                     \
   do {                                                                                       \
@@ -434,119 +448,142 @@ int nidreg_create(const nidreg_desc* d, nidreg_handle** out) {
   // cost_calculator_nid.cpp:47) is pose independent -> bucket by column group (stable), so a
   // workgroup owns GW histogram columns.  Records are float32 when that is lossless or when the
   // caller asked for FP32 geometry; otherwise double.
-  const char* pbase = reinterpret_cast<const char*>(d->points);
-  const int64_t pstride = d->point_stride > 0 ? d->point_stride : 32;
-  const bool spatial = !(d->flags & NIDREG_FLAG_INPUT_ORDER);
-  const int nthreads = int(std::max(1u, std::min(32u, std::thread::hardware_concurrency())));
-  auto parallel_for = [&](int64_t n, const std::function<void(int64_t, int64_t, int)>& fn) {
-    const int T = int(std::min<int64_t>(nthreads, std::max<int64_t>(1, n / 65536)));
-    if (T <= 1) {
-      fn(0, n, 0);
-      return;
+  std::vector<int64_t> gcount;
+  if (cloud) {
+    // device path: [ViewCulling::cull ->] bucket -> Morton sort -> gather, all on the GPU (nid_build.hip)
+    CullArgs ca;
+    if (T_cull) {
+      ca.model = d->model_id;
+      std::memcpy(ca.intr, d->intrinsics, sizeof(ca.intr));
+      std::memcpy(ca.dist, d->distortion, sizeof(ca.dist));
+      std::memcpy(ca.T, T_cull, sizeof(ca.T));
+      ca.W = d->width;
+      ca.H = d->height;
+      ca.min_z = min_z;
+      ca.depth = enable_depth ? 1 : 0;
     }
-    std::vector<std::thread> th;
-    for (int t = 0; t < T; t++) th.emplace_back([&, t]() { fn(n * t / T, n * (t + 1) / T, t); });
-    for (auto& x : th) x.join();
-  };
-
-  // pass 1 (parallel): histogram column, float-representability, Morton code of the bearing
-  std::vector<uint32_t> bin(N), mort(spatial ? N : 0);
-  std::vector<int> lossless_t(nthreads, 1);
-  std::vector<std::vector<int64_t>> gcount_t(nthreads, std::vector<int64_t>(h->NG, 0));
-  parallel_for(N, [&](int64_t lo, int64_t hi, int t) {
-    bool ll = true;
-    std::vector<int64_t>& gc = gcount_t[t];
-    for (int64_t i = lo; i < hi; i++) {
-      const double* p = reinterpret_cast<const double*>(pbase + i * pstride);
-      if (ll) {
-        for (int k = 0; k < 3; k++)
-          if (double(float(p[k])) != p[k] && p[k] == p[k]) ll = false;
-      }
-      const int b = std::max(0, std::min(B - 1, cast_int(d->intensities[i] * B)));
-      bin[i] = uint32_t(b);
-      gc[b / GW]++;
-      if (spatial) {
-        // bearing cell: the sums are order independent (fixed point), so any order gives the same
-        // bits; a spatially coherent one makes the 64 lanes of a wave gather from neighbouring image
-        // lines for ANY pose (camera and LiDAR are rigidly mounted: a compact patch of bearings stays a
-        // compact patch of pixels)
-        const double az = std::atan2(p[1], p[0]);
-        const double el = std::atan2(p[2], std::sqrt(p[0] * p[0] + p[1] * p[1]));
-        uint32_t qa = uint32_t(std::min(65535.0, std::max(0.0, (az + M_PI) * (65535.0 / (2.0 * M_PI)))));
-        uint32_t qe = uint32_t(std::min(65535.0, std::max(0.0, (el + 0.5 * M_PI) * (65535.0 / M_PI))));
-        if (!(az == az) || !(el == el)) qa = qe = 0;
-        uint32_t m = 0;
-        for (int bb = 0; bb < 16; bb++) m |= (((qa >> bb) & 1u) << (2 * bb)) | (((qe >> bb) & 1u) << (2 * bb + 1));
-        mort[i] = m;
-      }
-    }
-    lossless_t[t] = ll ? 1 : 0;
-  });
-  bool lossless = true;
-  for (int t = 0; t < nthreads; t++) lossless = lossless && lossless_t[t];
-  std::vector<int64_t> gcount(h->NG + 1, 0);
-  for (int g = 0; g < h->NG; g++) {
-    int64_t c = 0;
-    for (int t = 0; t < nthreads; t++) c += gcount_t[t][g];
-    gcount[g + 1] = gcount[g] + c;
-  }
-  h->rec64 = (d->precision == NIDREG_PREC_FP64 && !lossless) ? 1 : 0;
-  const size_t rec_bytes = h->rec64 ? sizeof(Rec64) : sizeof(Rec32);
-  {
-    // order[k] = source index of the k-th device record: stable bucketing by column group, then (default)
-    // each group sorted by Morton code; NIDREG_FLAG_INPUT_ORDER keeps the caller's order inside groups.
-    std::vector<uint32_t> order(N);
-    {
-      std::vector<int64_t> cursor(gcount.begin(), gcount.end() - 1);
-      for (int64_t i = 0; i < N; i++) order[cursor[bin[i] / GW]++] = uint32_t(i);
-    }
-    if (spatial) {
-      std::atomic<int> next_group(0);
-      auto worker = [&]() {
-        std::vector<std::pair<uint32_t, uint32_t>> tmp;
-        for (;;) {
-          const int g = next_group.fetch_add(1);
-          if (g >= h->NG) break;
-          const int64_t lo = gcount[g], hi = gcount[g + 1];
-          tmp.resize(size_t(hi - lo));
-          for (int64_t k = lo; k < hi; k++) tmp[size_t(k - lo)] = std::make_pair(mort[order[k]], order[k]);
-          std::sort(tmp.begin(), tmp.end());
-          for (int64_t k = lo; k < hi; k++) order[k] = tmp[size_t(k - lo)].second;
-        }
-      };
-      const int T = N > 200000 ? std::min(nthreads, h->NG) : 1;
+    void* recs = nullptr;
+    int rec64 = 0;
+    CREATE_TRY(build_records_device(cloud->d_pts, cloud->d_int, cloud->n, T_cull ? &ca : nullptr, B, GW, h->NG, d->precision == NIDREG_PREC_FP32, &recs, &rec64, gcount, nullptr));
+    h->d_pts = recs;
+    h->rec64 = rec64;
+    N = gcount[size_t(h->NG)];
+    h->num_points = N;
+  } else {
+    const char* pbase = reinterpret_cast<const char*>(d->points);
+    const int64_t pstride = d->point_stride > 0 ? d->point_stride : 32;
+    const bool spatial = !(d->flags & NIDREG_FLAG_INPUT_ORDER);
+    const int nthreads = int(std::max(1u, std::min(32u, std::thread::hardware_concurrency())));
+    auto parallel_for = [&](int64_t n, const std::function<void(int64_t, int64_t, int)>& fn) {
+      const int T = int(std::min<int64_t>(nthreads, std::max<int64_t>(1, n / 65536)));
       if (T <= 1) {
-        worker();
-      } else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < T; t++) th.emplace_back(worker);
-        for (auto& x : th) x.join();
+        fn(0, n, 0);
+        return;
       }
-    }
-    std::vector<unsigned char> recs(size_t(std::max<int64_t>(N, 1)) * rec_bytes);
-    parallel_for(N, [&](int64_t lo, int64_t hi, int) {
-      for (int64_t dst = lo; dst < hi; dst++) {
-        const int64_t i = order[dst];
+      std::vector<std::thread> th;
+      for (int t = 0; t < T; t++) th.emplace_back([&, t]() { fn(n * t / T, n * (t + 1) / T, t); });
+      for (auto& x : th) x.join();
+    };
+
+    // pass 1 (parallel): histogram column, float-representability, Morton code of the bearing
+    std::vector<uint32_t> bin(N), mort(spatial ? N : 0);
+    std::vector<int> lossless_t(nthreads, 1);
+    std::vector<std::vector<int64_t>> gcount_t(nthreads, std::vector<int64_t>(h->NG, 0));
+    parallel_for(N, [&](int64_t lo, int64_t hi, int t) {
+      bool ll = true;
+      std::vector<int64_t>& gc = gcount_t[t];
+      for (int64_t i = lo; i < hi; i++) {
         const double* p = reinterpret_cast<const double*>(pbase + i * pstride);
-        if (h->rec64) {
-          Rec64 r;
-          r.x = p[0];
-          r.y = p[1];
-          r.z = p[2];
-          r.bin = bin[i];
-          std::memcpy(recs.data() + size_t(dst) * rec_bytes, &r, rec_bytes);
-        } else {
-          Rec32 r;
-          r.x = float(p[0]);
-          r.y = float(p[1]);
-          r.z = float(p[2]);
-          r.bin = bin[i];
-          std::memcpy(recs.data() + size_t(dst) * rec_bytes, &r, rec_bytes);
+        if (ll) {
+          for (int k = 0; k < 3; k++)
+            if (double(float(p[k])) != p[k] && p[k] == p[k]) ll = false;
+        }
+        const int b = std::max(0, std::min(B - 1, cast_int(d->intensities[i] * B)));
+        bin[i] = uint32_t(b);
+        gc[b / GW]++;
+        if (spatial) {
+          // bearing cell: the sums are order independent (fixed point), so any order gives the same
+          // bits; a spatially coherent one makes the 64 lanes of a wave gather from neighbouring image
+          // lines for ANY pose (camera and LiDAR are rigidly mounted: a compact patch of bearings stays a
+          // compact patch of pixels)
+          const double az = std::atan2(p[1], p[0]);
+          const double el = std::atan2(p[2], std::sqrt(p[0] * p[0] + p[1] * p[1]));
+          uint32_t qa = uint32_t(std::min(65535.0, std::max(0.0, (az + M_PI) * (65535.0 / (2.0 * M_PI)))));
+          uint32_t qe = uint32_t(std::min(65535.0, std::max(0.0, (el + 0.5 * M_PI) * (65535.0 / M_PI))));
+          if (!(az == az) || !(el == el)) qa = qe = 0;
+          uint32_t m = 0;
+          for (int bb = 0; bb < 16; bb++) m |= (((qa >> bb) & 1u) << (2 * bb)) | (((qe >> bb) & 1u) << (2 * bb + 1));
+          mort[i] = m;
         }
       }
+      lossless_t[t] = ll ? 1 : 0;
     });
-    CREATE_TRY(hipMalloc(&h->d_pts, recs.size() + 64));
-    CREATE_TRY(hipMemcpy(h->d_pts, recs.data(), recs.size(), hipMemcpyHostToDevice));
+    bool lossless = true;
+    for (int t = 0; t < nthreads; t++) lossless = lossless && lossless_t[t];
+    gcount.assign(size_t(h->NG) + 1, 0);
+    for (int g = 0; g < h->NG; g++) {
+      int64_t c = 0;
+      for (int t = 0; t < nthreads; t++) c += gcount_t[t][g];
+      gcount[g + 1] = gcount[g] + c;
+    }
+    h->rec64 = (d->precision == NIDREG_PREC_FP64 && !lossless) ? 1 : 0;
+    const size_t rec_bytes = h->rec64 ? sizeof(Rec64) : sizeof(Rec32);
+    {
+      // order[k] = source index of the k-th device record: stable bucketing by column group, then (default)
+      // each group sorted by Morton code; NIDREG_FLAG_INPUT_ORDER keeps the caller's order inside groups.
+      std::vector<uint32_t> order(N);
+      {
+        std::vector<int64_t> cursor(gcount.begin(), gcount.end() - 1);
+        for (int64_t i = 0; i < N; i++) order[cursor[bin[i] / GW]++] = uint32_t(i);
+      }
+      if (spatial) {
+        std::atomic<int> next_group(0);
+        auto worker = [&]() {
+          std::vector<std::pair<uint32_t, uint32_t>> tmp;
+          for (;;) {
+            const int g = next_group.fetch_add(1);
+            if (g >= h->NG) break;
+            const int64_t lo = gcount[g], hi = gcount[g + 1];
+            tmp.resize(size_t(hi - lo));
+            for (int64_t k = lo; k < hi; k++) tmp[size_t(k - lo)] = std::make_pair(mort[order[k]], order[k]);
+            std::sort(tmp.begin(), tmp.end());
+            for (int64_t k = lo; k < hi; k++) order[k] = tmp[size_t(k - lo)].second;
+          }
+        };
+        const int T = N > 200000 ? std::min(nthreads, h->NG) : 1;
+        if (T <= 1) {
+          worker();
+        } else {
+          std::vector<std::thread> th;
+          for (int t = 0; t < T; t++) th.emplace_back(worker);
+          for (auto& x : th) x.join();
+        }
+      }
+      std::vector<unsigned char> recs(size_t(std::max<int64_t>(N, 1)) * rec_bytes);
+      parallel_for(N, [&](int64_t lo, int64_t hi, int) {
+        for (int64_t dst = lo; dst < hi; dst++) {
+          const int64_t i = order[dst];
+          const double* p = reinterpret_cast<const double*>(pbase + i * pstride);
+          if (h->rec64) {
+            Rec64 r;
+            r.x = p[0];
+            r.y = p[1];
+            r.z = p[2];
+            r.bin = bin[i];
+            std::memcpy(recs.data() + size_t(dst) * rec_bytes, &r, rec_bytes);
+          } else {
+            Rec32 r;
+            r.x = float(p[0]);
+            r.y = float(p[1]);
+            r.z = float(p[2]);
+            r.bin = bin[i];
+            std::memcpy(recs.data() + size_t(dst) * rec_bytes, &r, rec_bytes);
+          }
+        }
+      });
+      CREATE_TRY(hipMalloc(&h->d_pts, recs.size() + 64));
+      CREATE_TRY(hipMemcpy(h->d_pts, recs.data(), recs.size(), hipMemcpyHostToDevice));
+    }
   }
 
   // ---- chunk table: each chunk = one workgroup, points of one column group only
@@ -613,6 +650,57 @@ int nidreg_create(const nidreg_desc* d, nidreg_handle** out) {
 #undef CREATE_TRY
   *out = h;
   return NIDREG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nidreg_create(const nidreg_desc* d, nidreg_handle** out) { return create_impl(d, nullptr, nullptr, 0.0, 0, out); }
+
+int nidreg_cloud_create(int device_id, const double* points, int64_t point_stride, const double* intensities, int64_t num_points, nidreg_cloud** out) {
+  if (!out || num_points < 0 || num_points > int64_t(INT_MAX) || (num_points > 0 && (!points || !intensities))) return fail(NIDREG_ERR_INVALID, "nidreg_cloud_create: bad argument");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(NIDREG_ERR_NO_DEVICE, "nidreg_cloud_create: no HIP device");
+  if (device_id < 0 || device_id >= ndev) return fail(NIDREG_ERR_INVALID, "nidreg_cloud_create: device_id out of range");
+  HIP_TRY(hipSetDevice(device_id));
+  nidreg_cloud* c = new nidreg_cloud();
+  c->device = device_id;
+  c->n = num_points;
+  const size_t n1 = size_t(std::max<int64_t>(num_points, 1));
+  hipError_t e = hipMalloc(&c->d_pts, n1 * 32);
+  if (e == hipSuccess) e = hipMalloc(&c->d_int, n1 * 8);
+  const int64_t stride = point_stride > 0 ? point_stride : 32;
+  if (e == hipSuccess && num_points > 0) {
+    if (stride == 32) {
+      e = hipMemcpy(c->d_pts, points, size_t(num_points) * 32, hipMemcpyHostToDevice);
+    } else {
+      e = hipMemcpy2D(c->d_pts, 32, points, size_t(stride), 32, size_t(num_points), hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess) e = hipMemcpy(c->d_int, intensities, size_t(num_points) * 8, hipMemcpyHostToDevice);
+  }
+  if (e != hipSuccess) {
+    if (c->d_pts) (void)hipFree(c->d_pts);
+    if (c->d_int) (void)hipFree(c->d_int);
+    delete c;
+    return fail(NIDREG_ERR_HIP, std::string("nidreg_cloud_create: ") + hipGetErrorString(e));
+  }
+  *out = c;
+  return NIDREG_OK;
+}
+
+void nidreg_cloud_destroy(nidreg_cloud* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->d_pts) (void)hipFree(c->d_pts);
+  if (c->d_int) (void)hipFree(c->d_int);
+  delete c;
+}
+
+int nidreg_create_from_cloud(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T_camera_lidar, double min_z, int enable_depth_buffer_culling, nidreg_handle** out) {
+  if (!cloud) return fail(NIDREG_ERR_INVALID, "nidreg_create_from_cloud: null cloud");
+  return create_impl(d, cloud, T_camera_lidar, min_z, enable_depth_buffer_culling, out);
 }
 
 void nidreg_destroy(nidreg_handle* h) { free_handle(h); }

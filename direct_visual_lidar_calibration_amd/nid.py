@@ -90,14 +90,49 @@ def _prec(precision):
     raise ValueError(f"unknown precision {precision!r}")
 
 
+class Cloud:
+    """One LiDAR cloud resident on the GPU (``Frame::points`` + ``Frame::intensities`` uploaded once per
+    pair).  Handles built from it (``NIDCost.from_cloud`` / ``CostCalculatorNID.from_cloud``) are culled,
+    bucketed and sorted on the device -- no host round trip per outer iteration."""
+
+    def __init__(self, points, intensities, device=0):
+        lib = _lib.load()
+        self._lib = lib
+        points = np.ascontiguousarray(points, dtype=np.float64)
+        intensities = np.ascontiguousarray(intensities, dtype=np.float64)
+        if points.ndim != 2 or points.shape[1] != 4 or intensities.shape != (points.shape[0],):
+            raise ValueError("points must be (N, 4) float64 (x y z 1) and intensities (N,)")
+        c = ctypes.c_void_p()
+        _lib.check(lib.nidreg_cloud_create(int(device), _dp(points), points.strides[0] if points.shape[0] else 32, _dp(intensities), points.shape[0], ctypes.byref(c)),
+                   "nidreg_cloud_create")
+        self.c = c
+        self.device = int(device)
+        self.num_points = points.shape[0]
+
+    def close(self):
+        if getattr(self, "c", None):
+            self._lib.nidreg_cloud_destroy(self.c)
+            self.c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class _Handle:
     """RAII owner of one ``nidreg_handle`` (device residency of one LiDAR-camera pair)."""
 
-    def __init__(self, proj, image, points, intensities, bins, mode, precision, device, max_fov=0.0, columns_per_group=0, target_blocks=0, scale_points=0, flags=0, lds_copies=0, ext_stream=None, ext_hist=None, ext_out=None):
+    def __init__(self, proj, image, points, intensities, bins, mode, precision, device, max_fov=0.0, columns_per_group=0, target_blocks=0, scale_points=0, flags=0, lds_copies=0, ext_stream=None, ext_hist=None, ext_out=None, cloud=None, cull=None):
         if proj is None:
             raise ValueError("camera is None (create_camera failed)")
         lib = _lib.load()
         self._lib = lib
+        if cloud is not None:
+            points = np.zeros((0, 4))
+            intensities = np.zeros(0)
+            device = cloud.device
         points = np.ascontiguousarray(points, dtype=np.float64)
         intensities = np.ascontiguousarray(intensities, dtype=np.float64)
         if points.ndim != 2 or points.shape[1] != 4:
@@ -139,10 +174,17 @@ class _Handle:
         d.ext_hist = ext_hist
         d.ext_out = ext_out
         h = ctypes.c_void_p()
-        _lib.check(lib.nidreg_create(ctypes.byref(d), ctypes.byref(h)), "nidreg_create")
+        if cloud is None:
+            _lib.check(lib.nidreg_create(ctypes.byref(d), ctypes.byref(h)), "nidreg_create")
+        else:
+            # cull = None | (T_camera_lidar 4x4, min_z, enable_depth_buffer_culling)
+            T = None if cull is None else np.ascontiguousarray(np.asarray(cull[0], dtype=np.float64).reshape(4, 4))
+            min_z = 0.0 if cull is None else float(cull[1])
+            depth = 0 if cull is None else (1 if cull[2] else 0)
+            _lib.check(lib.nidreg_create_from_cloud(ctypes.byref(d), cloud.c, _dp(T), min_z, depth, ctypes.byref(h)), "nidreg_create_from_cloud")
         self.h = h
         self.bins = int(bins)
-        self.num_points = points.shape[0]
+        self.num_points = self.info()["num_points"] if cloud is not None else points.shape[0]
 
     def close(self):
         if getattr(self, "h", None):
@@ -201,6 +243,14 @@ class NIDCost(_Handle):
 
     def __init__(self, proj, normalized_image, points, intensities, bins=16, device=0, precision="fp64", **tuning):
         super().__init__(proj, normalized_image, points, intensities, bins, _lib.MODE_SPLINE, precision, device, **tuning)
+
+    @classmethod
+    def from_cloud(cls, proj, normalized_image, cloud, bins=16, cull=None, precision="fp64", **tuning):
+        """``cull -> new NIDCost`` (visual_camera_calibration.cpp:201-206) fused on the device: ``cull`` is
+        ``None`` or ``(T_camera_lidar 4x4, min_z, enable_depth_buffer_culling)``."""
+        self = cls.__new__(cls)
+        _Handle.__init__(self, proj, normalized_image, None, None, bins, _lib.MODE_SPLINE, precision, cloud.device, cloud=cloud, cull=cull, **tuning)
+        return self
 
     def __call__(self, T_camera_lidar_params, want_grad=True):
         """``operator()(params, residual)``: params = [qx qy qz qw tx ty tz].  Returns
@@ -335,6 +385,18 @@ class CostCalculatorNID(_Handle):
             max_fov = estimate_camera_fov(proj, (image.shape[1], image.shape[0]), device=device)
         self.max_fov = float(max_fov)
         super().__init__(proj, image, points, intensities, params.bins, _lib.MODE_NEAREST, precision, device, max_fov=self.max_fov, **tuning)
+
+    @classmethod
+    def from_cloud(cls, proj, image, cloud, params=None, max_fov=None, cull=None, precision="fp64", **tuning):
+        """``cull -> new CostCalculatorNID`` (visual_camera_calibration.cpp:76-85) fused on the device."""
+        params = params or NIDCostParams()
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        if max_fov is None:
+            max_fov = estimate_camera_fov(proj, (image.shape[1], image.shape[0]), device=cloud.device)
+        self = cls.__new__(cls)
+        self.max_fov = float(max_fov)
+        _Handle.__init__(self, proj, image, None, None, params.bins, _lib.MODE_NEAREST, precision, cloud.device, max_fov=self.max_fov, cloud=cloud, cull=cull, **tuning)
+        return self
 
     def calculate(self, T_camera_lidar):
         """``calculate(const Eigen::Isometry3d&)``: 4x4 matrix -> NID (no finite check, like the

@@ -124,6 +124,16 @@ int nidreg_device_count(void);
 int nidreg_create(const nidreg_desc* desc, nidreg_handle** out);
 void nidreg_destroy(nidreg_handle* h);
 
+/* Device-resident cloud (one upload per LiDAR-camera pair).  nidreg_create_from_cloud builds a handle from
+ * it entirely on the GPU: optional ViewCulling::cull at T_camera_lidar (row-major 4x4; NULL = no culling;
+ * min_z / enable_depth_buffer_culling as in nidreg_view_culling), then bucketing, Morton sort and record
+ * gather -- the reference's per-outer-iteration `cull -> new NIDCost` (visual_camera_calibration.cpp:
+ * 201-206) without a host round trip.  desc->points / intensities / num_points are ignored. */
+typedef struct nidreg_cloud nidreg_cloud;
+int nidreg_cloud_create(int device_id, const double* points, int64_t point_stride, const double* intensities, int64_t num_points, nidreg_cloud** out);
+void nidreg_cloud_destroy(nidreg_cloud* cloud);
+int nidreg_create_from_cloud(const nidreg_desc* desc, const nidreg_cloud* cloud, const double* T_camera_lidar, double min_z, int enable_depth_buffer_culling, nidreg_handle** out);
+
 /* NIDCost::operator(): cost (+ gradient when grad7 != NULL) at se3 = [qx qy qz qw tx ty tz] */
 int nidreg_eval(nidreg_handle* h, const double* se3, double* cost, double* grad7);
 

@@ -92,6 +92,31 @@ def test_fp32_geometry_mode_meets_the_pose_tolerance():
     assert dt <= 1e-3 and dr <= 1e-3, (dt, dr)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("reg", ["nid_bfgs", "nid_nelder_mead"])
+def test_device_resident_calibration_matches_cpu_path(reg):
+    """The whole inner loop without host round trips: cloud uploaded once, every outer iteration culls
+    + rebuilds the cost object on the GPU (NIDCost.from_cloud) -- same final pose as the CPU path."""
+    from direct_visual_lidar_calibration_amd import nid
+
+    s = synth.make_scene(CAMERAS["plumb_bob"], num_points=20000, seed=53, init_delta=(0.02, 0.4))
+    x_ref, log_ref = run_oracle(s, reg, 16)
+    proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
+    max_fov = oracle_lib.estimate_camera_fov(s.model, s.intrinsics, s.distortion, s.width, s.height)
+    min_z = float(np.cos(max_fov))
+    cloud = nid.Cloud(s.points, s.intensities)
+    p = calibration.VisualCameraCalibrationParams(nid_bins=16, registration_type=reg, max_outer_iterations=3)
+    cal = calibration.VisualCameraCalibration(
+        [(s.image_u8, None, None)], p,
+        fused_nid_factory=lambda k, T, b: nid.NIDCost.from_cloud(proj, s.image_f64, cloud, b, cull=(T, min_z, True)),
+        fused_nearest_factory=lambda k, T, b: nid.CostCalculatorNID.from_cloud(proj, s.image_u8, cloud, nid.NIDCostParams(b), max_fov=max_fov, cull=(T, min_z, True)),
+        multi_factory=lambda init, costs: _multi(nid, init, costs))
+    x_gpu = cal.calibrate(s.T_camera_lidar_init)
+    dt, dr = se3.delta_trans_rot(x_ref, x_gpu)
+    assert dt <= 1e-3 and dr <= 1e-3, (dt, dr)
+    cloud.close()
+
+
 def _multi(nid, init, costs):
     m = nid.MultiNIDCost(init)
     for c in costs:

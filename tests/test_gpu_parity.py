@@ -421,3 +421,52 @@ def test_baseline_config_cameras_at_scale(camera, n):
     joint, hi, hp = cost.histograms()
     assert np.abs(joint - ref["hist"]).max() <= 1e-9 and np.array_equal(hp, ref["hist_points"])
     cost.close()
+
+
+@pytest.mark.parametrize("model", ["plumb_bob", "fisheye", "equirectangular"])
+def test_device_resident_cull_and_build_matches_host_path(model):
+    """nidreg_create_from_cloud: ViewCulling + bucketing + sort + gather on the GPU gives the same handle
+    contents as the host path fed with the CPU-culled cloud: identical fixed-point histogram, cost and
+    gradient (the record order may differ; the sums do not)."""
+    s = scene_for(model, n=30000)
+    T = se3.to_matrix(s.T_camera_lidar_init)
+    Tinv = np.linalg.inv(T)
+    pc = s.points[:6000, :3] @ T[:3, :3].T + T[:3, 3]
+    extra = np.concatenate([pc * (1.0 + 1.0 / np.linalg.norm(pc, axis=1, keepdims=True)), -pc]) @ Tinv[:3, :3].T + Tinv[:3, 3]
+    pts = np.concatenate([s.points, np.concatenate([extra, np.ones((extra.shape[0], 1))], -1)])
+    ints = np.concatenate([s.intensities, s.intensities[:6000], s.intensities[:6000]])
+    proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
+    min_z = np.cos(oracle_lib.estimate_camera_fov(s.model, s.intrinsics, s.distortion, s.width, s.height))
+    idx = oracle_lib.view_culling(s.model, s.intrinsics, s.distortion, s.width, s.height, pts, T, True)
+    cloud = nid.Cloud(pts, ints)
+    x = s.T_camera_lidar_init
+    for bins in (16, 256):
+        host = nid.NIDCost(proj, s.image_f64, pts[idx], ints[idx], bins)
+        dev = nid.NIDCost.from_cloud(proj, s.image_f64, cloud, bins, cull=(T, min_z, True))
+        assert dev.num_points == idx.shape[0] == host.num_points
+        ok_h, c_h, g_h = host(x)
+        ok_d, c_d, g_d = dev(x)
+        assert ok_h and ok_d and c_d == c_h
+        assert np.array_equal(dev.histogram_fixed()[0], host.histogram_fixed()[0])
+        assert np.allclose(g_d, g_h, rtol=1e-12, atol=1e-15)  # partial sums are grouped differently
+        host.close()
+        dev.close()
+    # no culling: every point, and the NEAREST twin
+    dev = nid.NIDCost.from_cloud(proj, s.image_f64, cloud, 64)
+    host = nid.NIDCost(proj, s.image_f64, pts, ints, 64)
+    assert dev(x, want_grad=False)[1] == host(x, want_grad=False)[1]
+    dev.close()
+    host.close()
+    max_fov = float(np.arccos(min_z))
+    cd = nid.CostCalculatorNID.from_cloud(proj, s.image_u8, cloud, nid.NIDCostParams(16), max_fov=max_fov, cull=(T, min_z, True))
+    ch = nid.CostCalculatorNID(proj, s.image_u8, pts[idx], ints[idx], nid.NIDCostParams(16), max_fov=max_fov)
+    assert cd.calculate(T) == ch.calculate(T) and np.array_equal(cd.histogram_fixed()[0], ch.histogram_fixed()[0])
+    cd.close()
+    ch.close()
+    # a cloud that is not float32-representable keeps double records
+    c2 = nid.Cloud(pts + np.array([1e-9, 0, 0, 0]), ints)
+    d2 = nid.NIDCost.from_cloud(proj, s.image_f64, c2, 16)
+    assert d2.info()["record_bytes"] == 32
+    d2.close()
+    c2.close()
+    cloud.close()
