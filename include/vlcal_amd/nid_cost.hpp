@@ -24,6 +24,23 @@ inline double get_real(const T& x) { return x.a; }
 template <>
 inline double get_real(const double& x) { return x; }
 
+// One LiDAR cloud resident on the GPU (upload once per pair).  Optional extension over the reference:
+// with it, `ViewCulling::cull -> new NIDCost` of visual_camera_calibration.cpp:201-206 runs entirely on
+// the device (see the second NIDCost constructor).
+class DeviceCloud {
+public:
+  DeviceCloud(const Frame::ConstPtr& points, const int device_id = 0) {
+    nidreg_cloud* c = nullptr;
+    if (nidreg_cloud_create(device_id, reinterpret_cast<const double*>(points->points), sizeof(points->points[0]), points->intensities, static_cast<int64_t>(points->size()), &c) != NIDREG_OK)
+      throw std::runtime_error(std::string("vlcal::DeviceCloud: ") + nidreg_last_error());
+    cloud = std::shared_ptr<nidreg_cloud>(c, &nidreg_cloud_destroy);
+  }
+  const nidreg_cloud* get() const { return cloud.get(); }
+
+private:
+  std::shared_ptr<nidreg_cloud> cloud;
+};
+
 class NIDCost {
 public:
   NIDCost(const camera::GenericCameraBase::ConstPtr& proj, const cv::Mat& normalized_image, const Frame::ConstPtr& points, const int bins = 16, const int device_id = 0,
@@ -49,6 +66,29 @@ public:
     d.intensities = points->intensities;
     nidreg_handle* h = nullptr;
     if (nidreg_create(&d, &h) != NIDREG_OK) throw std::runtime_error(std::string("vlcal::NIDCost: ") + nidreg_last_error());
+    handle = std::shared_ptr<nidreg_handle>(h, &nidreg_destroy);
+  }
+
+  // cull (at T_camera_lidar, row-major 4x4; nullptr = no culling) + build on the device
+  NIDCost(const camera::GenericCameraBase::ConstPtr& proj, const cv::Mat& normalized_image, const DeviceCloud& cloud, const double* T_camera_lidar, const double min_z,
+          const bool enable_depth_buffer_culling, const int bins = 16, const int device_id = 0, const int precision = NIDREG_PREC_FP64) {
+    nidreg_desc d{};
+    d.struct_size = sizeof(nidreg_desc);
+    d.device_id = device_id;
+    d.model_id = proj->nidreg_model_id();
+    d.mode = NIDREG_MODE_SPLINE;
+    d.precision = precision;
+    d.bins = bins;
+    for (int i = 0; i < 5; i++) d.intrinsics[i] = proj->nidreg_intrinsics()[i];
+    for (int i = 0; i < 8; i++) d.distortion[i] = proj->nidreg_distortion()[i];
+    d.width = normalized_image.cols;
+    d.height = normalized_image.rows;
+    d.image_dtype = NIDREG_IMAGE_F64;
+    d.image = normalized_image.data;
+    d.image_row_stride = static_cast<int64_t>(normalized_image.step);
+    nidreg_handle* h = nullptr;
+    if (nidreg_create_from_cloud(&d, cloud.get(), T_camera_lidar, min_z, enable_depth_buffer_culling ? 1 : 0, &h) != NIDREG_OK)
+      throw std::runtime_error(std::string("vlcal::NIDCost: ") + nidreg_last_error());
     handle = std::shared_ptr<nidreg_handle>(h, &nidreg_destroy);
   }
 

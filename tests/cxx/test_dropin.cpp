@@ -65,6 +65,11 @@ int main(int argc, char** argv) {
   if (!multi(params, &res)) return 7;
   double c2 = 0.0;
   if (!(*multi.costs[0])(se3, &c2)) return 8;
+  // device-resident route (no culling): must give the very same cost
+  vlcal::DeviceCloud cloud(frame);
+  vlcal::NIDCost from_cloud(proj, img64, cloud, nullptr, 0.0, false, bins);
+  double c3 = 0.0;
+  if (!from_cloud(se3, &c3) || c3 != c2) return 9;
 
   auto data = std::make_shared<vlcal::VisualLiDARData>(img8, frame);
   vlcal::NIDCostParams np;

@@ -470,3 +470,46 @@ def test_device_resident_cull_and_build_matches_host_path(model):
     d2.close()
     c2.close()
     cloud.close()
+
+
+def test_concurrent_handles_from_host_threads_and_no_leaks():
+    """The reference evaluates one NIDCost per OpenMP thread (visual_camera_calibration.cpp:161):
+    concurrent nidreg_eval on DIFFERENT handles from different host threads must be safe and give
+    the single-threaded bits.  Also: create/destroy in a loop does not leak device memory."""
+    import threading
+
+    import torch
+
+    scenes = [scene_for("plumb_bob", n=20000, seed=60 + k) for k in range(4)]
+    proj = nid.create_camera(scenes[0].model, scenes[0].intrinsics, scenes[0].distortion)
+    costs = [nid.NIDCost(proj, s.image_f64, s.points, s.intensities, 64) for s in scenes]
+    rng = np.random.default_rng(9)
+    poses = [synth.random_pose_near(scenes[0].T_camera_lidar_true, rng) for _ in range(25)]
+    serial = [[c(x) for x in poses] for c in costs]
+    results = [None] * len(costs)
+
+    def work(k):
+        results[k] = [costs[k](x) for x in poses]
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(costs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for k in range(len(costs)):
+        for (ok_a, c_a, g_a), (ok_b, c_b, g_b) in zip(serial[k], results[k]):
+            assert ok_a == ok_b and c_a == c_b and np.array_equal(g_a, g_b)
+    for c in costs:
+        c.close()
+    s = scenes[0]
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(60):
+        c = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, 256)
+        c(poses[0])
+        c.close()
+        cl = nid.Cloud(s.points, s.intensities)
+        d = nid.NIDCost.from_cloud(proj, s.image_f64, cl, 16)
+        d.close()
+        cl.close()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 64 * 1024 * 1024
