@@ -80,13 +80,21 @@ def main():
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the NID core)")
+    # test hooks (not used by the driver): run several ranks on ONE GPU over gloo to exercise the
+    # multi-process code path where only a single device is available
+    backend = os.environ.get("NIDREG_BENCH_BACKEND", "nccl")
+    if os.environ.get("NIDREG_BENCH_ONE_GPU"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     from direct_visual_lidar_calibration_amd import nid, synth
 
@@ -133,7 +141,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
