@@ -1,0 +1,79 @@
+"""CPU tests of the host-side conventions the callers rely on (se3.py, dfo.py): Sophus SE3 storage
+order and right-plus manifold, the 7x6 PlusJacobian Ceres multiplies onto the ambient gradient, GTSAM
+Pose3::Expmap, TUM order of calib.json, and the restated Nelder-Mead."""
+import numpy as np
+import scipy.linalg
+
+from direct_visual_lidar_calibration_amd import se3
+from direct_visual_lidar_calibration_amd.dfo import NelderMead, NelderMeadParams
+
+
+def rand_pose(rng):
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    return np.concatenate([q, rng.normal(size=3)])
+
+
+def test_matrix_roundtrip_and_inverse():
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        x = rand_pose(rng)
+        T = se3.to_matrix(x)
+        assert np.allclose(T[:3, :3] @ T[:3, :3].T, np.eye(3), atol=1e-12) and abs(np.linalg.det(T[:3, :3]) - 1) < 1e-12
+        y = se3.from_matrix(T)
+        assert np.allclose(se3.to_matrix(y), T, atol=1e-12)
+        assert np.allclose(se3.to_matrix(se3.inverse(x)), np.linalg.inv(T), atol=1e-12)
+        z = rand_pose(rng)
+        assert np.allclose(se3.to_matrix(se3.compose(x, z)), T @ se3.to_matrix(z), atol=1e-12)
+
+
+def test_exp_matches_matrix_exponential():
+    rng = np.random.default_rng(1)
+    for scale in (1e-12, 1e-6, 0.3, 2.0):
+        d = rng.normal(size=6) * scale
+        ups, om = d[:3], d[3:]
+        A = np.zeros((4, 4))
+        A[:3, :3] = se3.hat(om)
+        A[:3, 3] = ups
+        assert np.allclose(se3.to_matrix(se3.se3_exp(d)), scipy.linalg.expm(A), atol=1e-10)
+        # GTSAM order is [omega; v]
+        assert np.allclose(se3.pose3_expmap(np.concatenate([om, ups])), scipy.linalg.expm(A), atol=1e-10)
+
+
+def test_plus_jacobian_is_the_derivative_of_plus():
+    rng = np.random.default_rng(2)
+    x = rand_pose(rng)
+    J = se3.plus_jacobian(x)
+    h = 1e-7
+    for k in range(6):
+        e = np.zeros(6)
+        e[k] = h
+        # un-normalised difference of the 7 storage numbers
+        fd = (se3.plus(x, e) - se3.plus(x, -e)) / (2 * h)
+        assert np.allclose(fd, J[:, k], atol=1e-6)
+
+
+def test_tum_order_and_delta():
+    x = rand_pose(np.random.default_rng(3))
+    tum = se3.to_tum(x)
+    assert np.allclose(tum[:3], x[4:]) and np.allclose(tum[3:], x[:4])
+    assert np.allclose(se3.from_tum(tum), x)
+    y = se3.plus(x, np.array([0.03, -0.04, 0.0, 0.0, 0.0, 0.02]))
+    dt, dr = se3.delta_trans_rot(x, y)
+    assert abs(dr - 0.02) < 1e-9 and abs(dt - 0.05) < 1e-3
+
+
+def test_nelder_mead_minimises_and_counts_like_the_reference():
+    calls = []
+
+    def f(x):
+        calls.append(x.copy())
+        return float((x[0] - 1.0) ** 2 + 10 * (x[1] + 0.5) ** 2)
+
+    r = NelderMead(NelderMeadParams(init_step=0.1, convergence_var_thresh=1e-12, max_iterations=500)).optimize(f, np.zeros(2))
+    assert r.converged and np.allclose(r.x, [1.0, -0.5], atol=1e-4)
+    assert r.num_evaluations == len(calls)
+    # simplex construction: x0, then x0 + init_step * e_i (nelder_mead.hpp:36-46)
+    assert np.allclose(calls[0], [0, 0]) and np.allclose(calls[1], [0.1, 0]) and np.allclose(calls[2], [0, 0.1])
+    # the centroid is EVALUATED every iteration (nelder_mead.hpp:58): >= 2 evaluations per iteration
+    assert r.num_evaluations >= 3 + 2 * r.num_iterations
