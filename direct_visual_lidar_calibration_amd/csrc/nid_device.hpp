@@ -143,12 +143,23 @@ __device__ __forceinline__ auto mad(const A& a, const B& b, const C& c) -> declt
   }
 }
 
+// 1/z by v_rcp_f64 + two Newton steps (5 instructions instead of the ~12 of the IEEE division
+// sequence); |z| is a camera-frame depth in metres, never denormal / inf in range of interest, and a
+// NaN / zero z still yields a NaN / inf projection, i.e. an outlier.
+__device__ __forceinline__ double fast_rcp(double z) {
+  double r = __builtin_amdgcn_rcp(z);
+  r = fma(fma(-z, r, 1.0), r, r);
+  r = fma(fma(-z, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ float fast_rcp(float z) { return 1.0f / z; }
+
 // perspective division: exact x/z, y/z (NEAREST path) or one reciprocal and two multiplies (SPLINE
 // kernels; both passes use the same form, so they agree on every knot)
 template <bool FAST, typename real>
 __device__ __forceinline__ void persp(real x, real y, real z, real& px, real& py) {
   if (FAST) {
-    const real iz = real(1) / z;
+    const real iz = fast_rcp(z);
     px = x * iz;
     py = y * iz;
   } else {
@@ -273,7 +284,7 @@ template <int MODEL, typename real>
 __device__ __forceinline__ void project_jac(const CamParams<real>& c, real x, real y, real z, real& u, real& v, real* du, real* dv) {
   if (MODEL == MODEL_PLUMB_BOB || MODEL == MODEL_RATIONAL) {
     project<MODEL, real, real, true>(c, x, y, z, u, v);  // value: identical expression to the histogram pass
-    const real iz = real(1) / z;
+    const real iz = fast_rcp(z);
     const real px = x * iz, py = y * iz;
     const real x2 = px * px, y2 = py * py, xy = px * py;
     const real r2 = fma(px, px, y2);
@@ -375,7 +386,8 @@ __device__ __forceinline__ void bspline(real s, real* b) {
   // bit-identical across tilings); the fusions we want are therefore written out
   const real s2 = s * s, s3 = s2 * s;
   const real k16 = real(1.0 / 6.0), k36 = real(3.0 / 6.0), k46 = real(4.0 / 6.0);
-  b[0] = fma(-k16, s3, fma(k36, s2, fma(-k36, s, k16)));
+  const real t = real(1) - s;  // b0 = (1-s)^3 / 6, written so that it can never round below +0: the
+  b[0] = k16 * (t * t * t);     // subnormal fixed-point trick (to_fixed_dn) needs sign bit 0 on every weight
   b[1] = fma(k36, s3, k46 - s2);
   b[2] = fma(-k36, s3, fma(k36, s2, fma(k36, s, k16)));
   b[3] = k16 * s3;
@@ -397,14 +409,13 @@ __device__ __forceinline__ void transform_fma(const PoseParams<real>& pose, real
   cz = fma(pose.R[8], z, fma(pose.R[7], y, fma(pose.R[6], x, pose.t[2])));
 }
 
-// weight in [0,1] -> unsigned fixed point with `frac` fractional bits via the magic-constant
-// trick: magic = 2^(52-frac); the low mantissa bits of (w + magic) are round-to-nearest(w * 2^frac)
-// The weight is the product wa * wb; the product and the magic add are one fma.  wa * wb >= -1e-15
-// always (B-spline values), which rounds to the integer 0, so no clamp is needed.
-__device__ __forceinline__ u64 to_fixed(double wa, double wb, double magic) {
-  const double d = fma(wa, wb, magic);
-  return u64(__double_as_longlong(d)) & 0x000FFFFFFFFFFFFFull;
-}
+// weight -> unsigned fixed point with `frac` fractional bits in ONE instruction: the x-weights are
+// pre-multiplied by dn = 2^(frac - 1074), so the product bxs * by is a SUBNORMAL double whose bit
+// pattern (exponent field 0) IS the integer round-to-nearest(bx' * by * 2^frac) -- no magic add, no mask.
+// (bx' = bx rounded to 2^-frac by the pre-scaling: total quantisation <= 0.75 units of 2^-frac instead
+// of 0.5; still deterministic and order independent.)  gfx950 handles fp64 denormals at full rate.
+__device__ __forceinline__ u64 to_fixed_dn(double bx_scaled, double by) { return u64(__double_as_longlong(bx_scaled * by)); }
+
 
 // The bin image is stored in STRIPS of four rows with the four vertically adjacent pixels of a
 // column contiguous: byte address of padded pixel (x, y) = (y >> 2) * 4 * pitch + 4 * x + (y & 3).

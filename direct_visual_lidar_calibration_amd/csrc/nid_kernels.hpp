@@ -130,7 +130,7 @@ __device__ __forceinline__ void grad_final_body(const double* partials, int nblo
 template <int MODEL, typename Rec, typename real>
 __global__ __launch_bounds__(kThreads) void k_spline_hist(
   const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint8_t* __restrict__ img, int pitch, int W, int H, PoseParams<real> pose, CamParams<real> cam, int B,
-  int GW, int cshift, double magic, u64* __restrict__ hist) {
+  int GW, int cshift, double dn_scale, u64* __restrict__ hist) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u64* tile = reinterpret_cast<u64*>(smem);
   const int tile_n = GW * B;
@@ -184,9 +184,10 @@ __global__ __launch_bounds__(kThreads) void k_spline_hist(
       real bx[4], by[4];
       bspline<real>(uc - fu, bx);
       bspline<real>(vc - fv, by);
-      const real keep = in ? real(1) : real(0);
+      const double keep = in ? dn_scale : 0.0;  // 2^(frac - 1074); an outlier / padding slot adds exact zeros
+      double bxs[4];
 #pragma unroll
-      for (int a = 0; a < 4; a++) bx[a] *= keep;
+      for (int a = 0; a < 4; a++) bxs[a] = double(bx[a]) * keep;
       u64* col = tile + ((((bins_[k] - col0) * uint32_t(B)) << cshift) + lane_copy);
       // padded bin image: tap (a,b) of knot (kx,ky) is padded pixel (kx + a, ky + b) (edge-replicated,
       // which is the reference's clamp of knots_x / knots_y, nid_cost.hpp:70-73)
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(kThreads) void k_spline_hist(
 #pragma unroll
         for (int a = 0; a < 4; a++) {
           const uint32_t r = (cols[a] >> (8 * b)) & 0xffu;
-          atomicAdd(&col[r << cshift], to_fixed(double(bx[a]), double(by[b]), magic));  // ds_add_u64
+          atomicAdd(&col[r << cshift], to_fixed_dn(bxs[a], double(by[b])));  // v_mul_f64 + ds_add_u64
         }
       }
     }

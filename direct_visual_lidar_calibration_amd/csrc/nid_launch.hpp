@@ -24,7 +24,7 @@ struct PassArgs {
   double R[9], t[3];  // SPLINE pose
   double iso[12];     // NEAREST pose (rows 0..2 of the 4x4)
   double intr[5], dist[8];
-  double magic;     // 2^(52 - frac_bits)
+  double magic;     // 2^(frac_bits - 1074): subnormal pre-scale of the x-weights
   double inv_unit;  // 2^(-frac_bits)
   double cos_fov;
   unsigned long long* hist;

@@ -135,7 +135,7 @@ void fill_pass_args(const nidreg_handle* h, PassArgs& a) {
   a.cshift = h->cshift;
   std::memcpy(a.intr, h->intr, sizeof(a.intr));
   std::memcpy(a.dist, h->dist, sizeof(a.dist));
-  a.magic = std::ldexp(1.0, 52 - h->frac_bits);
+  a.magic = std::ldexp(1.0, h->frac_bits - 1074);  // subnormal pre-scale of the x-weights (to_fixed_dn)
   a.inv_unit = std::ldexp(1.0, -h->frac_bits);
   a.cos_fov = std::cos(h->max_fov);
   a.hist = h->d_hist;
