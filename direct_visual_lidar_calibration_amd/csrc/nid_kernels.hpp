@@ -77,7 +77,7 @@ __device__ __forceinline__ bool last_workgroup_arrives(unsigned int* counter, un
 //   grad_v = 2 w A + 2 (M v + M^T v - 2 tr(M) v);  grad_t = gt.
 // out[1..7] = d NID / d [qx qy qz qw tx ty tz]; out_host (nullable) = host-mapped mirror.
 // s_red: kWaves * 12 doubles of LDS.
-__device__ __forceinline__ void grad_final_body(const double* partials, int nblocks, double qx, double qy, double qz, double qw, double* out, double* out_host, double* s_red) {
+__device__ __forceinline__ void grad_final_body(const double* partials, int nblocks, double qx, double qy, double qz, double qw, double* out, double* out_host, double tag, double* s_red) {
   const int tid = threadIdx.x;
   double acc[12];
 #pragma unroll
@@ -120,6 +120,8 @@ __device__ __forceinline__ void grad_final_body(const double* partials, int nblo
     if (out_host) {
       for (int k = 0; k < 7; k++) out_host[1 + k] = g[k];
       __threadfence_system();
+      // completion tag of this evaluation: the host polls this word instead of synchronising the stream
+      __hip_atomic_store(&out_host[15], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
@@ -321,7 +323,7 @@ __global__ __launch_bounds__(kThreads) void k_nearest_hist(
 // nid_cost.hpp:86-104: NID = (Hj - MI) / Hj, MI = Hi + Hp - Hj.
 __device__ __forceinline__ void entropy_final_body(
   const u64* hist, int B, int NG, double inv_unit, const double* part_hj, const u64* row_part, const u64* col_sum, double* phi_q, double* hist_image_out, double* hist_points_out,
-  EntropyScalars* scal, double* out, double* out_host, double* s_red) {
+  EntropyScalars* scal, double* out, double* out_host, double tag, double* s_red) {
   const int tid = threadIdx.x;
   const double S = double(hist[size_t(B) * size_t(B) + kTailInliers]);
   double hi_acc = 0.0, hp_acc = 0.0, hj_acc = 0.0;
@@ -378,6 +380,7 @@ __device__ __forceinline__ void entropy_final_body(
       out_host[8] = e.status;
       out_host[9] = S;
       __threadfence_system();
+      if (tag != 0.0) __hip_atomic_store(&out_host[15], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // final kernel of a cost-only evaluation
     }
   }
 }
@@ -385,7 +388,7 @@ __device__ __forceinline__ void entropy_final_body(
 constexpr int kEntropyColsMax = 16;
 __global__ __launch_bounds__(kThreads) void k_entropy(
   const u64* __restrict__ hist, int B, int CB, double inv_unit, double* part_hj, u64* row_part, double* phi_q, double* hist_image_out, double* hist_points_out,
-  EntropyScalars* scal, double* out, double* out_host, unsigned int* counter) {
+  EntropyScalars* scal, double* out, double* out_host, double tag, unsigned int* counter) {
   __shared__ double s_red[3 * kWaves];
   __shared__ int s_flag;
   const int tid = threadIdx.x;
@@ -418,7 +421,7 @@ __global__ __launch_bounds__(kThreads) void k_entropy(
   }
   const u64* col_sum = hist + size_t(B) * size_t(B) + kTailWords;  // accumulated by the histogram kernels' flush
   if (last_workgroup_arrives<false>(counter, gridDim.x, &s_flag))
-    entropy_final_body(hist, B, int(gridDim.x), inv_unit, part_hj, row_part, col_sum, phi_q, hist_image_out, hist_points_out, scal, out, out_host, s_red);
+    entropy_final_body(hist, B, int(gridDim.x), inv_unit, part_hj, row_part, col_sum, phi_q, hist_image_out, hist_points_out, scal, out, out_host, tag, s_red);
 }
 
 #endif  // NID_COMMON_KERNELS
@@ -433,7 +436,7 @@ template <int MODEL, typename Rec, typename real>
 __global__ __launch_bounds__(kThreads) void k_spline_grad(
   const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint8_t* __restrict__ img, int pitch, int W, int H, PoseParams<real> pose, CamParams<real> cam, int B,
   int GW, int cshift, double inv_unit, const u64* __restrict__ hist, const double* __restrict__ phi_q, const EntropyScalars* __restrict__ scal, double* partials, double qx,
-  double qy, double qz, double qw, double* out, double* out_host, unsigned int* counter) {
+  double qy, double qz, double qw, double* out, double* out_host, double tag, unsigned int* counter) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* gtile = reinterpret_cast<double*>(smem);
   const int tile_n = GW * B;
@@ -538,14 +541,14 @@ __global__ __launch_bounds__(kThreads) void k_spline_grad(
     // [12][nchunks] (coalesced for the final reduction), stored write-through at agent scope
     __hip_atomic_store(&partials[size_t(tid) * gridDim.x + blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (last_workgroup_arrives<true>(counter, gridDim.x, s_flag)) grad_final_body(partials, int(gridDim.x), qx, qy, qz, qw, out, out_host, s_red);
+  if (last_workgroup_arrives<true>(counter, gridDim.x, s_flag)) grad_final_body(partials, int(gridDim.x), qx, qy, qz, qw, out, out_host, tag, s_red);
 }
 
 #ifdef NID_COMMON_KERNELS
 // standalone finalisation (only launched for an empty cloud, where k_spline_grad has no workgroups)
-__global__ __launch_bounds__(kThreads) void k_grad_final(const double* partials, int nblocks, double qx, double qy, double qz, double qw, double* out, double* out_host) {
+__global__ __launch_bounds__(kThreads) void k_grad_final(const double* partials, int nblocks, double qx, double qy, double qz, double qw, double* out, double* out_host, double tag) {
   __shared__ double s_red[kWaves * 12];
-  grad_final_body(partials, nblocks, qx, qy, qz, qw, out, out_host, s_red);
+  grad_final_body(partials, nblocks, qx, qy, qz, qw, out, out_host, tag, s_red);
 }
 #endif  // NID_COMMON_KERNELS
 

@@ -34,6 +34,7 @@ struct PassArgs {
   double q[4];          // quaternion of the pose (gradient chain rule)
   double* out;          // device result block
   double* out_host;     // host-mapped mirror (nullable)
+  double tag;           // completion tag written behind the results (host polls it)
   unsigned int* counter;  // last-workgroup ticket
   hipStream_t stream;
   size_t lds_hist, lds_grad;

@@ -82,6 +82,8 @@ struct nidreg_handle {
   double* h_out = nullptr;       // pinned, host-mapped
   double* d_out_host = nullptr;  // device address of h_out (NULL when results live in ext_out)
   unsigned int* d_counters = nullptr;  // [0] entropy ticket, [1] gradient ticket
+  double seq = 0.0;                    // completion tag of the evaluation in flight (host-mapped polling)
+  unsigned int evals_since_reap = 0;
 
   size_t lds_hist = 0, lds_grad = 0, lds_entropy = 0;
   int64_t hist_words = 0;
@@ -145,6 +147,7 @@ void fill_pass_args(const nidreg_handle* h, PassArgs& a) {
   for (int k = 0; k < 4; k++) a.q[k] = h->last_q[k];
   a.out = h->d_out;
   a.out_host = h->d_out_host;
+  a.tag = h->seq;
   a.counter = h->d_counters + 1;
   a.stream = h->stream;
   a.lds_hist = h->lds_hist;
@@ -199,11 +202,11 @@ int launch_hist_nearest(nidreg_handle* h, const double* T) {
   return NIDREG_OK;
 }
 
-int launch_entropy(nidreg_handle* h) {
+int launch_entropy(nidreg_handle* h, double tag) {
   const double inv_unit = std::ldexp(1.0, -h->frac_bits);
   hipLaunchKernelGGL(
     k_entropy, dim3(h->NEB), dim3(kThreads), 0, h->stream, h->d_hist, h->bins, kEntropyCols, inv_unit, h->d_part_hj, h->d_row_part, h->d_phi_q, h->d_hist_image,
-    h->d_hist_points, h->d_scal, h->d_out, h->d_out_host, h->d_counters);
+    h->d_hist_points, h->d_scal, h->d_out, h->d_out_host, tag, h->d_counters);
   HIP_TRY(hipGetLastError());
   return NIDREG_OK;
 }
@@ -221,7 +224,7 @@ int launch_grad(nidreg_handle* h) {
   }
   if (h->timing) HIP_TRY(hipEventRecord(h->ev[4], h->stream));
   if (h->nchunks == 0) {  // empty cloud: no gradient workgroups ran, finalise (zeros) stand-alone
-    hipLaunchKernelGGL(k_grad_final, dim3(1), dim3(kThreads), 0, h->stream, h->d_partials, 0, h->last_q[0], h->last_q[1], h->last_q[2], h->last_q[3], h->d_out, h->d_out_host);
+    hipLaunchKernelGGL(k_grad_final, dim3(1), dim3(kThreads), 0, h->stream, h->d_partials, 0, h->last_q[0], h->last_q[1], h->last_q[2], h->last_q[3], h->d_out, h->d_out_host, h->seq);
     HIP_TRY(hipGetLastError());
   }
   return NIDREG_OK;
@@ -231,11 +234,12 @@ int launch_grad(nidreg_handle* h) {
 int eval_launch(nidreg_handle* h, const double* se3, bool want_grad) {
   if (h->mode != NIDREG_MODE_SPLINE) return fail(NIDREG_ERR_INVALID, "nidreg_eval: handle was created in NEAREST mode");
   HIP_TRY(hipSetDevice(h->device));
+  h->seq += 1.0;
   if (h->timing) HIP_TRY(hipEventRecord(h->ev[0], h->stream));
   int rc = launch_hist_spline(h, se3);
   if (rc) return rc;
   if (h->timing) HIP_TRY(hipEventRecord(h->ev[2], h->stream));
-  rc = launch_entropy(h);
+  rc = launch_entropy(h, want_grad ? 0.0 : h->seq);
   if (rc) return rc;
   if (h->timing) HIP_TRY(hipEventRecord(h->ev[3], h->stream));
   h->ev_grad = want_grad;
@@ -252,7 +256,30 @@ int eval_launch(nidreg_handle* h, const double* se3, bool want_grad) {
 
 int eval_finish(nidreg_handle* h, double* cost, double* grad7) {
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->d_out_host) {
+    // the finalising workgroup wrote the results and then this evaluation's tag into host-mapped memory:
+    // poll the tag (a few us cheaper than hipStreamSynchronize); look at the stream now and then so that a
+    // faulted kernel cannot hang the caller, and so the runtime can retire finished commands
+    volatile double* flag = h->h_out + 15;
+    unsigned long long spins = 0;
+    while (*flag != h->seq) {
+      if ((++spins & 0x3fffull) == 0) {
+        const hipError_t q = hipStreamQuery(h->stream);
+        if (q == hipSuccess) {
+          if (*flag != h->seq) HIP_TRY(hipStreamSynchronize(h->stream));
+          if (*flag != h->seq) return fail(NIDREG_ERR_HIP, "nidreg_eval: stream drained but the completion tag is missing");
+          break;
+        }
+        if (q != hipErrorNotReady) return fail(NIDREG_ERR_HIP, std::string("nidreg_eval: ") + hipGetErrorString(q));
+      }
+    }
+    if (++h->evals_since_reap >= 256) {
+      h->evals_since_reap = 0;
+      (void)hipStreamQuery(h->stream);
+    }
+  } else {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
   if (cost) *cost = h->h_out[0];
   if (grad7)
     for (int k = 0; k < 7; k++) grad7[k] = h->h_out[1 + k];
@@ -262,11 +289,12 @@ int eval_finish(nidreg_handle* h, double* cost, double* grad7) {
 int iso_launch(nidreg_handle* h, const double* T) {
   if (h->mode != NIDREG_MODE_NEAREST) return fail(NIDREG_ERR_INVALID, "nidreg_eval_iso: handle was created in SPLINE mode");
   HIP_TRY(hipSetDevice(h->device));
+  h->seq += 1.0;
   if (h->timing) HIP_TRY(hipEventRecord(h->ev[0], h->stream));
   int rc = launch_hist_nearest(h, T);
   if (rc) return rc;
   if (h->timing) HIP_TRY(hipEventRecord(h->ev[2], h->stream));
-  rc = launch_entropy(h);
+  rc = launch_entropy(h, h->seq);
   if (rc) return rc;
   if (h->timing) {
     HIP_TRY(hipEventRecord(h->ev[3], h->stream));
@@ -876,7 +904,7 @@ int nidreg_shard_hist(nidreg_handle* h, const double* se3) {
 int nidreg_shard_entropy(nidreg_handle* h) {
   if (!h) return fail(NIDREG_ERR_INVALID, "nidreg_shard_entropy: null handle");
   HIP_TRY(hipSetDevice(h->device));
-  return launch_entropy(h);
+  return launch_entropy(h, 0.0);
 }
 
 int nidreg_shard_grad(nidreg_handle* h) {
@@ -888,8 +916,12 @@ int nidreg_shard_grad(nidreg_handle* h) {
 int nidreg_shard_finish(nidreg_handle* h, double* cost, double* grad7) {
   if (!h) return fail(NIDREG_ERR_INVALID, "nidreg_shard_finish: null handle");
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipMemcpyAsync(h->h_out, h->d_out, NIDREG_OUT_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  return eval_finish(h, cost, grad7);
+  if (!h->d_out_host) HIP_TRY(hipMemcpyAsync(h->h_out, h->d_out, NIDREG_OUT_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (cost) *cost = h->h_out[0];
+  if (grad7)
+    for (int k = 0; k < 7; k++) grad7[k] = h->h_out[1 + k];
+  return h->h_out[8] != 0.0 ? NIDREG_FALSE : NIDREG_OK;
 }
 
 int nidreg_set_timing(nidreg_handle* h, int enable) {
