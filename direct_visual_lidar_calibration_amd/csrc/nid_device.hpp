@@ -24,22 +24,26 @@ namespace nidreg {
 
 typedef unsigned long long u64;
 
+// the scalar math (camera models, B-spline basis, dual numbers) is also compiled for the host so that
+// tests/cxx/test_device_math.cpp can check it without a GPU; the loads / LDS code below is device only
+#define NID_HD __host__ __device__ __forceinline__
+
 // ------------------------------------------------------------------------------------------
 // scalar helpers for float / double
-__device__ __forceinline__ float m_sqrt(float x) { return sqrtf(x); }
-__device__ __forceinline__ double m_sqrt(double x) { return sqrt(x); }
-__device__ __forceinline__ float m_atan2(float y, float x) { return atan2f(y, x); }
-__device__ __forceinline__ double m_atan2(double y, double x) { return atan2(y, x); }
-__device__ __forceinline__ float m_asin(float x) { return asinf(x); }
-__device__ __forceinline__ double m_asin(double x) { return asin(x); }
-__device__ __forceinline__ float m_atan(float x) { return atanf(x); }
-__device__ __forceinline__ double m_atan(double x) { return atan(x); }
-__device__ __forceinline__ float m_abs(float x) { return fabsf(x); }
-__device__ __forceinline__ double m_abs(double x) { return fabs(x); }
-__device__ __forceinline__ float m_floor(float x) { return floorf(x); }
-__device__ __forceinline__ double m_floor(double x) { return floor(x); }
-__device__ __forceinline__ float m_val(float x) { return x; }
-__device__ __forceinline__ double m_val(double x) { return x; }
+NID_HD float m_sqrt(float x) { return sqrtf(x); }
+NID_HD double m_sqrt(double x) { return sqrt(x); }
+NID_HD float m_atan2(float y, float x) { return atan2f(y, x); }
+NID_HD double m_atan2(double y, double x) { return atan2(y, x); }
+NID_HD float m_asin(float x) { return asinf(x); }
+NID_HD double m_asin(double x) { return asin(x); }
+NID_HD float m_atan(float x) { return atanf(x); }
+NID_HD double m_atan(double x) { return atan(x); }
+NID_HD float m_abs(float x) { return fabsf(x); }
+NID_HD double m_abs(double x) { return fabs(x); }
+NID_HD float m_floor(float x) { return floorf(x); }
+NID_HD double m_floor(double x) { return floor(x); }
+NID_HD float m_val(float x) { return x; }
+NID_HD double m_val(double x) { return x; }
 
 // ------------------------------------------------------------------------------------------
 // forward-mode dual number with three partials (d/dx, d/dy, d/dz of the camera-frame point).
@@ -49,56 +53,56 @@ __device__ __forceinline__ double m_val(double x) { return x; }
 template <typename real>
 struct Dual3 {
   real a, d0, d1, d2;
-  __device__ __forceinline__ Dual3() {}
-  __device__ __forceinline__ Dual3(real v) : a(v), d0(0), d1(0), d2(0) {}
-  __device__ __forceinline__ Dual3(real v, real x, real y, real z) : a(v), d0(x), d1(y), d2(z) {}
+  NID_HD Dual3() {}
+  NID_HD Dual3(real v) : a(v), d0(0), d1(0), d2(0) {}
+  NID_HD Dual3(real v, real x, real y, real z) : a(v), d0(x), d1(y), d2(z) {}
 };
 
 template <typename real>
-__device__ __forceinline__ real m_val(const Dual3<real>& x) { return x.a; }
+NID_HD real m_val(const Dual3<real>& x) { return x.a; }
 
 #define NID_D Dual3<real>
-template <typename real> __device__ __forceinline__ NID_D operator+(const NID_D& f, const NID_D& g) { return NID_D(f.a + g.a, f.d0 + g.d0, f.d1 + g.d1, f.d2 + g.d2); }
-template <typename real> __device__ __forceinline__ NID_D operator+(const NID_D& f, real s) { return NID_D(f.a + s, f.d0, f.d1, f.d2); }
-template <typename real> __device__ __forceinline__ NID_D operator+(real s, const NID_D& f) { return NID_D(s + f.a, f.d0, f.d1, f.d2); }
-template <typename real> __device__ __forceinline__ NID_D operator-(const NID_D& f, const NID_D& g) { return NID_D(f.a - g.a, f.d0 - g.d0, f.d1 - g.d1, f.d2 - g.d2); }
-template <typename real> __device__ __forceinline__ NID_D operator-(const NID_D& f, real s) { return NID_D(f.a - s, f.d0, f.d1, f.d2); }
-template <typename real> __device__ __forceinline__ NID_D operator-(real s, const NID_D& f) { return NID_D(s - f.a, -f.d0, -f.d1, -f.d2); }
-template <typename real> __device__ __forceinline__ NID_D operator-(const NID_D& f) { return NID_D(-f.a, -f.d0, -f.d1, -f.d2); }
-template <typename real> __device__ __forceinline__ NID_D operator*(const NID_D& f, const NID_D& g) {
+template <typename real> NID_HD NID_D operator+(const NID_D& f, const NID_D& g) { return NID_D(f.a + g.a, f.d0 + g.d0, f.d1 + g.d1, f.d2 + g.d2); }
+template <typename real> NID_HD NID_D operator+(const NID_D& f, real s) { return NID_D(f.a + s, f.d0, f.d1, f.d2); }
+template <typename real> NID_HD NID_D operator+(real s, const NID_D& f) { return NID_D(s + f.a, f.d0, f.d1, f.d2); }
+template <typename real> NID_HD NID_D operator-(const NID_D& f, const NID_D& g) { return NID_D(f.a - g.a, f.d0 - g.d0, f.d1 - g.d1, f.d2 - g.d2); }
+template <typename real> NID_HD NID_D operator-(const NID_D& f, real s) { return NID_D(f.a - s, f.d0, f.d1, f.d2); }
+template <typename real> NID_HD NID_D operator-(real s, const NID_D& f) { return NID_D(s - f.a, -f.d0, -f.d1, -f.d2); }
+template <typename real> NID_HD NID_D operator-(const NID_D& f) { return NID_D(-f.a, -f.d0, -f.d1, -f.d2); }
+template <typename real> NID_HD NID_D operator*(const NID_D& f, const NID_D& g) {
   return NID_D(f.a * g.a, fma(f.a, g.d0, f.d0 * g.a), fma(f.a, g.d1, f.d1 * g.a), fma(f.a, g.d2, f.d2 * g.a));
 }
-template <typename real> __device__ __forceinline__ NID_D operator*(const NID_D& f, real s) { return NID_D(f.a * s, f.d0 * s, f.d1 * s, f.d2 * s); }
-template <typename real> __device__ __forceinline__ NID_D operator*(real s, const NID_D& f) { return NID_D(f.a * s, f.d0 * s, f.d1 * s, f.d2 * s); }
-template <typename real> __device__ __forceinline__ NID_D operator/(const NID_D& f, const NID_D& g) {
+template <typename real> NID_HD NID_D operator*(const NID_D& f, real s) { return NID_D(f.a * s, f.d0 * s, f.d1 * s, f.d2 * s); }
+template <typename real> NID_HD NID_D operator*(real s, const NID_D& f) { return NID_D(f.a * s, f.d0 * s, f.d1 * s, f.d2 * s); }
+template <typename real> NID_HD NID_D operator/(const NID_D& f, const NID_D& g) {
   const real gi = real(1) / g.a;
   const real q = f.a * gi;
   return NID_D(q, fma(-q, g.d0, f.d0) * gi, fma(-q, g.d1, f.d1) * gi, fma(-q, g.d2, f.d2) * gi);
 }
-template <typename real> __device__ __forceinline__ NID_D operator/(const NID_D& f, real s) {
+template <typename real> NID_HD NID_D operator/(const NID_D& f, real s) {
   const real si = real(1) / s;
   return NID_D(f.a * si, f.d0 * si, f.d1 * si, f.d2 * si);
 }
-template <typename real> __device__ __forceinline__ bool operator<(const NID_D& f, real s) { return f.a < s; }
-template <typename real> __device__ __forceinline__ bool operator>(const NID_D& f, real s) { return f.a > s; }
-template <typename real> __device__ __forceinline__ NID_D m_sqrt(const NID_D& f) {
+template <typename real> NID_HD bool operator<(const NID_D& f, real s) { return f.a < s; }
+template <typename real> NID_HD bool operator>(const NID_D& f, real s) { return f.a > s; }
+template <typename real> NID_HD NID_D m_sqrt(const NID_D& f) {
   const real t = m_sqrt(f.a);
   const real k = real(1) / (real(2) * t);
   return NID_D(t, f.d0 * k, f.d1 * k, f.d2 * k);
 }
-template <typename real> __device__ __forceinline__ NID_D m_atan2(const NID_D& g, const NID_D& f) {
+template <typename real> NID_HD NID_D m_atan2(const NID_D& g, const NID_D& f) {
   const real k = real(1) / fma(f.a, f.a, g.a * g.a);
   return NID_D(m_atan2(g.a, f.a), k * fma(-g.a, f.d0, f.a * g.d0), k * fma(-g.a, f.d1, f.a * g.d1), k * fma(-g.a, f.d2, f.a * g.d2));
 }
-template <typename real> __device__ __forceinline__ NID_D m_asin(const NID_D& f) {
+template <typename real> NID_HD NID_D m_asin(const NID_D& f) {
   const real k = real(1) / m_sqrt(real(1) - f.a * f.a);
   return NID_D(m_asin(f.a), k * f.d0, k * f.d1, k * f.d2);
 }
-template <typename real> __device__ __forceinline__ NID_D m_atan(const NID_D& f) {
+template <typename real> NID_HD NID_D m_atan(const NID_D& f) {
   const real k = real(1) / (real(1) + f.a * f.a);
   return NID_D(m_atan(f.a), k * f.d0, k * f.d1, k * f.d2);
 }
-template <typename real> __device__ __forceinline__ NID_D m_abs(const NID_D& f) {
+template <typename real> NID_HD NID_D m_abs(const NID_D& f) {
   const real s = f.a < real(0) ? real(-1) : real(1);
   return NID_D(m_abs(f.a), s * f.d0, s * f.d1, s * f.d2);
 }
@@ -135,7 +139,7 @@ enum { MODEL_PLUMB_BOB = 0, MODEL_FISHEYE = 1, MODEL_OMNIDIR = 2, MODEL_EQUIRECT
 // no fma; Dual3 operands: their operators).  Every use below nests the terms so that the unfused
 // form reproduces the reference's left-to-right association exactly (fp addition is commutative).
 template <bool FAST, typename A, typename B, typename C>
-__device__ __forceinline__ auto mad(const A& a, const B& b, const C& c) -> decltype(a * b + c) {
+NID_HD auto mad(const A& a, const B& b, const C& c) -> decltype(a * b + c) {
   if constexpr (FAST && std::is_floating_point<A>::value && std::is_floating_point<B>::value && std::is_floating_point<C>::value) {
     return fma(a, b, c);
   } else {
@@ -146,18 +150,83 @@ __device__ __forceinline__ auto mad(const A& a, const B& b, const C& c) -> declt
 // 1/z by v_rcp_f64 + two Newton steps (5 instructions instead of the ~12 of the IEEE division
 // sequence); |z| is a camera-frame depth in metres, never denormal / inf in range of interest, and a
 // NaN / zero z still yields a NaN / inf projection, i.e. an outlier.
-__device__ __forceinline__ double fast_rcp(double z) {
-  double r = __builtin_amdgcn_rcp(z);
+NID_HD double rcp_seed(double z) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rcp(z);
+#else
+  return double(1.0f / float(z));  // host build (tests): a 24-bit seed, like the hardware's
+#endif
+}
+NID_HD double rsq_seed(double z) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rsq(z);
+#else
+  return double(1.0f / sqrtf(float(z)));
+#endif
+}
+NID_HD double fast_rcp(double z) {
+  double r = rcp_seed(z);
   r = fma(fma(-z, r, 1.0), r, r);
   r = fma(fma(-z, r, 1.0), r, r);
   return r;
 }
-__device__ __forceinline__ float fast_rcp(float z) { return 1.0f / z; }
+NID_HD float fast_rcp(float z) { return 1.0f / z; }
+// 1/sqrt(z) by v_rsq_f64 + two Newton steps r += r (1 - z r^2) / 2.  z = 0 -> NaN (inf * 0), z < 0 -> NaN.
+NID_HD double fast_rsq(double z) {
+  double r = rsq_seed(z);
+  r = fma(0.5 * r, fma(-z * r, r, 1.0), r);
+  r = fma(0.5 * r, fma(-z * r, r, 1.0), r);
+  return r;
+}
+NID_HD float fast_rsq(float z) { return 1.0f / sqrtf(z); }
+
+// atan2 for the SPLINE kernels' fisheye / equirectangular projections: octant reduction to t in [0,1]
+// with one fast reciprocal, then atan(t) = t P(t^2) with a 20-term polynomial (Chebyshev interpolant of
+// atan(sqrt s)/sqrt s on [0,1], tools/gen_atan_poly.py; max abs error 2.3e-16 in the double Horner
+// form), ~40 instructions against ~110 for the library routine with its IEEE division.
+// atan2(0, 0) = 0 like libm (equirectangular.hpp:21 relies on it for points on the vertical axis).
+NID_HD double fast_atan2(double y, double x) {
+  const double kC[20] = {
+    1.00000000000000000e+00,
+    -3.33333333333307003e-01,
+    1.99999999996479605e-01,
+    -1.42857142669267329e-01,
+    1.11111105780020827e-01,
+    -9.09089979321734132e-02,
+    7.69219899745829383e-02,
+    -6.66576491068972266e-02,
+    5.87682811448727235e-02,
+    -5.23742347191881660e-02,
+    4.66874530484852890e-02,
+    -4.08112475031788546e-02,
+    3.38712670270067476e-02,
+    -2.55686236443717387e-02,
+    1.67195960635073901e-02,
+    -8.99108054265826059e-03,
+    3.75113848396514118e-03,
+    -1.12525443022346450e-03,
+    2.14238107386039464e-04,
+    -1.93423475928923002e-05,
+  };
+  const double ax = fabs(x), ay = fabs(y);
+  const bool swap = ay > ax;
+  const double mx = swap ? ay : ax, mn = swap ? ax : ay;  // NaN operands propagate (no maxNum semantics)
+  const double t = mn * fast_rcp(mx < 1e-30 ? 1e-30 : mx);  // 0/0 -> 0; a NaN mx stays NaN
+  const double s = t * t;
+  double p = kC[19];
+#pragma unroll
+  for (int k = 18; k >= 0; k--) p = fma(p, s, kC[k]);
+  double a = t * p;
+  a = swap ? 1.57079632679489661923 - a : a;
+  a = x < 0.0 ? 3.14159265358979323846 - a : a;
+  return copysign(a, y);
+}
+NID_HD float fast_atan2(float y, float x) { return atan2f(y, x); }
 
 // perspective division: exact x/z, y/z (NEAREST path) or one reciprocal and two multiplies (SPLINE
 // kernels; both passes use the same form, so they agree on every knot)
 template <bool FAST, typename real>
-__device__ __forceinline__ void persp(real x, real y, real z, real& px, real& py) {
+NID_HD void persp(real x, real y, real z, real& px, real& py) {
   if (FAST) {
     const real iz = fast_rcp(z);
     px = x * iz;
@@ -168,7 +237,7 @@ __device__ __forceinline__ void persp(real x, real y, real z, real& px, real& py
   }
 }
 template <bool FAST, typename real>
-__device__ __forceinline__ void persp(const Dual3<real>& x, const Dual3<real>& y, const Dual3<real>& z, Dual3<real>& px, Dual3<real>& py) {
+NID_HD void persp(const Dual3<real>& x, const Dual3<real>& y, const Dual3<real>& z, Dual3<real>& px, Dual3<real>& py) {
   px = x / z;  // Dual3 division is reciprocal-multiply already
   py = y / z;
 }
@@ -176,7 +245,7 @@ __device__ __forceinline__ void persp(const Dual3<real>& x, const Dual3<real>& y
 // projection models (reference: include/camera/{pinhole,fisheye,omnidir,equirectangular,atan,
 // rational_polynomial}.hpp), T = real or Dual3<real>.
 template <int MODEL, typename T, typename real, bool FAST = false>
-__device__ __forceinline__ void project(const CamParams<real>& c, const T& x, const T& y, const T& z, T& u, T& v) {
+NID_HD void project(const CamParams<real>& c, const T& x, const T& y, const T& z, T& u, T& v) {
   if (MODEL == MODEL_PLUMB_BOB) {  // pinhole.hpp:13-51, distortion k1 k2 p1 p2 k3
     const real k1 = c.dist[0], k2 = c.dist[1], p1 = c.dist[2], p2 = c.dist[3], k3 = c.dist[4];
     T px, py;
@@ -195,29 +264,52 @@ __device__ __forceinline__ void project(const CamParams<real>& c, const T& x, co
     v = mad<FAST>(c.intr[1], dy, c.intr[3]);
   } else if (MODEL == MODEL_FISHEYE) {  // fisheye.hpp:14-36 (abs(z) at :16)
     const real k1 = c.dist[0], k2 = c.dist[1], k3 = c.dist[2], k4 = c.dist[3];
-    const T r = m_sqrt(mad<FAST>(x, x, y * y));
-    const T theta = m_atan2(r, m_abs(z));
-    const T th2 = theta * theta;
-    const T th4 = th2 * th2;
-    const T th6 = th4 * th2;
-    const T th8 = th4 * th4;
-    const T theta_d = theta * mad<FAST>(k4, th8, mad<FAST>(k3, th6, mad<FAST>(k2, th4, mad<FAST>(k1, th2, real(1)))));
-    const T s = theta_d / r;
-    u = mad<FAST>(c.intr[0], s * x, c.intr[2]);
-    v = mad<FAST>(c.intr[1], s * y, c.intr[3]);
+    if constexpr (FAST && std::is_floating_point<T>::value) {
+      // 1/r from one rsqrt (r = r2 / r), atan2 without the IEEE division, theta_d / r as a multiply.
+      // r2 = 0 gives 1/r = NaN, hence a NaN projection, like the reference's 0/0 (fisheye.hpp:31-33).
+      const T r2 = fma(x, x, y * y);
+      const T ir = fast_rsq(r2);
+      const T theta = fast_atan2(r2 * ir, m_abs(z));
+      const T th2 = theta * theta;
+      const T theta_d = theta * fma(th2, fma(th2, fma(th2, fma(th2, k4, k3), k2), k1), real(1));
+      const T s = theta_d * ir;
+      u = fma(c.intr[0], s * x, c.intr[2]);
+      v = fma(c.intr[1], s * y, c.intr[3]);
+    } else {
+      const T r = m_sqrt(mad<FAST>(x, x, y * y));
+      const T theta = m_atan2(r, m_abs(z));
+      const T th2 = theta * theta;
+      const T th4 = th2 * th2;
+      const T th6 = th4 * th2;
+      const T th8 = th4 * th4;
+      const T theta_d = theta * mad<FAST>(k4, th8, mad<FAST>(k3, th6, mad<FAST>(k2, th4, mad<FAST>(k1, th2, real(1)))));
+      const T s = theta_d / r;
+      u = mad<FAST>(c.intr[0], s * x, c.intr[2]);
+      v = mad<FAST>(c.intr[1], s * y, c.intr[3]);
+    }
   } else if (MODEL == MODEL_OMNIDIR) {  // omnidir.hpp:14-41
     const real xi = c.intr[4];
     const real k1 = c.dist[0], k2 = c.dist[1], p1 = c.dist[2], p2 = c.dist[3];
     const T n2 = mad<FAST>(z, z, mad<FAST>(y, y, x * x));                 // x x + y y + z z
-    T sx = x, sy = y, sz = z;
-    if (n2 > real(0)) {
-      const T n = m_sqrt(n2);
-      sx = x / n;
-      sy = y / n;
-      sz = z / n;
+    T ux, uy;
+    if constexpr (FAST && std::is_floating_point<T>::value) {
+      // unit-sphere normalisation by one rsqrt, mirror division by one reciprocal
+      const T in = n2 > real(0) ? fast_rsq(n2) : real(1);
+      const T iden = fast_rcp(fma(z, in, xi));
+      ux = (x * in) * iden;
+      uy = (y * in) * iden;
+    } else {
+      T sx = x, sy = y, sz = z;
+      if (n2 > real(0)) {
+        const T n = m_sqrt(n2);
+        sx = x / n;
+        sy = y / n;
+        sz = z / n;
+      }
+      const T den = sz + xi;
+      ux = sx / den;
+      uy = sy / den;
     }
-    const T den = sz + xi;
-    const T ux = sx / den, uy = sy / den;
     const T x2 = ux * ux, y2 = uy * uy, xy = ux * uy;
     const T r2 = mad<FAST>(ux, ux, y2);
     const T r4 = r2 * r2;
@@ -228,7 +320,19 @@ __device__ __forceinline__ void project(const CamParams<real>& c, const T& x, co
     v = mad<FAST>(c.intr[1], ny, c.intr[3]);
   } else if (MODEL == MODEL_EQUIRECT) {  // equirectangular.hpp:14-28, intr = [W H]
     const T n2 = mad<FAST>(z, z, mad<FAST>(y, y, x * x));
-    if (n2 < real(1e-3)) {
+    if constexpr (FAST && std::is_floating_point<T>::value) {
+      // asin(y / |p|) = atan2(y, rho) with rho = sqrt(x^2 + z^2): no normalisation of the bearing is
+      // needed at all, and both angles share the division-free atan2
+      const T rho2 = fma(x, x, z * z);
+      const T rho = rho2 > real(0) ? rho2 * fast_rsq(rho2) : real(0);
+      const T lon = fast_atan2(x, z);
+      const T nlat = fast_atan2(y, rho);  // = -lat
+      const bool tiny = n2 < real(1e-3);
+      const T uu = fma(c.intr[0] * real(0.15915494309189533577), lon, c.intr[0] * real(0.5));
+      const T vv = fma(c.intr[1] * real(0.31830988618379067154), nlat, c.intr[1] * real(0.5));
+      u = tiny ? c.intr[0] * real(0.5) : uu;
+      v = tiny ? c.intr[1] * real(0.5) : vv;
+    } else if (n2 < real(1e-3)) {
       u = T(c.intr[0] / real(2));
       v = T(c.intr[1] / real(2));
     } else {
@@ -276,62 +380,141 @@ __device__ __forceinline__ void project(const CamParams<real>& c, const T& x, co
   }
 }
 
-// projection value + 2x3 Jacobian d(u,v)/d(x,y,z) for the gradient pass.  Generic route: Dual3
-// forward mode (3 partials through every operation).  plumb_bob / rational_polynomial: the Jacobian of
-// the distortion polynomial is written out by hand (it is symmetric) and chained with the closed-form
-// Jacobian of the perspective division, ~2.5x fewer fp64 operations than Dual3.
+// Jacobian of the radial-tangential distortion shared by plumb_bob / rational_polynomial / omnidir,
+//   dx = rc px + 2 p1 px py + p2 (r2 + 2 px^2),  dy = rc py + p1 (r2 + 2 py^2) + 2 p2 px py,
+// written out by hand (it is symmetric up to fx / fy): a = diag(fx, fy) d(dx, dy)/d(px, py).
 template <int MODEL, typename real>
-__device__ __forceinline__ void project_jac(const CamParams<real>& c, real x, real y, real z, real& u, real& v, real* du, real* dv) {
+NID_HD void radtan_jac(const CamParams<real>& c, real px, real py, real& a00, real& a01, real& a10, real& a11) {
+  const real x2 = px * px, y2 = py * py, xy = px * py;
+  const real r2 = fma(px, px, y2);
+  const real r4 = r2 * r2;
+  const real p1 = c.dist[2], p2 = c.dist[3];
+  real rc, rcp;  // radial factor and d(rc)/d(r2)
+  if (MODEL == MODEL_PLUMB_BOB) {
+    const real k1 = c.dist[0], k2 = c.dist[1], k3 = c.dist[4];
+    const real r6 = r2 * r4;
+    rc = fma(k3, r6, fma(k2, r4, fma(k1, r2, real(1))));
+    rcp = fma(real(3) * k3, r4, fma(real(2) * k2, r2, k1));
+  } else if (MODEL == MODEL_OMNIDIR) {
+    const real k1 = c.dist[0], k2 = c.dist[1];
+    rc = fma(k2, r4, fma(k1, r2, real(1)));
+    rcp = fma(real(2) * k2, r2, k1);
+  } else {
+    const real k1 = c.dist[0], k2 = c.dist[1], k3 = c.dist[4], k4 = c.dist[5], k5 = c.dist[6], k6 = c.dist[7];
+    const real r6 = r2 * r4;
+    const real num = fma(k3, r6, fma(k2, r4, fma(k1, r2, real(1))));
+    const real den = fma(k6, r6, fma(k5, r4, fma(k4, r2, real(1))));
+    const real nump = fma(real(3) * k3, r4, fma(real(2) * k2, r2, k1));
+    const real denp = fma(real(3) * k6, r4, fma(real(2) * k5, r2, k4));
+    if (den > real(1e-8)) {
+      const real id = real(1) / den;
+      rc = num * id;
+      rcp = (nump - rc * denp) * id;
+    } else {
+      rc = num;
+      rcp = nump;
+    }
+  }
+  const real off = fma(real(2) * xy, rcp, real(2) * fma(p1, px, p2 * py));  // d(dx)/d(py) = d(dy)/d(px)
+  a00 = c.intr[0] * fma(real(2) * x2, rcp, rc + real(2) * fma(p1, py, real(3) * p2 * px));
+  a01 = c.intr[0] * off;
+  a10 = c.intr[1] * off;
+  a11 = c.intr[1] * fma(real(2) * y2, rcp, rc + real(2) * fma(real(3) * p1, py, p2 * px));
+}
+
+// projection value + 2x3 Jacobian d(u,v)/d(x,y,z) for the gradient pass.  The value is the same
+// expression as in the histogram pass (both passes agree on every knot).  The Jacobians of the five
+// models the configs use are written out by hand -- 2.5x (plumb_bob) to ~6x (equirectangular) fewer
+// fp64 operations than pushing three partials through every operation; `atan` keeps the generic
+// Dual3 forward mode.  Same chain rules as the reference's Jets (a1-a10 in SURVEY.md section 8).
+template <int MODEL, typename real>
+NID_HD void project_jac(const CamParams<real>& c, real x, real y, real z, real& u, real& v, real* du, real* dv) {
   if (MODEL == MODEL_PLUMB_BOB || MODEL == MODEL_RATIONAL) {
-    project<MODEL, real, real, true>(c, x, y, z, u, v);  // value: identical expression to the histogram pass
+    project<MODEL, real, real, true>(c, x, y, z, u, v);
     const real iz = fast_rcp(z);
     const real px = x * iz, py = y * iz;
-    const real x2 = px * px, y2 = py * py, xy = px * py;
-    const real r2 = fma(px, px, y2);
-    const real r4 = r2 * r2;
-    real rc, rcp, p1, p2;  // radial factor and d(rc)/d(r2)
-    if (MODEL == MODEL_PLUMB_BOB) {
-      const real k1 = c.dist[0], k2 = c.dist[1], k3 = c.dist[4];
-      p1 = c.dist[2];
-      p2 = c.dist[3];
-      const real r6 = r2 * r4;
-      rc = fma(k3, r6, fma(k2, r4, fma(k1, r2, real(1))));
-      rcp = fma(real(3) * k3, r4, fma(real(2) * k2, r2, k1));
-    } else {
-      const real k1 = c.dist[0], k2 = c.dist[1], k3 = c.dist[4], k4 = c.dist[5], k5 = c.dist[6], k6 = c.dist[7];
-      p1 = c.dist[2];
-      p2 = c.dist[3];
-      const real r6 = r2 * r4;
-      const real num = fma(k3, r6, fma(k2, r4, fma(k1, r2, real(1))));
-      const real den = fma(k6, r6, fma(k5, r4, fma(k4, r2, real(1))));
-      const real nump = fma(real(3) * k3, r4, fma(real(2) * k2, r2, k1));
-      const real denp = fma(real(3) * k6, r4, fma(real(2) * k5, r2, k4));
-      if (den > real(1e-8)) {
-        const real id = real(1) / den;
-        rc = num * id;
-        rcp = (nump - rc * denp) * id;
-      } else {
-        rc = num;
-        rcp = nump;
-      }
-    }
-    const real off = fma(real(2) * xy, rcp, real(2) * fma(p1, px, p2 * py));  // d(dx)/d(py) = d(dy)/d(px)
-    const real a00 = c.intr[0] * fma(real(2) * x2, rcp, rc + real(2) * fma(p1, py, real(3) * p2 * px));
-    const real a01 = c.intr[0] * off;
-    const real a10 = c.intr[1] * off;
-    const real a11 = c.intr[1] * fma(real(2) * y2, rcp, rc + real(2) * fma(real(3) * p1, py, p2 * px));
+    real a00, a01, a10, a11;
+    radtan_jac<MODEL, real>(c, px, py, a00, a01, a10, a11);
     du[0] = a00 * iz;
     du[1] = a01 * iz;
     du[2] = -fma(du[0], px, du[1] * py);
     dv[0] = a10 * iz;
     dv[1] = a11 * iz;
     dv[2] = -fma(dv[0], px, dv[1] * py);
+  } else if (MODEL == MODEL_OMNIDIR) {
+    // m = s_xy / (s_z + xi), s = p / |p|:  d(m)/d(s) = [I2 | -m] / den,  d(s)/d(p) = (I - s s^T) / |p|
+    project<MODEL, real, real, true>(c, x, y, z, u, v);
+    const real n2 = fma(z, z, fma(y, y, x * x));
+    const bool pos = n2 > real(0);
+    const real in = pos ? fast_rsq(n2) : real(1);
+    const real sx = x * in, sy = y * in, sz = z * in;
+    const real iden = fast_rcp(sz + c.intr[4]);
+    const real ux = sx * iden, uy = sy * iden;
+    real a00, a01, a10, a11;
+    radtan_jac<MODEL, real>(c, ux, uy, a00, a01, a10, a11);
+    // an un-normalised point (|p| = 0, omnidir.hpp:19) has d(s)/d(p) = I: dot = 0 and in = 1 below
+    {
+      const real b0 = a00 * iden, b1 = a01 * iden, b2 = -fma(b0, ux, b1 * uy);
+      const real dot = pos ? fma(b2, sz, fma(b1, sy, b0 * sx)) : real(0);
+      du[0] = fma(-dot, sx, b0) * in;
+      du[1] = fma(-dot, sy, b1) * in;
+      du[2] = fma(-dot, sz, b2) * in;
+    }
+    {
+      const real b0 = a10 * iden, b1 = a11 * iden, b2 = -fma(b0, ux, b1 * uy);
+      const real dot = pos ? fma(b2, sz, fma(b1, sy, b0 * sx)) : real(0);
+      dv[0] = fma(-dot, sx, b0) * in;
+      dv[1] = fma(-dot, sy, b1) * in;
+      dv[2] = fma(-dot, sz, b2) * in;
+    }
+  } else if (MODEL == MODEL_FISHEYE) {
+    // (u, v) = f .* s (x, y) + c,  s = theta_d(theta) / r,  theta = atan2(r, |z|),  r = |(x, y)|:
+    //   d(s x)/dx = s + x^2 q,  d(s x)/dy = x y q,  d(s x)/dz = -x theta_d' sgn(z) / |p|^2,
+    //   q = (theta_d' |z| / |p|^2 - s) / r^2
+    project<MODEL, real, real, true>(c, x, y, z, u, v);
+    const real k1 = c.dist[0], k2 = c.dist[1], k3 = c.dist[2], k4 = c.dist[3];
+    const real r2 = fma(x, x, y * y);
+    const real ir = fast_rsq(r2);
+    const real az = m_abs(z);
+    const real theta = fast_atan2(r2 * ir, az);
+    const real th2 = theta * theta;
+    const real theta_d = theta * fma(th2, fma(th2, fma(th2, fma(th2, k4, k3), k2), k1), real(1));
+    const real dtheta_d = fma(th2, fma(th2, fma(th2, fma(th2, real(9) * k4, real(7) * k3), real(5) * k2), real(3) * k1), real(1));
+    const real s = theta_d * ir;
+    const real in2 = fast_rcp(fma(z, z, r2));
+    const real ir2 = ir * ir;
+    const real q = fma(dtheta_d * az, in2, -s) * ir2;
+    const real wz = (z < real(0) ? dtheta_d : -dtheta_d) * in2;  // -theta_d' sgn(z) / |p|^2
+    const real fx = c.intr[0], fy = c.intr[1];
+    const real xq = x * q, yq = y * q;
+    du[0] = fx * fma(x, xq, s);
+    du[1] = fx * (x * yq);
+    du[2] = fx * (x * wz);
+    dv[0] = fy * (y * xq);
+    dv[1] = fy * fma(y, yq, s);
+    dv[2] = fy * (y * wz);
+  } else if (MODEL == MODEL_EQUIRECT) {
+    // u = W (1/2 + atan2(x, z) / 2 pi),  v = H (1/2 + atan2(y, rho) / pi),  rho = |(x, z)|
+    project<MODEL, real, real, true>(c, x, y, z, u, v);
+    const real rho2 = fma(x, x, z * z);
+    const real n2 = fma(y, y, rho2);
+    const bool tiny = fma(z, z, fma(y, y, x * x)) < real(1e-3);  // the value's own test (equirectangular.hpp:16)
+    const real irho = fast_rsq(rho2);
+    const real in2 = fast_rcp(n2);
+    const real ku = tiny ? real(0) : c.intr[0] * real(0.15915494309189533577) * (irho * irho);
+    const real kv = tiny ? real(0) : c.intr[1] * real(0.31830988618379067154) * in2;
+    du[0] = ku * z;
+    du[1] = real(0);
+    du[2] = -ku * x;
+    const real t = -(kv * y) * irho;
+    dv[0] = t * x;
+    dv[1] = kv * (rho2 * irho);
+    dv[2] = t * z;
   } else {
     typedef Dual3<real> D;
     D uu, vv;
+    project<MODEL, real, real, true>(c, x, y, z, u, v);  // value: the histogram pass's own expression
     project<MODEL, D, real, true>(c, D(x, real(1), real(0), real(0)), D(y, real(0), real(1), real(0)), D(z, real(0), real(0), real(1)), uu, vv);
-    u = uu.a;
-    v = vv.a;
     du[0] = uu.d0;
     du[1] = uu.d1;
     du[2] = uu.d2;
@@ -380,7 +563,7 @@ struct Chunk {  // one workgroup's slice of the bucketed cloud
 // uniform cubic B-spline basis, the reference's 4x4 coefficient matrix / 6 (nid_cost.hpp:29-33),
 // evaluated as C * [1 s s^2 s^3]^T in the same term order
 template <typename real>
-__device__ __forceinline__ void bspline(real s, real* b) {
+NID_HD void bspline(real s, real* b) {
   // explicit fma: all translation units are built with -ffp-contract=off so that every point gets
   // the same arithmetic no matter which unrolled slot / chunk / GPU processes it (the histogram is
   // bit-identical across tilings); the fusions we want are therefore written out
@@ -393,7 +576,7 @@ __device__ __forceinline__ void bspline(real s, real* b) {
   b[3] = k16 * s3;
 }
 template <typename real>
-__device__ __forceinline__ void bspline_deriv(real s, real* d) {
+NID_HD void bspline_deriv(real s, real* d) {
   const real s2 = s * s;
   d[0] = fma(real(-0.5), s2, s - real(0.5));
   d[1] = fma(real(1.5), s2, real(-2) * s);
@@ -403,7 +586,7 @@ __device__ __forceinline__ void bspline_deriv(real s, real* d) {
 
 // p_cam = R p + t with fused multiply-adds (SPLINE kernels)
 template <typename real>
-__device__ __forceinline__ void transform_fma(const PoseParams<real>& pose, real x, real y, real z, real& cx, real& cy, real& cz) {
+NID_HD void transform_fma(const PoseParams<real>& pose, real x, real y, real z, real& cx, real& cy, real& cz) {
   cx = fma(pose.R[2], z, fma(pose.R[1], y, fma(pose.R[0], x, pose.t[0])));
   cy = fma(pose.R[5], z, fma(pose.R[4], y, fma(pose.R[3], x, pose.t[1])));
   cz = fma(pose.R[8], z, fma(pose.R[7], y, fma(pose.R[6], x, pose.t[2])));

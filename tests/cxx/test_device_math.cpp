@@ -1,0 +1,137 @@
+// Host-side check of the scalar device math in csrc/nid_device.hpp (compiled by hipcc as a HIP
+// source, run on the CPU -- no kernel is launched): the SPLINE kernels' FAST projections
+// (reciprocal / rsqrt with Newton steps, division-free atan2) and the hand-derived 2x3 projection
+// Jacobians are compared with the oracle's camera functors instantiated with double and Jet<7>
+// (the reference's own route to those derivatives, generic_camera_base.hpp:34-40).
+// Prints one line per model: max |uv - uv_ref| (pixels), max relative Jacobian error; exit 1 on failure.
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+
+#include "../../direct_visual_lidar_calibration_amd/csrc/nid_device.hpp"
+#include "../../oracle/cameras.hpp"
+
+using namespace nidreg;
+
+template <int MODEL, typename Proj>
+static int check(const char* name, const double* intr, int ni, const double* dist, int nd, double tol_uv, double tol_jac) {
+  CamParams<double> c;
+  double I[5] = {0, 0, 0, 0, 0}, D[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 5; i++) c.intr[i] = I[i] = i < ni ? intr[i] : 0.0;
+  for (int i = 0; i < 8; i++) c.dist[i] = D[i] = i < nd ? dist[i] : 0.0;
+  std::mt19937_64 rng(1234 + MODEL);
+  std::uniform_real_distribution<double> U(-1.0, 1.0);
+  Proj proj;
+  double e_uv = 0, e_fast_exact = 0, e_j = 0;
+  int n_checked = 0;
+  for (int it = 0; it < 200000; it++) {
+    double x, y, z;
+    if (MODEL == MODEL_EQUIRECT || MODEL == MODEL_OMNIDIR) {  // full sphere (omnidir: in front of the mirror singularity)
+      x = 20 * U(rng), y = 20 * U(rng), z = 20 * U(rng);
+      if (MODEL == MODEL_OMNIDIR && z < 0.2 * std::sqrt(x * x + y * y)) continue;
+    } else {
+      z = 0.5 + 15 * (U(rng) + 1.0);
+      x = z * 1.2 * U(rng), y = z * 0.8 * U(rng);
+    }
+    if (it % 1000 == 7 && MODEL == MODEL_FISHEYE) z = -z;  // fisheye.hpp:16 takes abs(z)
+    // reference value and Jacobian (Jets seeded on x, y, z)
+    oracle::V3<oracle::Jet7> pj{oracle::Jet7(x, 0), oracle::Jet7(y, 1), oracle::Jet7(z, 2)};
+    const oracle::V2<oracle::Jet7> rj = proj(I, D, pj);
+    // exact-order device expression (NEAREST path) and FAST expression (SPLINE path)
+    double ue, ve, uf, vf, u, v, du[3], dv[3];
+    project<MODEL, double, double, false>(c, x, y, z, ue, ve);
+    project<MODEL, double, double, true>(c, x, y, z, uf, vf);
+    project_jac<MODEL, double>(c, x, y, z, u, v, du, dv);
+    if (!(std::isfinite(rj.x.a) && std::isfinite(rj.y.a))) continue;
+    if (u != uf || v != vf) {
+      std::printf("%s: project_jac value differs from the histogram pass's value\n", name);
+      return 1;
+    }
+    if (ue != rj.x.a || ve != rj.y.a) {  // the NEAREST path must be bit-identical to the CPU expression
+      // pow(theta, k) in the reference vs products here can differ in the last bit for fisheye
+      if (std::fabs(ue - rj.x.a) > 1e-9 || std::fabs(ve - rj.y.a) > 1e-9) {
+        std::printf("%s: exact-order projection differs: %.17g %.17g vs %.17g %.17g\n", name, ue, ve, rj.x.a, rj.y.a);
+        return 1;
+      }
+    }
+    e_fast_exact = std::fmax(e_fast_exact, std::fmax(std::fabs(ue - rj.x.a), std::fabs(ve - rj.y.a)));
+    e_uv = std::fmax(e_uv, std::fmax(std::fabs(uf - rj.x.a), std::fabs(vf - rj.y.a)));
+    double scale = 1e-300;
+    for (int k = 0; k < 3; k++) scale = std::fmax(scale, std::fmax(std::fabs(rj.x.v[k]), std::fabs(rj.y.v[k])));
+    for (int k = 0; k < 3; k++) {
+      e_j = std::fmax(e_j, std::fabs(du[k] - rj.x.v[k]) / scale);
+      e_j = std::fmax(e_j, std::fabs(dv[k] - rj.y.v[k]) / scale);
+    }
+    n_checked++;
+  }
+  std::printf("%s checked=%d exact_vs_ref=%.3g fast_vs_ref=%.3g jac_rel=%.3g\n", name, n_checked, e_fast_exact, e_uv, e_j);
+  if (!(e_uv <= tol_uv) || !(e_j <= tol_jac) || n_checked < 50000) return 1;
+  return 0;
+}
+
+int main() {
+  int bad = 0;
+  {
+    const double intr[4] = {1100, 1100, 960, 540}, dist[5] = {-0.04, 0.08, 1e-4, -3e-4, -0.04};
+    bad += check<MODEL_PLUMB_BOB, oracle::PinholeProjection>("plumb_bob", intr, 4, dist, 5, 1e-9, 1e-11);
+  }
+  {
+    const double intr[4] = {600, 600, 960, 540}, dist[4] = {-0.01, 0.002, -1e-4, 1e-5};
+    bad += check<MODEL_FISHEYE, oracle::FisheyeProjection>("fisheye", intr, 4, dist, 4, 1e-9, 1e-11);
+  }
+  {
+    const double intr[5] = {600, 600, 1024, 1024, 1.0}, dist[4] = {-0.02, 0.003, 2e-4, -1e-4};
+    bad += check<MODEL_OMNIDIR, oracle::OmnidirProjection>("omnidir", intr, 5, dist, 4, 1e-9, 1e-11);
+  }
+  {
+    const double intr[2] = {2048, 2048};
+    bad += check<MODEL_EQUIRECT, oracle::EquirectProjection>("equirectangular", intr, 2, nullptr, 0, 1e-9, 1e-10);
+  }
+  {
+    const double intr[4] = {500, 500, 320, 240}, dist[1] = {0.9};
+    bad += check<MODEL_ATAN, oracle::AtanProjection>("atan", intr, 4, dist, 1, 1e-9, 1e-11);
+  }
+  {
+    const double intr[4] = {1100, 1100, 960, 540}, dist[8] = {0.1, -0.05, 1e-4, -2e-4, 0.01, 0.05, -0.02, 0.003};
+    bad += check<MODEL_RATIONAL, oracle::RationalProjection>("rational_polynomial", intr, 4, dist, 8, 1e-9, 1e-11);
+  }
+  // the poles / axis of the equirectangular model: atan2(0, 0) = 0 like libm
+  {
+    CamParams<double> c{};
+    c.intr[0] = 2048, c.intr[1] = 1024;
+    double u, v;
+    project<MODEL_EQUIRECT, double, double, true>(c, 0.0, 3.0, 0.0, u, v);
+    oracle::EquirectProjection P;
+    const double I[2] = {2048, 1024};
+    const oracle::V2<double> r = P(I, nullptr, oracle::V3<double>{0.0, 3.0, 0.0});
+    std::printf("equirect axis: %.17g %.17g vs %.17g %.17g\n", u, v, r.x, r.y);
+    if (std::fabs(u - r.x) > 1e-9 || std::fabs(v - r.y) > 1e-9) bad++;
+    project<MODEL_EQUIRECT, double, double, true>(c, 0.01, 0.0, 0.01, u, v);  // |p|^2 < 1e-3 -> image centre
+    if (u != 1024.0 || v != 512.0) bad++;
+    // fisheye on the optical axis: NaN like the reference's 0/0
+    CamParams<double> f{};
+    f.intr[0] = f.intr[1] = 600, f.intr[2] = 960, f.intr[3] = 540;
+    project<MODEL_FISHEYE, double, double, true>(f, 0.0, 0.0, 5.0, u, v);
+    if (u == u || v == v) {
+      std::printf("fisheye axis: expected NaN, got %g %g\n", u, v);
+      bad++;
+    }
+  }
+  // fast_atan2 / fast_rcp / fast_rsq accuracy
+  {
+    std::mt19937_64 rng(99);
+    std::uniform_real_distribution<double> U(-1.0, 1.0);
+    double ea = 0, er = 0, es = 0;
+    for (int i = 0; i < 2000000; i++) {
+      const double a = 30 * U(rng), b = 30 * U(rng);
+      ea = std::fmax(ea, std::fabs(fast_atan2(a, b) - std::atan2(a, b)));
+      const double z = 0.01 + 100 * std::fabs(U(rng));
+      er = std::fmax(er, std::fabs(fast_rcp(z) * z - 1.0));
+      es = std::fmax(es, std::fabs(fast_rsq(z) * std::sqrt(z) - 1.0));
+    }
+    std::printf("fast_atan2 max abs err %.3g, fast_rcp rel %.3g, fast_rsq rel %.3g\n", ea, er, es);
+    if (ea > 1e-15 || er > 5e-16 || es > 5e-16) bad++;
+    if (fast_atan2(0.0, 0.0) != 0.0 || fast_atan2(0.0, -1.0) != std::atan2(0.0, -1.0) || fast_atan2(-0.0, 1.0) != 0.0) bad++;
+  }
+  return bad ? 1 : 0;
+}
