@@ -62,7 +62,8 @@ EXPORTS = [
     "nidreg_model_from_name", "nidreg_device_count", "nidreg_create", "nidreg_destroy", "nidreg_cloud_create", "nidreg_cloud_destroy", "nidreg_create_from_cloud", "nidreg_eval", "nidreg_eval_iso", "nidreg_eval_multi",
     "nidreg_eval_iso_multi", "nidreg_get_hist", "nidreg_get_hist_fixed", "nidreg_project", "nidreg_project_model", "nidreg_view_culling", "nidreg_hist_words", "nidreg_shard_hist",
     "nidreg_shard_entropy", "nidreg_shard_grad", "nidreg_shard_finish", "nidreg_set_timing", "nidreg_get_timing", "nidreg_get_info", "nidreg_last_error",
-    "nidreg_version",
+    "nidreg_version", "nidreg_colorizer_create", "nidreg_colorizer_update", "nidreg_colorizer_device_colors", "nidreg_colorizer_destroy", "nidreg_generate_lidar_image",
+    "nidreg_equalize_intensities",
 ]
 
 _lib = None
@@ -106,6 +107,16 @@ def load():
     lib.nidreg_get_timing.argtypes = [ctypes.c_void_p, c_float_p]
     lib.nidreg_get_info.argtypes = [ctypes.c_void_p, c_int64_p]
     lib.nidreg_model_from_name.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    lib.nidreg_colorizer_create.argtypes = [ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, c_double_p,
+                                            ctypes.c_int64, c_float_p, ctypes.c_double, ctypes.POINTER(ctypes.c_void_p)]
+    lib.nidreg_colorizer_update.argtypes = [ctypes.c_void_p, c_double_p, ctypes.c_double, c_float_p]
+    lib.nidreg_colorizer_device_colors.restype = ctypes.c_void_p
+    lib.nidreg_colorizer_device_colors.argtypes = [ctypes.c_void_p]
+    lib.nidreg_colorizer_destroy.restype = None
+    lib.nidreg_colorizer_destroy.argtypes = [ctypes.c_void_p]
+    lib.nidreg_generate_lidar_image.argtypes = [ctypes.c_int, c_double_p, c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_double_p, ctypes.c_int64, c_double_p,
+                                                ctypes.c_int64, c_double_p, c_double_p, ctypes.POINTER(ctypes.c_int32)]
+    lib.nidreg_equalize_intensities.argtypes = [ctypes.c_int, c_double_p, ctypes.c_int64]
     _lib = lib
     return lib
 

@@ -172,4 +172,55 @@ done:
   return e;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Intensity rank equalisation (src/vlcal/preprocess/preprocess.cpp:464-473, preprocess_map.cpp): sort the
+// indices by intensity, then intensity[indices[i]] = floor(256 * double(i) / n) / 256.  The reference's
+// std::sort is unstable, so the rank order inside a group of EQUAL intensities is unspecified there;
+// the radix sort is stable (ties keep index order), one of the orders the reference can produce.
+namespace {
+__global__ __launch_bounds__(256) void k_eq_keys(const double* __restrict__ v, long long n, unsigned long long* __restrict__ keys, unsigned int* __restrict__ idx) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v[i] + 0.0);  // -0 -> +0: they compare equal
+  keys[i] = (b >> 63) ? ~b : (b | 0x8000000000000000ull);                              // total order of the doubles
+  idx[i] = (unsigned int)i;
+}
+__global__ __launch_bounds__(256) void k_eq_scatter(const unsigned int* __restrict__ idx_sorted, long long n, double* __restrict__ v) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int bins = 256;
+  v[idx_sorted[i]] = floor(bins * double(i) / double(n)) / bins;
+}
+}  // namespace
+
+hipError_t equalize_intensities_device(double* d_intensities, long long n, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipError_t e = hipSuccess;
+  unsigned long long *d_keys = nullptr, *d_keys2 = nullptr;
+  unsigned int *d_idx = nullptr, *d_idx2 = nullptr;
+  void* d_tmp = nullptr;
+  size_t tmp_bytes = 0;
+  const unsigned grid = unsigned((n + 255) / 256);
+  BUILD_TRY(hipMalloc(&d_keys, size_t(n) * 8));
+  BUILD_TRY(hipMalloc(&d_keys2, size_t(n) * 8));
+  BUILD_TRY(hipMalloc(&d_idx, size_t(n) * 4));
+  BUILD_TRY(hipMalloc(&d_idx2, size_t(n) * 4));
+  hipLaunchKernelGGL(k_eq_keys, dim3(grid), dim3(256), 0, stream, d_intensities, n, d_keys, d_idx);
+  BUILD_TRY(hipGetLastError());
+  BUILD_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_keys, d_keys2, d_idx, d_idx2, size_t(n), 0, 64, stream));
+  BUILD_TRY(hipMalloc(&d_tmp, tmp_bytes));
+  BUILD_TRY(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_keys, d_keys2, d_idx, d_idx2, size_t(n), 0, 64, stream));
+  hipLaunchKernelGGL(k_eq_scatter, dim3(grid), dim3(256), 0, stream, d_idx2, n, d_intensities);
+  BUILD_TRY(hipGetLastError());
+  BUILD_TRY(hipStreamSynchronize(stream));
+done:
+  if (d_keys) (void)hipFree(d_keys);
+  if (d_keys2) (void)hipFree(d_keys2);
+  if (d_idx) (void)hipFree(d_idx);
+  if (d_idx2) (void)hipFree(d_idx2);
+  if (d_tmp) (void)hipFree(d_tmp);
+  return e;
+}
+
 }  // namespace nidreg

@@ -3,6 +3,7 @@
 // integer histogram is exactly reproducible.
 #include "nid_launch_impl.hpp"
 #include "nid_cull_kernels.hpp"
+#include "nid_render_kernels.hpp"
 
 namespace nidreg {
 
@@ -24,6 +25,50 @@ hipError_t launch_cull(int model, const double* intr, const double* dist, const 
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_cull_keep, dim3(grid), dim3(256), 0, stream, d_pts, stride_d, n, iso, depth, d_pix, d_zbuf, d_keep);
+  return hipGetLastError();
+}
+
+
+hipError_t launch_colorize(int model, const double* intr, const double* dist, const double* d_pts, long long stride_d, long long n, const double* T, const uint8_t* d_img, int W, int H,
+                           double min_nz, const float* d_icolor, double blend_weight, float* d_out, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  struct { int model; } a{model};
+  const CamParams<double> cam = make_cam<double>(intr, dist);
+  IsoParams<double> iso;
+  for (int k = 0; k < 12; k++) iso.m[k] = T[k];
+  // Eigen: Vector4f * double converts the scalar to float first (points_color_updater.cpp:57)
+  const float wf = float(blend_weight), omwf = float(1.0 - blend_weight);
+  const unsigned grid = unsigned((n + 255) / 256);
+#define NID_LAUNCH(M)                                                                                                                                                  \
+  hipLaunchKernelGGL((k_colorize<M>), dim3(grid), dim3(256), 0, stream, d_pts, stride_d, n, iso, cam, d_img, W, H, min_nz, reinterpret_cast<const float4*>(d_icolor), wf, omwf, \
+                     reinterpret_cast<float4*>(d_out))
+  NID_MODEL_SWITCH(NID_LAUNCH)
+#undef NID_LAUNCH
+  return hipGetLastError();
+}
+
+hipError_t launch_lidar_image(int model, const double* intr, const double* dist, const double* d_pts, long long stride_d, const double* d_intensities, long long n, const double* T, int W,
+                              int H, double min_nz, int* d_pix, u64* d_zmin, int* d_index_image, double* d_intensity_image, hipStream_t stream) {
+  struct { int model; } a{model};
+  const CamParams<double> cam = make_cam<double>(intr, dist);
+  IsoParams<double> iso;
+  for (int k = 0; k < 12; k++) iso.m[k] = T[k];
+  const long long npix = (long long)W * H;
+  hipError_t e = hipMemsetAsync(d_zmin, 0xff, size_t(npix) * sizeof(u64), stream);       // > every finite distance
+  if (e == hipSuccess) e = hipMemsetAsync(d_index_image, 0xff, size_t(npix) * sizeof(int), stream);  // -1
+  if (e != hipSuccess) return e;
+  if (n > 0) {
+    const unsigned grid = unsigned((n + 255) / 256);
+#define NID_LAUNCH(M) hipLaunchKernelGGL((k_lidar_zmin<M>), dim3(grid), dim3(256), 0, stream, d_pts, stride_d, n, iso, cam, W, H, min_nz, d_pix, d_zmin)
+    NID_MODEL_SWITCH(NID_LAUNCH)
+#undef NID_LAUNCH
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_lidar_argmax, dim3(grid), dim3(256), 0, stream, d_pts, stride_d, n, iso, d_pix, d_zmin, d_index_image);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(k_lidar_resolve, dim3(unsigned((npix + 255) / 256)), dim3(256), 0, stream, d_intensities, d_index_image, npix, d_intensity_image);
   return hipGetLastError();
 }
 

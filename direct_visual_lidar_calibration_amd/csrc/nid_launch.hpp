@@ -3,6 +3,7 @@
 // floating-point contraction rules (nid_kernels_f64.hip: -ffp-contract=off so +,-,*,/,sqrt match the
 // CPU bit for bit; nid_kernels_f32.hip: fused multiply-adds allowed).
 #pragma once
+#include <string>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -48,6 +49,19 @@ template <typename real> hipError_t launch_project(int model, const double* intr
 // ViewCulling::cull (nid_cull_kernels.hpp); all pointers are device memory
 hipError_t launch_cull(int model, const double* intr, const double* dist, const double* d_pts, long long stride_d, long long n, const double* T, int W, int H, double min_z,
                        int depth, int* d_pix, unsigned int* d_zbuf, unsigned char* d_keep, hipStream_t stream);
+
+// PointsColorUpdater::update / generate_lidar_image (nid_render_kernels.hpp); all pointers are device memory,
+// T = rows of the 4x4 T_camera_lidar
+hipError_t launch_colorize(int model, const double* intr, const double* dist, const double* d_pts, long long stride_d, long long n, const double* T, const uint8_t* d_img, int W, int H,
+                           double min_nz, const float* d_icolor, double blend_weight, float* d_out, hipStream_t stream);
+hipError_t launch_lidar_image(int model, const double* intr, const double* dist, const double* d_pts, long long stride_d, const double* d_intensities, long long n, const double* T, int W,
+                              int H, double min_nz, int* d_pix, u64* d_zmin, int* d_index_image, double* d_intensity_image, hipStream_t stream);
+
+// preprocess.cpp:464-473 rank equalisation in place on a device array (nid_build.hip; synchronises the stream)
+hipError_t equalize_intensities_device(double* d_intensities, long long n, hipStream_t stream);
+
+// error text of the calling thread (nidreg_last_error); returns `code`
+int fail(int code, const std::string& msg);
 
 // view-culling parameters for the device-side record build (all host values; T = rows of the 4x4)
 struct CullArgs {

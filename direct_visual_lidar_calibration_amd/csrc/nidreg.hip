@@ -26,11 +26,16 @@ using namespace nidreg;
 namespace {
 
 thread_local std::string g_last_error;
+}  // namespace
 
+namespace nidreg {
 int fail(int code, const std::string& msg) {
   g_last_error = msg;
   return code;
 }
+}  // namespace nidreg
+
+namespace {
 
 #define HIP_TRY(expr)                                                                                   \
   do {                                                                                                  \

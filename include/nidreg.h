@@ -18,6 +18,9 @@
  *                                                              (src/vlcal/calib/visual_camera_calibration.cpp:103-119)
  *   nidreg_project           GenericCameraBase::project        (include/camera/generic_camera_base.hpp:29)
  *   nidreg_view_culling      ViewCulling::cull                 (src/vlcal/calib/view_culling.cpp:21-92)
+ *   nidreg_colorizer_*       vlcal::PointsColorUpdater         (src/vlcal/common/points_color_updater.cpp:26-61)
+ *   nidreg_generate_lidar_image  vlcal::generate_lidar_image   (src/vlcal/preprocess/generate_lidar_image.cpp:7-41)
+ *   nidreg_equalize_intensities  the rank equalisation loop    (src/vlcal/preprocess/preprocess.cpp:464-473)
  *   nidreg_shard_*           (no reference counterpart) split-phase evaluation of one pair whose
  *                            points are sharded over several GPUs; the caller all-reduces the
  *                            fixed-point histogram (RCCL) between the phases.
@@ -170,6 +173,38 @@ int nidreg_project_model(int model_id, const double* intrinsics, const double* d
  * indices_out (capacity num_points) and returns their number, or a negative error code. */
 int64_t nidreg_view_culling(int model_id, const double* intrinsics, const double* distortion, int device_id, int width, int height, double min_z, int enable_depth_buffer_culling,
                             const double* points, int64_t point_stride, int64_t num_points, const double* T_camera_lidar, int32_t* indices_out);
+
+/* PointsColorUpdater (src/vlcal/common/points_color_updater.cpp): the per-frame recolouring of the
+ * whole cloud the viewer runs every 50 ms while the optimiser works (visual_lidar_visualizer.cpp:89-100).
+ * create = the constructor (:26-35): uploads the 8-bit image, the points ((x y z 1) doubles, byte
+ * stride >= 32) and the per-point intensity colours (n x RGBA float; the reference fills them with
+ * glk::colormapf(TURBO, intensity), a table that lives in Iridescence, so the caller passes them;
+ * NULL = (1,1,1,1) like the icosahedron constructor, :24).  min_nz = cos(estimate_camera_fov + 0.5 deg) (:12).
+ * update = PointsColorUpdater::update (:37-61): colours[i] = (pix/255, pix/255, pix/255, 1) * float(w)
+ * + intensity_colors[i] * float(1 - w) in float arithmetic, or (0,0,0,0) when the point is outside the
+ * FoV / image.  colors_out: host n x 4 floats, or NULL to leave the result on the device
+ * (nidreg_colorizer_device_colors; valid until the next update / destroy). */
+typedef struct nidreg_colorizer nidreg_colorizer;
+int nidreg_colorizer_create(int device_id, int model_id, const double* intrinsics, const double* distortion, int width, int height, const uint8_t* image, int64_t image_row_stride,
+                            int64_t num_points, const double* points, int64_t point_stride, const float* intensity_colors, double min_nz, nidreg_colorizer** out);
+int nidreg_colorizer_update(nidreg_colorizer* c, const double* T_camera_lidar, double blend_weight, float* colors_out);
+const float* nidreg_colorizer_device_colors(nidreg_colorizer* c);
+void nidreg_colorizer_destroy(nidreg_colorizer* c);
+
+/* generate_lidar_image (src/vlcal/preprocess/generate_lidar_image.cpp:7-41): z-buffered rendering of
+ * the cloud through the camera model.  min_nz = cos(estimate_camera_fov) (:10-11).  Per pixel the point
+ * with the smallest squared camera-frame distance wins; on exact ties the largest index (the sequential
+ * reference overwrites on `!(stored < sq_dist)`, :31).  intensity_image: height x width doubles (0 where
+ * nothing landed), index_image: height x width int32 (-1 where nothing landed); either may be NULL.
+ * Output is identical to the CPU loop's for any thread order. */
+int nidreg_generate_lidar_image(int model_id, const double* intrinsics, const double* distortion, int device_id, int width, int height, double min_nz, const double* points,
+                                int64_t point_stride, const double* intensities, int64_t num_points, const double* T_camera_lidar, double* intensity_image, int32_t* index_image);
+
+/* Intensity rank equalisation of an integrated cloud (src/vlcal/preprocess/preprocess.cpp:464-473,
+ * src/preprocess_map.cpp): in place, intensities[rank order i] = floor(256 * i / n) / 256, the values the
+ * NID path then bins.  Device radix sort; stable, i.e. equal intensities keep their index order (the
+ * reference's std::sort leaves that order unspecified). */
+int nidreg_equalize_intensities(int device_id, double* intensities, int64_t num_points);
 
 /* ---- split-phase evaluation for a pair whose points are sharded across GPUs --------------
  * rank r:  nidreg_shard_hist(h, se3)      zero + accumulate this shard's fixed-point histogram

@@ -8,6 +8,9 @@
 //   src/vlcal/calib/view_culling.cpp:13-92                  -> view_culling_ref()
 //   src/vlcal/common/estimate_fov.cpp:17-51                 -> estimate_camera_fov_ref()
 //   include/dfo/nelder_mead.hpp:11-113                      -> nelder_mead_ref()
+//   src/vlcal/common/points_color_updater.cpp:37-61         -> points_color_update_ref()
+//   src/vlcal/preprocess/generate_lidar_image.cpp:7-41      -> generate_lidar_image_ref()
+//   src/vlcal/preprocess/preprocess.cpp:464-473             -> equalize_intensities_ref()
 // Third-party arithmetic restated from published definitions (sources absent from
 // /root/reference): ceres::Jet (jet.hpp), Sophus SO3/SE3 `operator*(point)`
 // (uv = 2 q.vec x p; p' = p + q.w uv + q.vec x uv + t, no quaternion normalisation),
@@ -465,6 +468,68 @@ static std::vector<int> view_culling_ref(
   return indices;
 }
 
+// points_color_updater.cpp:37-61.  intensity_colors / colors_out: n x 4 floats (Eigen::Vector4f).
+// `color * blend_weight`: Eigen converts the double scalar to the expression's float scalar first.
+static void points_color_update_ref(
+  const CameraBase* proj, const uint8_t* image, int rows, int cols, const double* points, int64_t num_points, const float* intensity_colors, double min_nz, const double* T_camera_lidar,
+  double blend_weight, float* colors_out) {
+  const float wf = static_cast<float>(blend_weight);
+  const float omwf = static_cast<float>(1.0 - blend_weight);
+  for (int64_t i = 0; i < num_points; i++) {
+    float* out = colors_out + 4 * i;
+    out[0] = out[1] = out[2] = out[3] = 0.0f;  // Vector4f::Zero() for skipped points
+    double pc[4];
+    iso_mul_point4(T_camera_lidar, points + 4 * i, pc);
+    const V3<double> p3{pc[0], pc[1], pc[2]};
+    if (normalized(p3).z < min_nz) continue;  // out of FoV
+    const V2<double> uv = proj->project(p3);
+    const int px = cast_int(uv.x), py = cast_int(uv.y);
+    if (px < 0 || py < 0 || px >= cols || py >= rows) continue;  // out of image
+    const unsigned char pix = image[static_cast<int64_t>(py) * cols + px];
+    const float color[4] = {pix / 255.0f, pix / 255.0f, pix / 255.0f, 1.0f};
+    const float* ic = intensity_colors + 4 * i;
+    for (int k = 0; k < 4; k++) out[k] = color[k] * wf + ic[k] * omwf;
+  }
+}
+
+// generate_lidar_image.cpp:7-41.  intensity_image: rows x cols doubles, index_image: rows x cols int32.
+static void generate_lidar_image_ref(
+  const CameraBase* proj, int width, int height, double min_z, const double* points, const double* intensities, int64_t num_points, const double* T_camera_lidar, double* intensity_image,
+  int32_t* index_image) {
+  const size_t npix = static_cast<size_t>(width) * height;
+  std::vector<double> sq_dist_image(npix, std::numeric_limits<double>::max());
+  std::fill(intensity_image, intensity_image + npix, 0.0);
+  std::fill(index_image, index_image + npix, -1);
+  for (int64_t i = 0; i < num_points; i++) {
+    double pc[4];
+    iso_mul_point4(T_camera_lidar, points + 4 * i, pc);
+    const V3<double> p3{pc[0], pc[1], pc[2]};
+    if (normalized(p3).z < min_z) continue;
+    const V2<double> uv = proj->project(p3);
+    const int px = cast_int(uv.x), py = cast_int(uv.y);
+    if (px < 0 || py < 0 || px >= width || py >= height) continue;
+    const double sq_dist = pc[0] * pc[0] + pc[1] * pc[1] + pc[2] * pc[2];
+    const size_t q = static_cast<size_t>(py) * width + px;
+    if (sq_dist_image[q] < sq_dist) continue;
+    sq_dist_image[q] = sq_dist;
+    intensity_image[q] = intensities[i];
+    index_image[q] = static_cast<int32_t>(i);
+  }
+}
+
+// preprocess.cpp:464-473: rank equalisation of the integrated cloud's intensities into 256 levels.
+// std::sort is not stable; among EQUAL intensities the rank order is unspecified in the reference, so
+// only the multiset of values per tie group is defined -- the restatement uses a stable sort.
+static void equalize_intensities_ref(double* intensities, int64_t n) {
+  std::vector<int> indices(n);
+  std::iota(indices.begin(), indices.end(), 0);
+  std::stable_sort(indices.begin(), indices.end(), [&](const int lhs, const int rhs) { return intensities[lhs] < intensities[rhs]; });
+  const int bins = 256;
+  std::vector<double> out(n);
+  for (int64_t i = 0; i < n; i++) out[indices[i]] = std::floor(bins * static_cast<double>(i) / n) / bins;
+  std::copy(out.begin(), out.end(), intensities);
+}
+
 // visual_camera_calibration.cpp:149-156 -- MultiNIDCost trust gate.
 // delta = init^-1 * T ; reject if |delta.t| > 0.2 or angle(delta.R) > 2 deg.
 static void quat_to_rot(const double* q, double* R) {  // q = [x y z w], unit
@@ -646,6 +711,31 @@ int64_t oracle_view_culling(
   std::copy(idx.begin(), idx.end(), indices_out);
   return static_cast<int64_t>(idx.size());
 }
+
+// PointsColorUpdater::update; min_nz as the constructor computes it: cos(estimate_camera_fov + 0.5 deg)
+int oracle_points_color_update(
+  const char* model, const double* intr, int n_intr, const double* dist, int n_dist, const uint8_t* image, int rows, int cols, const double* points, int64_t num_points,
+  const float* intensity_colors, const double* T, double blend_weight, float* colors_out, double* min_nz_out) {
+  auto cam = oracle::make_camera(model, intr, n_intr, dist, n_dist);
+  if (!cam) return -1;
+  const double min_nz = std::cos(oracle::estimate_camera_fov_ref(cam.get(), cols, rows) + 0.5 * M_PI / 180.0);
+  if (min_nz_out) *min_nz_out = min_nz;
+  oracle::points_color_update_ref(cam.get(), image, rows, cols, points, num_points, intensity_colors, min_nz, T, blend_weight, colors_out);
+  return 0;
+}
+
+// generate_lidar_image
+int oracle_generate_lidar_image(
+  const char* model, const double* intr, int n_intr, const double* dist, int n_dist, int width, int height, const double* points, const double* intensities, int64_t num_points,
+  const double* T, double* intensity_image, int32_t* index_image) {
+  auto cam = oracle::make_camera(model, intr, n_intr, dist, n_dist);
+  if (!cam) return -1;
+  const double min_z = std::cos(oracle::estimate_camera_fov_ref(cam.get(), width, height));
+  oracle::generate_lidar_image_ref(cam.get(), width, height, min_z, points, intensities, num_points, T, intensity_image, index_image);
+  return 0;
+}
+
+void oracle_equalize_intensities(double* intensities, int64_t n) { oracle::equalize_intensities_ref(intensities, n); }
 
 // Nelder-Mead with a C callback (used by the parity driver in tests).
 typedef double (*oracle_nm_fn)(const double* x, void* user);

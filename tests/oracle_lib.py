@@ -35,6 +35,7 @@ def lib():
         build()
         _lib = ctypes.CDLL(_LIB_PATH)
         _lib.oracle_view_culling.restype = ctypes.c_int64
+        _lib.oracle_equalize_intensities.restype = None
     return _lib
 
 
@@ -168,6 +169,47 @@ def view_culling(model, intrinsics, distortion, width, height, points, T, enable
     if n < 0:
         raise ValueError("oracle: bad camera model")
     return idx[:n].copy()
+
+
+def points_color_update(model, intrinsics, distortion, image_u8, points, intensity_colors, T, blend_weight):
+    """PointsColorUpdater::update restatement.  Returns (colors n x 4 float32, min_nz)."""
+    image_u8 = np.ascontiguousarray(image_u8, dtype=np.uint8)
+    points = np.ascontiguousarray(points, dtype=np.float64)
+    T = np.ascontiguousarray(T, dtype=np.float64).reshape(4, 4)
+    ic = np.ascontiguousarray(intensity_colors, dtype=np.float32).reshape(-1, 4)
+    out = np.empty((points.shape[0], 4), dtype=np.float32)
+    min_nz = ctypes.c_double(0.0)
+    m, ip, ni, dp, nd, keep = _cam_args(model, intrinsics, distortion)
+    rc = lib().oracle_points_color_update(
+        m, ip, ni, dp, nd, image_u8.ctypes.data_as(c_uint8_p), ctypes.c_int(image_u8.shape[0]), ctypes.c_int(image_u8.shape[1]), _dp(points), ctypes.c_int64(points.shape[0]),
+        ic.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), _dp(T), ctypes.c_double(blend_weight), out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), ctypes.byref(min_nz),
+    )
+    if rc != 0:
+        raise ValueError("oracle: bad camera model")
+    return out, min_nz.value
+
+
+def generate_lidar_image(model, intrinsics, distortion, width, height, points, intensities, T):
+    """generate_lidar_image restatement.  Returns (intensity_image H x W float64, index_image H x W int32)."""
+    points = np.ascontiguousarray(points, dtype=np.float64)
+    intensities = np.ascontiguousarray(intensities, dtype=np.float64)
+    T = np.ascontiguousarray(T, dtype=np.float64).reshape(4, 4)
+    iimg = np.empty((height, width), dtype=np.float64)
+    idx = np.empty((height, width), dtype=np.int32)
+    m, ip, ni, dp, nd, keep = _cam_args(model, intrinsics, distortion)
+    rc = lib().oracle_generate_lidar_image(
+        m, ip, ni, dp, nd, ctypes.c_int(width), ctypes.c_int(height), _dp(points), _dp(intensities), ctypes.c_int64(points.shape[0]), _dp(T), _dp(iimg), idx.ctypes.data_as(c_int_p),
+    )
+    if rc != 0:
+        raise ValueError("oracle: bad camera model")
+    return iimg, idx
+
+
+def equalize_intensities(intensities):
+    """preprocess.cpp:464-473 rank equalisation (stable order among ties)."""
+    a = np.array(intensities, dtype=np.float64, copy=True)
+    lib().oracle_equalize_intensities(_dp(a), ctypes.c_int64(a.shape[0]))
+    return a
 
 
 _NM_FN = ctypes.CFUNCTYPE(ctypes.c_double, c_double_p, ctypes.c_void_p)
