@@ -54,6 +54,20 @@ def pmc_traffic(kernel, n_points, width, height, bins, precision):
     return best
 
 
+def baseline_config_label(args):
+    """Which BASELINE.json config the chosen workload is (the default run is configs[1])."""
+    key = (args.points, args.camera, args.bins)
+    table = {
+        (100000, "pinhole_vga", 16): "BASELINE configs[0] on the GPU",
+        (10000000, "pinhole_1080p", 256): "BASELINE configs[1]",
+        (10000000, "equirect_2k", 256): "BASELINE configs[2], un-sharded" if args.mode == "pairs" else "BASELINE configs[2]",
+        (10000000, "omnidir_2k", 256): "BASELINE configs[2] omnidir variant, un-sharded" if args.mode == "pairs" else "BASELINE configs[2] omnidir variant",
+        (5000000, "fisheye_1080p", 256): "BASELINE configs[3], one pair per GPU",
+        (50000000, "pinhole_4k", 256): "BASELINE configs[4]",
+    }
+    return table.get(key, "custom workload")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -272,7 +286,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{'1 pair per GPU' if args.mode == 'pairs' else '1 pair point-sharded'}, {args.points}-pt Ouster-style cloud + "
-                f"{scene.width}x{scene.height} {scene.model}, {args.bins}x{args.bins} NID bins, cost+Jacobian (BASELINE configs[1])",
+                f"{scene.width}x{scene.height} {scene.model}, {args.bins}x{args.bins} NID bins, cost+Jacobian ({baseline_config_label(args)})",
                 "points": args.points,
                 "image": [scene.width, scene.height],
                 "bins": args.bins,
