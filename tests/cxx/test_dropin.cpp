@@ -6,8 +6,12 @@
 #include <cstdlib>
 #include <vector>
 
+#include <cmath>
+
 #include "vlcal_amd/cost_calculator_nid.hpp"
+#include "vlcal_amd/generate_lidar_image.hpp"
 #include "vlcal_amd/nid_cost.hpp"
+#include "vlcal_amd/points_color_updater.hpp"
 
 struct MultiNIDCost {  // visual_camera_calibration.cpp:141-178 without the trust gate / OpenMP
   std::vector<std::shared_ptr<vlcal::NIDCost>> costs;
@@ -79,8 +83,31 @@ int main(int argc, char** argv) {
   for (int k = 0; k < 16; k++) Tm.m[k] = T[k];
   const double cn = calc.calculate(Tm);
 
+  // PointsColorUpdater::update and generate_lidar_image through their drop-in headers (checksums)
+  vlcal::PointsColorUpdater updater(proj, img8, frame, nullptr, std::cos(max_fov + 0.5 * M_PI / 180.0));
+  const std::vector<float>& colors = updater.update(Tm, 0.7);
+  double color_sum = 0.0;
+  long n_colored = 0;
+  for (int i = 0; i < N; i++) {
+    for (int k = 0; k < 4; k++) color_sum += colors[size_t(i) * 4 + k];
+    n_colored += colors[size_t(i) * 4 + 3] > 0.0f ? 1 : 0;
+  }
+  std::vector<double> lidar_intensity(size_t(W) * H);
+  std::vector<int32_t> lidar_index(size_t(W) * H);
+  vlcal::generate_lidar_image(proj, W, H, Tm, frame, std::cos(max_fov), lidar_intensity.data(), lidar_index.data());
+  long idx_count = 0;
+  double idx_sum = 0.0, inten_sum = 0.0;
+  for (size_t q = 0; q < lidar_index.size(); q++) {
+    if (lidar_index[q] >= 0) {
+      idx_count++;
+      idx_sum += lidar_index[q];
+    }
+    inten_sum += lidar_intensity[q];
+  }
+
   printf("%.17g", res.a);
   for (int k = 0; k < 7; k++) printf(" %.17g", res.v[k]);
-  printf(" %.17g %.17g\n", c2, cn);
+  printf(" %.17g %.17g", c2, cn);
+  printf(" %.17g %ld %ld %.17g %.17g\n", color_sum, n_colored, idx_count, idx_sum, inten_sum);
   return 0;
 }

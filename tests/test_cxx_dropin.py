@@ -59,3 +59,12 @@ def test_dropin_matches_oracle(tmp_path):
         assert np.allclose(vals[1:8], ref["grad"], rtol=1e-7, atol=1e-10)
         cn, _ = oracle_lib.cost_calculator_nid(s.model, s.intrinsics, s.distortion, s.image_u8, s.points, s.intensities, bins, max_fov, T)
         assert abs(vals[9] - cn) <= 1e-12
+        # PointsColorUpdater / generate_lidar_image drop-in headers: checksums against the oracle
+        ones = np.ones((s.points.shape[0], 4), dtype=np.float32)
+        col, _ = oracle_lib.points_color_update(s.model, s.intrinsics, s.distortion, s.image_u8, s.points, ones, T, 0.7)
+        assert abs(vals[10] - float(col.astype(np.float64).sum())) <= 1e-6 * max(1.0, abs(vals[10]))
+        assert int(vals[11]) == int((col[:, 3] > 0).sum())
+        li, lidx = oracle_lib.generate_lidar_image(s.model, s.intrinsics, s.distortion, s.width, s.height, s.points, s.intensities, T)
+        assert int(vals[12]) == int((lidx >= 0).sum()) and int(vals[12]) > 0
+        assert vals[13] == float(lidx[lidx >= 0].astype(np.float64).sum())
+        assert abs(vals[14] - float(li.sum())) <= 1e-9 * max(1.0, abs(vals[14]))
