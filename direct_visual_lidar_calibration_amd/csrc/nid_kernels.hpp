@@ -129,8 +129,18 @@ __device__ __forceinline__ void grad_final_body(const double* partials, int nblo
 // ------------------------------------------------------------------------------------------
 // pass A (SPLINE): joint histogram with bicubic B-spline soft assignment.
 // LDS: tile[GW*B << cshift] u64 (this workgroup's GW histogram columns, 2^cshift copies) + 1 u32 inlier counter.
-template <int MODEL, typename Rec, typename real>
-__global__ __launch_bounds__(kThreads) void k_spline_hist(
+//
+// WIDE = the B = 256 / GW = 1 specialisation (the headline configuration): 512 threads share one
+// histogram column with 32 lane-private copies, so a cell lives at LDS byte address
+// (bin_image << 8) | (copy << 3) and ONE v_perm_b32 builds it from the packed bin-image word (the
+// generic path needs a byte extract + shift and an add per tap); the tile then spans 64 KB, hence
+// the 8-wave workgroup (2 workgroups = 16 waves per CU, the same wave occupancy as 4 x 4 waves).
+// The tile must start at LDS address 0: this kernel has no static LDS, so the dynamic segment does.
+// Measured on cfg 2: 74.3 -> 71.5 us.
+constexpr int kWideThreads = 512;
+constexpr int kWideShift = 5;
+template <int MODEL, typename Rec, typename real, bool WIDE>
+__global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_spline_hist(
   const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint8_t* __restrict__ img, int pitch, int W, int H, PoseParams<real> pose, CamParams<real> cam, int B,
   int GW, int cshift, double dn_scale, u64* __restrict__ hist) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -145,9 +155,10 @@ __global__ __launch_bounds__(kThreads) void k_spline_hist(
   u64* s_colsum = tile + tile_w;  // GW words: this workgroup's contribution to each column sum
   unsigned int* s_inl = reinterpret_cast<unsigned int*>(s_colsum + GW);
 
+  constexpr int kT = WIDE ? kWideThreads : kThreads;
   const int tid = threadIdx.x;
   const Chunk ch = chunks[blockIdx.x];
-  for (int k = tid; k < tile_w; k += kThreads) tile[k] = 0;
+  for (int k = tid; k < tile_w; k += kT) tile[k] = 0;
   if (tid == 0) *s_inl = 0;
   if (tid < GW) s_colsum[tid] = 0;
   __syncthreads();
@@ -161,17 +172,17 @@ __global__ __launch_bounds__(kThreads) void k_spline_hist(
   // parallelism), and the per-point body is branch-free: an outlier (or a slot past the end of the
   // chunk) runs the same instructions with its knot clamped into the image and its x-weights zeroed,
   // so it adds exact zeros.  That lets the scheduler interleave the kUnroll independent points.
-  for (uint32_t base = 0; base < ch.count; base += kThreads * kUnroll) {
+  for (uint32_t base = 0; base < ch.count; base += kT * kUnroll) {
     real xs[kUnroll], ys[kUnroll], zs[kUnroll];
     uint32_t bins_[kUnroll];
 #pragma unroll
     for (int k = 0; k < kUnroll; k++) {
-      const uint32_t ii = min(base + uint32_t(k) * kThreads + tid, ch.count - 1u);
+      const uint32_t ii = min(base + uint32_t(k) * kT + tid, ch.count - 1u);
       load_rec<real>(pts + ch.start + ii, xs[k], ys[k], zs[k], bins_[k]);
     }
 #pragma unroll
     for (int k = 0; k < kUnroll; k++) {
-      const bool valid = base + uint32_t(k) * kThreads + tid < ch.count;
+      const bool valid = base + uint32_t(k) * kT + tid < ch.count;
       real cx, cy, cz;
       transform_fma<real>(pose, xs[k], ys[k], zs[k], cx, cy, cz);
       real u, v;
@@ -199,8 +210,14 @@ __global__ __launch_bounds__(kThreads) void k_spline_hist(
       for (int b = 0; b < 4; b++) {
 #pragma unroll
         for (int a = 0; a < 4; a++) {
-          const uint32_t r = (cols[a] >> (8 * b)) & 0xffu;
-          atomicAdd(&col[r << cshift], to_fixed_dn(bxs[a], double(by[b])));  // v_mul_f64 + ds_add_u64
+          if (WIDE) {
+            typedef __attribute__((address_space(3))) u64 lds_u64_t;
+            const uint32_t addr = __builtin_amdgcn_perm(cols[a], lane_copy << 3, 0x0c0c0000u | (uint32_t(4 + b) << 8));  // [0, 0, byte b of cols[a], copy * 8]
+            __hip_atomic_fetch_add((lds_u64_t*)(uintptr_t)addr, to_fixed_dn(bxs[a], double(by[b])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          } else {
+            const uint32_t r = (cols[a] >> (8 * b)) & 0xffu;
+            atomicAdd(&col[r << cshift], to_fixed_dn(bxs[a], double(by[b])));  // v_mul_f64 + ds_add_u64
+          }
         }
       }
     }
@@ -215,7 +232,7 @@ __global__ __launch_bounds__(kThreads) void k_spline_hist(
 
   // flush the tile: contiguous in the [bin_points][bin_image] device layout
   u64* dst = hist + size_t(ch.group) * size_t(tile_n);
-  for (int k = tid; k < tile_n; k += kThreads) {
+  for (int k = tid; k < tile_n; k += kT) {
     u64 vv = 0;
     for (uint32_t j = 0; j <= cmask; j++) vv += tile[(uint32_t(k) << cshift) + ((j + uint32_t(k)) & cmask)];  // rotated: conflict-free reads
     if (vv) {
@@ -432,7 +449,13 @@ __global__ __launch_bounds__(kThreads) void k_entropy(
 // Per point: (gx, gy) = sum_taps G * d(w_tap)/d(u, v); gp = (gx gy) * d(uv)/d(p_cam) (Dual3
 // projection); accumulate M += gp p^T (3x3) and gt += gp (3).  One 12-double partial per workgroup.
 // LDS: gtile[GW*B] doubles + kWaves*12 doubles.
-template <int MODEL, typename Rec, typename real>
+//
+// GW1 = the single-column specialisation (GW = 1, i.e. B > 128): every point of the workgroup reads the
+// same column of G, so the table needs no per-point column offset, and -- reads of one address
+// broadcast, unlike atomics -- no lane-private copies either: the tap's LDS byte address is just
+// bin_image << 3, ONE v_lshlrev_b32_sdwa instead of extract + shift + add (gtile sits at LDS
+// address 0: no static LDS in this kernel).  Measured on cfg 2: 103.4 -> 99.5 us.
+template <int MODEL, typename Rec, typename real, bool GW1>
 __global__ __launch_bounds__(kThreads) void k_spline_grad(
   const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint8_t* __restrict__ img, int pitch, int W, int H, PoseParams<real> pose, CamParams<real> cam, int B,
   int GW, int cshift, double inv_unit, const u64* __restrict__ hist, const double* __restrict__ phi_q, const EntropyScalars* __restrict__ scal, double* partials, double qx,
@@ -440,6 +463,7 @@ __global__ __launch_bounds__(kThreads) void k_spline_grad(
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* gtile = reinterpret_cast<double*>(smem);
   const int tile_n = GW * B;
+  if (GW1) cshift = 0;
   const uint32_t cmask = (1u << cshift) - 1u;  // G is replicated like the histogram tile: lane-private copies, conflict-free ds_read_b64
   double* s_red = gtile + (tile_n << cshift);
   int* s_flag = reinterpret_cast<int*>(s_red + kWaves * 12);
@@ -493,6 +517,7 @@ __global__ __launch_bounds__(kThreads) void k_spline_grad(
         bspline<real>(vv - fv, by);
         bspline_deriv<real>(uu - fu, dbx);
         bspline_deriv<real>(vv - fv, dby);
+        typedef __attribute__((address_space(3))) const double lds_f64_t;
         const double* gcol = gtile + ((((bins_[k] - col0) * uint32_t(B)) << cshift) + lane_copy);
         uint32_t cols[4];
         load_patch(img, pitch, kx, ky, cols);
@@ -502,7 +527,8 @@ __global__ __launch_bounds__(kThreads) void k_spline_grad(
           real sa = real(0), sb = real(0);
 #pragma unroll
           for (int a = 0; a < 4; a++) {
-            const real g = real(gcol[((cols[a] >> (8 * b)) & 0xffu) << cshift]);
+            const uint32_t r = (cols[a] >> (8 * b)) & 0xffu;
+            const real g = GW1 ? real(*(lds_f64_t*)(uintptr_t)(r << 3)) : real(gcol[r << cshift]);
             sa = fma(g, dbx[a], sa);
             sb = fma(g, bx[a], sb);
           }

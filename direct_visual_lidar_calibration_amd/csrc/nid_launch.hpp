@@ -22,6 +22,7 @@ struct PassArgs {
   int nchunks;
   const uint8_t* img;  // padded, edge-replicated bin image
   int pitch, W, H, B, GW, cshift;
+  int wide;  // SPLINE histogram pass: the 512-thread / 32-copy single-column specialisation (B = 256, GW = 1)
   double R[9], t[3];  // SPLINE pose
   double iso[12];     // NEAREST pose (rows 0..2 of the 4x4)
   double intr[5], dist[8];

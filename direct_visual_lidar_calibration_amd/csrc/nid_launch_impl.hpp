@@ -47,16 +47,24 @@ template <typename real, typename Rec>
 static hipError_t launch_spline_hist_rec(const PassArgs& a) {
   const PoseParams<real> pose = make_pose<real>(a);
   const CamParams<real> cam = make_cam<real>(a.intr, a.dist);
-#define NID_LAUNCH(M)                                                                                                                                  \
+#define NID_LAUNCH_W(M, WIDE, THREADS)                                                                                                                 \
   {                                                                                                                                                    \
-    auto k = k_spline_hist<M, Rec, real>;                                                                                                              \
+    auto k = k_spline_hist<M, Rec, real, WIDE>;                                                                                                        \
     hipError_t e = ensure_lds(k, a.lds_hist);                                                                                                          \
     if (e != hipSuccess) return e;                                                                                                                     \
-    hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(kThreads), a.lds_hist, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, pose, cam, \
-                       a.B, a.GW, a.cshift, a.magic, a.hist);                                                                                                    \
+    hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(THREADS), a.lds_hist, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, pose, cam, \
+                       a.B, a.GW, a.cshift, a.magic, a.hist);                                                                                                   \
   }
-  NID_MODEL_SWITCH(NID_LAUNCH)
+  if (a.wide) {  // B = 256, GW = 1, 32 copies, 512 threads (see k_spline_hist)
+#define NID_LAUNCH(M) NID_LAUNCH_W(M, true, kWideThreads)
+    NID_MODEL_SWITCH(NID_LAUNCH)
 #undef NID_LAUNCH
+  } else {
+#define NID_LAUNCH(M) NID_LAUNCH_W(M, false, kThreads)
+    NID_MODEL_SWITCH(NID_LAUNCH)
+#undef NID_LAUNCH
+  }
+#undef NID_LAUNCH_W
   return hipGetLastError();
 }
 
@@ -64,16 +72,24 @@ template <typename real, typename Rec>
 static hipError_t launch_spline_grad_rec(const PassArgs& a) {
   const PoseParams<real> pose = make_pose<real>(a);
   const CamParams<real> cam = make_cam<real>(a.intr, a.dist);
-#define NID_LAUNCH(M)                                                                                                                                  \
+#define NID_LAUNCH_G(M, GW1)                                                                                                                           \
   {                                                                                                                                                    \
-    auto k = k_spline_grad<M, Rec, real>;                                                                                                              \
+    auto k = k_spline_grad<M, Rec, real, GW1>;                                                                                                         \
     hipError_t e = ensure_lds(k, a.lds_grad);                                                                                                          \
     if (e != hipSuccess) return e;                                                                                                                     \
     hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(kThreads), a.lds_grad, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, pose, cam, \
-                       a.B, a.GW, a.cshift, a.inv_unit, a.hist, a.phi_q, a.scal, a.partials, a.q[0], a.q[1], a.q[2], a.q[3], a.out, a.out_host, a.tag, a.counter);                                                                    \
+                       a.B, a.GW, a.cshift, a.inv_unit, a.hist, a.phi_q, a.scal, a.partials, a.q[0], a.q[1], a.q[2], a.q[3], a.out, a.out_host, a.tag, a.counter); \
   }
-  NID_MODEL_SWITCH(NID_LAUNCH)
+  if (a.GW == 1) {
+#define NID_LAUNCH(M) NID_LAUNCH_G(M, true)
+    NID_MODEL_SWITCH(NID_LAUNCH)
 #undef NID_LAUNCH
+  } else {
+#define NID_LAUNCH(M) NID_LAUNCH_G(M, false)
+    NID_MODEL_SWITCH(NID_LAUNCH)
+#undef NID_LAUNCH
+  }
+#undef NID_LAUNCH_G
   return hipGetLastError();
 }
 

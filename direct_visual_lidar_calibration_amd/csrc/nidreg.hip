@@ -60,11 +60,13 @@ struct nidreg_handle {
   int model = 0, mode = 0, precision = 0, bins = 0;
   int W = 0, H = 0, pitch = 0;
   int GW = 0, NG = 0, cshift = 0;
+  int wide = 0;  // k_spline_hist<.., WIDE>: B = 256, GW = 1, 32 copies, 512 threads
   int NEB = 0;  // entropy column blocks
   int frac_bits = 0;
   int rec64 = 0;
   int64_t num_points = 0;
-  int nchunks = 0;
+  int nchunks = 0;       // gradient pass / generic histogram kernels
+  int nchunks_hist = 0;  // WIDE histogram kernel's own table (0 = shares d_chunks)
   double intr[5] = {0}, dist[8] = {0};
   double max_fov = 0.0;
 
@@ -72,6 +74,7 @@ struct nidreg_handle {
   bool own_stream = false;
   void* d_pts = nullptr;
   Chunk* d_chunks = nullptr;
+  Chunk* d_chunks_hist = nullptr;
   uint8_t* d_img = nullptr;
   u64* d_hist = nullptr;
   bool own_hist = false;
@@ -108,6 +111,7 @@ void free_handle(nidreg_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->d_pts) (void)hipFree(h->d_pts);
   if (h->d_chunks) (void)hipFree(h->d_chunks);
+  if (h->d_chunks_hist) (void)hipFree(h->d_chunks_hist);
   if (h->d_img) (void)hipFree(h->d_img);
   if (h->own_hist && h->d_hist) (void)hipFree(h->d_hist);
   if (h->own_out && h->d_out) (void)hipFree(h->d_out);
@@ -140,6 +144,7 @@ void fill_pass_args(const nidreg_handle* h, PassArgs& a) {
   a.B = h->bins;
   a.GW = h->GW;
   a.cshift = h->cshift;
+  a.wide = h->wide;
   std::memcpy(a.intr, h->intr, sizeof(a.intr));
   std::memcpy(a.dist, h->dist, sizeof(a.dist));
   a.magic = std::ldexp(1.0, h->frac_bits - 1074);  // subnormal pre-scale of the x-weights (to_fixed_dn)
@@ -179,6 +184,10 @@ void pose_from_se3(const double* se3, double* R, double* t) {
 int launch_hist_spline(nidreg_handle* h, const double* se3) {
   PassArgs a;
   fill_pass_args(h, a);
+  if (h->d_chunks_hist) {
+    a.chunks = h->d_chunks_hist;
+    a.nchunks = h->nchunks_hist;
+  }
   pose_from_se3(se3, a.R, a.t);
   for (int k = 0; k < 4; k++) h->last_q[k] = se3[k];
   std::memcpy(h->last_R, a.R, sizeof(a.R));
@@ -430,12 +439,18 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
   while ((2 << cshift) <= copies && cshift < 4) cshift++;
   while (size_t(GW) * B * 8 > 128 * 1024 && GW > 1) GW /= 2;
   while ((size_t(GW) * B * 8 << cshift) > 64 * 1024 && cshift > 0) cshift--;
+  // the headline shape (256 bins, one column per workgroup, default tuning) takes the WIDE histogram
+  // kernel: 512 threads, 32 copies, one-instruction tap address (k_spline_hist); an explicit
+  // lds_copies keeps the generic kernel (tests compare the two bit for bit)
+  h->wide = (d->mode == NIDREG_MODE_SPLINE && B == 256 && GW == 1 && d->lds_copies == 0) ? 1 : 0;
+  if (h->wide) cshift = kWideShift;
   h->GW = GW;
   h->cshift = cshift;
   h->NG = (B + GW - 1) / GW;
   h->NEB = (B + kEntropyCols - 1) / kEntropyCols;
   h->lds_hist = (size_t(GW) * B * 8 << cshift) + size_t(GW) * 8 + 16;
-  h->lds_grad = (size_t(GW) * B * 8 << cshift) + size_t(kWaves) * 12 * 8 + 16;
+  // gradient pass: a single-column workgroup (GW = 1) keeps ONE copy of its G column (k_spline_grad<.., GW1>)
+  h->lds_grad = (GW == 1 ? size_t(B) * 8 : (size_t(GW) * B * 8 << cshift)) + size_t(kWaves) * 12 * 8 + 16;
   h->lds_entropy = size_t(B) * 8 + size_t(GW) * 8 + size_t(kWaves) * 8;
 
   // ---- fixed point: sum over a bin <= N * 2^frac must stay below 2^63
@@ -619,25 +634,44 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
     }
   }
 
-  // ---- chunk table: each chunk = one workgroup, points of one column group only
+  // ---- chunk tables: each chunk = one workgroup, points of one column group only.  By default a pass
+  // gets ONE round of co-resident workgroups (measured on cfg 2: the per-workgroup prologue / flush is
+  // amortised over more points and no partial last round is left -- 2048 chunks +4 %, 4096 +12 %):
+  // 4 workgroups per CU for the 256-thread kernels, 2 per CU for the WIDE histogram kernel (64 KB LDS
+  // each), which therefore has its own table.  A column group is split EVENLY into its chunks.
   {
-    const int target = d->target_blocks > 0 ? d->target_blocks : 2048;
-    int64_t CH = (N + target - 1) / std::max(target, 1);
-    CH = std::max<int64_t>(kThreads, ((CH + kThreads - 1) / kThreads) * kThreads);
-    std::vector<Chunk> chunks;
-    for (int g = 0; g < h->NG; g++) {
-      for (int64_t s = gcount[g]; s < gcount[g + 1]; s += CH) {
-        Chunk c;
-        c.start = uint32_t(s);
-        c.count = uint32_t(std::min<int64_t>(CH, gcount[g + 1] - s));
-        c.group = uint32_t(g);
-        c.pad = 0;
-        chunks.push_back(c);
+    int num_cus = 256;
+    if (hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || num_cus <= 0) num_cus = 256;
+    auto build_chunks = [&](int target, int threads, std::vector<Chunk>& chunks) {
+      int64_t CH = (N + target - 1) / std::max(target, 1);
+      CH = std::max<int64_t>(threads, ((CH + threads - 1) / threads) * threads);
+      for (int g = 0; g < h->NG; g++) {
+        const int64_t cnt = gcount[g + 1] - gcount[g];
+        if (cnt <= 0) continue;
+        const int64_t parts = (cnt + CH - 1) / CH;
+        const int64_t size = (((cnt + parts - 1) / parts + 63) / 64) * 64;  // 64 records = 1 KB: chunk starts stay aligned
+        for (int64_t s = gcount[g]; s < gcount[g + 1]; s += size) {
+          Chunk c;
+          c.start = uint32_t(s);
+          c.count = uint32_t(std::min<int64_t>(size, gcount[g + 1] - s));
+          c.group = uint32_t(g);
+          c.pad = 0;
+          chunks.push_back(c);
+        }
       }
-    }
+    };
+    std::vector<Chunk> chunks;
+    build_chunks(d->target_blocks > 0 ? d->target_blocks : 4 * num_cus, kThreads, chunks);
     h->nchunks = int(chunks.size());
     CREATE_TRY(hipMalloc(&h->d_chunks, std::max<size_t>(chunks.size(), 1) * sizeof(Chunk)));
     if (!chunks.empty()) CREATE_TRY(hipMemcpy(h->d_chunks, chunks.data(), chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice));
+    if (h->wide) {
+      std::vector<Chunk> wide_chunks;
+      build_chunks(d->target_blocks > 0 ? d->target_blocks : 2 * num_cus, kWideThreads, wide_chunks);
+      h->nchunks_hist = int(wide_chunks.size());
+      CREATE_TRY(hipMalloc(&h->d_chunks_hist, std::max<size_t>(wide_chunks.size(), 1) * sizeof(Chunk)));
+      if (!wide_chunks.empty()) CREATE_TRY(hipMemcpy(h->d_chunks_hist, wide_chunks.data(), wide_chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice));
+    }
   }
 
   // ---- per-evaluation scratch

@@ -33,4 +33,4 @@ for k in range(steps):
     if k >= 2:
         for key, v in cost.timing_ms().items():
             acc.setdefault(key, []).append(v)
-print(json.dumps({"prec": prec, "bins": bins, "info": cost.info(), "kernel_ms": {k: round(float(np.mean(v)), 4) for k, v in acc.items()}, "last_cost": c}))
+print(json.dumps({"prec": prec, "bins": bins, "info": cost.info(), "kernel_ms": {k: round(float(np.mean(v)), 4) for k, v in acc.items()}, "last_cost": c, "last_grad": [float(v) for v in g], "evals_per_s": round(1e3 / float(np.mean(acc["total"])), 1) if "total" in acc else None}))
