@@ -137,7 +137,10 @@ __device__ __forceinline__ void grad_final_body(const double* partials, int nblo
 // the 8-wave workgroup (2 workgroups = 16 waves per CU, the same wave occupancy as 4 x 4 waves).
 // The tile must start at LDS address 0: this kernel has no static LDS, so the dynamic segment does.
 // Measured on cfg 2: 74.3 -> 71.5 us.
-constexpr int kWideThreads = 512;
+#ifndef NID_WIDE_THREADS
+#define NID_WIDE_THREADS 512
+#endif
+constexpr int kWideThreads = NID_WIDE_THREADS;
 constexpr int kWideShift = 5;
 template <int MODEL, typename Rec, typename real, bool WIDE>
 __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_spline_hist(
