@@ -92,6 +92,37 @@ def test_spline_is_deterministic_and_tiling_independent():
         cost.close()
 
 
+def test_single_column_specialisations_match_generic_kernels():
+    """B = 256 with default tuning runs the WIDE histogram kernel (512 threads, 32 copies, v_perm
+    addressing) and the GW1 gradient kernel; an explicit lds_copies / columns_per_group selects the
+    generic kernels.  Same fixed-point histogram bit for bit, same cost, gradient equal to rounding --
+    for float records, double records and FP32 geometry."""
+    s = scene_for("fisheye", n=40000)
+    proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
+    x = s.T_camera_lidar_init
+    pts64 = s.points.copy()
+    pts64[:, :3] += 1e-9 * np.random.default_rng(0).normal(size=(pts64.shape[0], 3))  # not float-representable -> Rec64
+    for pts, prec in ((s.points, "fp64"), (pts64, "fp64"), (s.points, "fp32")):
+        wide = nid.NIDCost(proj, s.image_f64, pts, s.intensities, 256, precision=prec)
+        assert wide.info()["lds_copies"] == 32
+        generic = nid.NIDCost(proj, s.image_f64, pts, s.intensities, 256, precision=prec, lds_copies=16)
+        multi = nid.NIDCost(proj, s.image_f64, pts, s.intensities, 256, precision=prec, columns_per_group=4)
+        assert generic.info()["lds_copies"] == 16
+        ok0, c0, g0 = wide(x)
+        h0 = wide.histogram_fixed()
+        for other in (generic, multi):
+            ok1, c1, g1 = other(x)
+            h1 = other.histogram_fixed()
+            assert ok0 and ok1 and c0 == c1
+            assert np.array_equal(h0[0], h1[0]) and h0[1] == h1[1]
+            assert np.allclose(g0, g1, rtol=1e-11, atol=1e-14)
+        if prec == "fp64":
+            ref = oracle_lib.nid_cost(s.model, s.intrinsics, s.distortion, s.image_f64, pts, s.intensities, 256, x)
+            assert abs(c0 - ref["cost"]) <= 1e-10 and np.allclose(g0, ref["grad"], rtol=1e-7, atol=1e-10)
+        for c in (wide, generic, multi):
+            c.close()
+
+
 def test_spline_double_records_when_not_float_representable():
     s = scene_for("plumb_bob", n=8000)
     pts = s.points.copy()
