@@ -76,7 +76,12 @@ struct nidreg_handle {
   Chunk* d_chunks = nullptr;
   Chunk* d_chunks_hist = nullptr;
   uint8_t* d_img = nullptr;
-  u64* d_hist = nullptr;
+  u64* d_hist = nullptr;      // histogram of the current / most recent evaluation
+  // double buffering of the histogram (own buffers only): evaluation k accumulates into one buffer and
+  // its k_entropy zeroes the OTHER one for evaluation k + 1, so no memset sits on the critical path
+  u64* d_hist_buf[2] = {nullptr, nullptr};
+  bool hist_zeroed[2] = {false, false};
+  int hist_cur = 0;
   bool own_hist = false;
   double* d_out = nullptr;
   bool own_out = false;
@@ -113,7 +118,10 @@ void free_handle(nidreg_handle* h) {
   if (h->d_chunks) (void)hipFree(h->d_chunks);
   if (h->d_chunks_hist) (void)hipFree(h->d_chunks_hist);
   if (h->d_img) (void)hipFree(h->d_img);
-  if (h->own_hist && h->d_hist) (void)hipFree(h->d_hist);
+  if (h->own_hist) {
+    if (h->d_hist_buf[0]) (void)hipFree(h->d_hist_buf[0]);
+    if (h->d_hist_buf[1]) (void)hipFree(h->d_hist_buf[1]);
+  }
   if (h->own_out && h->d_out) (void)hipFree(h->d_out);
   if (h->d_part_hj) (void)hipFree(h->d_part_hj);
   if (h->d_row_part) (void)hipFree(h->d_row_part);
@@ -181,6 +189,24 @@ void pose_from_se3(const double* se3, double* R, double* t) {
   t[2] = se3[6];
 }
 
+// Select the buffer this evaluation accumulates into and make sure it is zero.  With own (double)
+// buffers the previous evaluation's k_entropy has already zeroed it; a caller-provided buffer
+// (ext_hist: the sharded protocol all-reduces it in place) or a buffer left dirty by a failed launch
+// is cleared with a memset.
+hipError_t begin_histogram(nidreg_handle* h) {
+  if (h->own_hist) {
+    h->hist_cur ^= 1;
+    h->d_hist = h->d_hist_buf[h->hist_cur];
+    if (!h->hist_zeroed[h->hist_cur]) {
+      hipError_t e = hipMemsetAsync(h->d_hist, 0, size_t(h->hist_words) * sizeof(u64), h->stream);
+      if (e != hipSuccess) return e;
+    }
+    h->hist_zeroed[h->hist_cur] = false;  // about to be written
+    return hipSuccess;
+  }
+  return hipMemsetAsync(h->d_hist, 0, size_t(h->hist_words) * sizeof(u64), h->stream);
+}
+
 int launch_hist_spline(nidreg_handle* h, const double* se3) {
   PassArgs a;
   fill_pass_args(h, a);
@@ -192,7 +218,8 @@ int launch_hist_spline(nidreg_handle* h, const double* se3) {
   for (int k = 0; k < 4; k++) h->last_q[k] = se3[k];
   std::memcpy(h->last_R, a.R, sizeof(a.R));
   std::memcpy(h->last_t, a.t, sizeof(a.t));
-  HIP_TRY(hipMemsetAsync(h->d_hist, 0, size_t(h->hist_words) * sizeof(u64), h->stream));
+  HIP_TRY(begin_histogram(h));
+  a.hist = h->d_hist;
   if (h->timing) HIP_TRY(hipEventRecord(h->ev[1], h->stream));
   if (h->precision == NIDREG_PREC_FP32) {
     HIP_TRY(launch_spline_hist<float>(a));
@@ -206,7 +233,8 @@ int launch_hist_nearest(nidreg_handle* h, const double* T) {
   PassArgs a;
   fill_pass_args(h, a);
   for (int k = 0; k < 12; k++) a.iso[k] = T[k];
-  HIP_TRY(hipMemsetAsync(h->d_hist, 0, size_t(h->hist_words) * sizeof(u64), h->stream));
+  HIP_TRY(begin_histogram(h));
+  a.hist = h->d_hist;
   if (h->timing) HIP_TRY(hipEventRecord(h->ev[1], h->stream));
   if (h->precision == NIDREG_PREC_FP32) {
     HIP_TRY(launch_nearest_hist<float>(a));
@@ -220,8 +248,9 @@ int launch_entropy(nidreg_handle* h, double tag) {
   const double inv_unit = std::ldexp(1.0, -h->frac_bits);
   hipLaunchKernelGGL(
     k_entropy, dim3(h->NEB), dim3(kThreads), 0, h->stream, h->d_hist, h->bins, kEntropyCols, inv_unit, h->d_part_hj, h->d_row_part, h->d_phi_q, h->d_hist_image,
-    h->d_hist_points, h->d_scal, h->d_out, h->d_out_host, tag, h->d_counters);
+    h->d_hist_points, h->d_scal, h->d_out, h->d_out_host, tag, h->d_counters, h->own_hist ? h->d_hist_buf[h->hist_cur ^ 1] : nullptr, h->hist_words);
   HIP_TRY(hipGetLastError());
+  if (h->own_hist) h->hist_zeroed[h->hist_cur ^ 1] = true;  // zeroed by this k_entropy for the next evaluation
   return NIDREG_OK;
 }
 
@@ -685,7 +714,12 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
   if (d->ext_hist) {
     h->d_hist = static_cast<u64*>(d->ext_hist);
   } else {
-    CREATE_TRY(hipMalloc(&h->d_hist, size_t(h->hist_words) * sizeof(u64)));
+    CREATE_TRY(hipMalloc(&h->d_hist_buf[0], size_t(h->hist_words) * sizeof(u64)));
+    CREATE_TRY(hipMalloc(&h->d_hist_buf[1], size_t(h->hist_words) * sizeof(u64)));
+    CREATE_TRY(hipMemset(h->d_hist_buf[1], 0, size_t(h->hist_words) * sizeof(u64)));
+    h->d_hist = h->d_hist_buf[0];
+    h->hist_cur = 0;
+    h->hist_zeroed[1] = true;  // [0] is zeroed below and read by nidreg_get_hist before the first evaluation
     h->own_hist = true;
   }
   if (d->ext_out) {

@@ -18,5 +18,5 @@ for l in open(p):
     try: d=json.loads(l)
     except Exception: print('BAD', l[:200]); continue
     k=d['kernel_ms']
-    print(f"{d['variant']:14s} tb={d['tb']:5d} total={k.get('total')} hist={k.get('hist')} ent={k.get('entropy')} grad={k.get('grad')} cost={d['last_cost']!r} g0={d['last_grad'][0]!r}")
+    print(f"{d['variant']:14s} tb={d['tb']:5d} wall={d.get('wall_ms')} total={k.get('total')} hist={k.get('hist')} ent={k.get('entropy')} grad={k.get('grad')} cost={d['last_cost']!r} g0={d['last_grad'][0]!r}")
 PY
