@@ -1,4 +1,5 @@
-// TEST INFRASTRUCTURE ONLY (see jet.hpp header).  PARITY UNPINNED.
+// TEST INFRASTRUCTURE ONLY (see jet.hpp header).  PARITY: bit-identical to include/camera/*.hpp compiled
+// from the reference tree against stand-in Eigen / ceres::Jet headers (oracle/_ref); third-party arithmetic UNPINNED.
 //
 // cameras.hpp -- CPU restatement of the reference's six projection functors and the
 // type-erased wrapper / string factory around them:

@@ -3,11 +3,17 @@
 // (direct_visual_lidar_calibration_amd/); only tests/, __graft_entry__.smoke() and
 // bench.py's cpu_baseline leg use it, and only as the checker.
 //
-// PARITY UNPINNED: the reference (koide3/direct_visual_lidar_calibration @ 2025-05-23)
-// ships no tests, golden vectors or fixtures for this path and cannot be compiled here
-// (Eigen / Ceres / Sophus / OpenCV absent), so this restatement is pinned only by an
-// independent second oracle (tests/pyoracle.py: numpy + torch.autograd) and by finite
-// differences -- see DESIGN.md.
+// PARITY: the reference (koide3/direct_visual_lidar_calibration @ 2025-05-23) ships no tests, golden
+// vectors or fixtures for this path, and its own build cannot run here (cmake + ROS + Eigen / Ceres /
+// Sophus / OpenCV / GTSAM / PCL, none installed, none vendored).  What pins this restatement:
+//   (1) oracle/_ref/libref.so (`make -C oracle ref`): the reference's OWN hot-path source files compiled
+//       unmodified, in place, against stand-in third-party headers (oracle/shim/); the restatement equals
+//       it bit for bit (tests/test_reference_build.py) and its outputs are committed as fixtures
+//       (tests/golden/reference_cases.npz, tests/test_reference_golden.py);
+//   (2) an independent second oracle (tests/pyoracle.py: numpy + torch.autograd) and finite differences.
+// STILL UNPINNED: the arithmetic of the absent third-party libraries themselves (ceres::Jet chain rules,
+// Sophus' point action, Eigen's reduction order, OpenCV's casts), restated from their published
+// definitions in this file and in oracle/shim/ -- see DESIGN.md section 5.
 //
 // jet.hpp -- forward-mode dual number with N partials.  Restates the arithmetic the
 // reference gets from ceres::Jet<double, 7> (Ceres Solver @ e47a42c2, un-vendored

@@ -1,5 +1,6 @@
-// TEST INFRASTRUCTURE ONLY (see jet.hpp header).  PARITY UNPINNED (no reference tests / goldens
-// exist for this path; pinned by tests/pyoracle.py and finite differences instead).
+// TEST INFRASTRUCTURE ONLY (see jet.hpp header).  PARITY: bit-identical to the reference's own sources
+// compiled against stand-in third-party headers (oracle/_ref, tests/test_reference_build.py); the third-party
+// arithmetic itself (Ceres / Sophus / Eigen / OpenCV, absent here) is restated and UNPINNED.
 //
 // nid_oracle.cpp -- CPU restatement, statement by statement, of the reference hot path:
 //   include/vlcal/costs/nid_cost.hpp:21-116                 -> nid_cost_ref<T>()

@@ -1,0 +1,217 @@
+// TEST INFRASTRUCTURE ONLY -- C ABI around the REFERENCE's own hot-path sources, compiled unmodified and in
+// place from /root/reference against the stand-in headers in oracle/shim/ (Eigen, Sophus, ceres::Jet,
+// OpenCV, Boost are not installed in this image; see oracle/shim/Eigen/Core for what that does and does
+// not pin).  Built by `make -C oracle ref` into oracle/_ref/libref.so (git-ignored; never shipped, never
+// imported by the product).  tests/test_reference_build.py compares oracle_* (the hand-written
+// restatement, nid_oracle.cpp) with ref_* (this file) on seeded inputs.
+//
+// Reference translation units linked in: src/camera/create_camera.cpp, src/vlcal/calib/cost_calculator_nid.cpp,
+// src/vlcal/calib/view_culling.cpp, src/vlcal/preprocess/generate_lidar_image.cpp; header-only:
+// include/camera/*.hpp, include/vlcal/costs/nid_cost.hpp, include/dfo/nelder_mead.hpp.
+// NOT compiled: src/vlcal/common/estimate_fov.cpp (needs PCL for estimate_lidar_fov) -- its two camera
+// functions (:17-51) are restated below on top of the reference's own dfo::NelderMead<2>.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include <ceres/jet.h>
+
+#include <camera/create_camera.hpp>
+#include <dfo/nelder_mead.hpp>
+#include <vlcal/calib/cost_calculator_nid.hpp>
+#include <vlcal/calib/view_culling.hpp>
+#include <vlcal/common/estimate_fov.hpp>
+#include <vlcal/costs/nid_cost.hpp>
+#include <vlcal/preprocess/generate_lidar_image.hpp>
+
+namespace vlcal {
+
+// visual_lidar_data.cpp:29 (that file also holds the PNG / PLY loading constructor: not compiled)
+VisualLiDARData::~VisualLiDARData() {}
+
+// estimate_fov.cpp:17-35.  AngleAxisd(x0, UnitX) * AngleAxisd(x1, UnitY) * UnitZ written out:
+// Ry(b) ez = (sin b, 0, cos b);  Rx(a) (x, y, z) = (x, cos a y - sin a z, sin a y + cos a z)
+Eigen::Vector3d estimate_direction(const camera::GenericCameraBase::ConstPtr& proj, const Eigen::Vector2d& pt_2d) {
+  const auto to_dir = [](const Eigen::Vector2d& x) {
+    const double sa = std::sin(x[0]), ca = std::cos(x[0]), sb = std::sin(x[1]), cb = std::cos(x[1]);
+    return Eigen::Vector3d(sb, -sa * cb, ca * cb);
+  };
+  const auto f = [&](const Eigen::Vector2d& x) {
+    const Eigen::Vector3d dir = to_dir(x);
+    const double err = (pt_2d - proj->project(dir)).squaredNorm();
+    return std::isfinite(err) ? err : std::numeric_limits<double>::max();
+  };
+  dfo::NelderMead<2>::Params params;
+  dfo::NelderMead<2> optimizer(params);
+  auto result = optimizer.optimize(f, Eigen::Vector2d::Zero());
+  return to_dir(result.x);
+}
+
+// estimate_fov.cpp:36-51
+double estimate_camera_fov(const camera::GenericCameraBase::ConstPtr& proj, const Eigen::Vector2i& image_size) {
+  const std::vector<Eigen::Vector2d> target_corners = {Eigen::Vector2d(0.0, 0.0), Eigen::Vector2d(image_size[0] / 2, 0.0), Eigen::Vector2d(0.0, image_size[1] / 2)};
+  double max_fov = 0.0;
+  for (const auto& corner : target_corners) {
+    const auto dir = estimate_direction(proj, corner);
+    const double fov = std::acos(dir.normalized().z());
+    if (fov > max_fov) {
+      max_fov = fov;
+    }
+  }
+  return max_fov;
+}
+
+}  // namespace vlcal
+
+namespace {
+
+camera::GenericCameraBase::ConstPtr make_camera(const char* model, const double* intr, int n_intr, const double* dist, int n_dist) {
+  return camera::create_camera(std::string(model), std::vector<double>(intr, intr + n_intr), std::vector<double>(dist, dist + n_dist));
+}
+
+std::shared_ptr<vlcal::FrameCPU> make_frame(const double* points, const double* intensities, int64_t n) {
+  return std::make_shared<vlcal::FrameCPU>(points, intensities, static_cast<size_t>(n));
+}
+
+template <int N>
+int run_nelder_mead(double init_step, double conv, int max_iter, double (*fn)(const double*, void*), void* user, const double* x0, double* x_out, double* y_out, int* iters_out) {
+  typename dfo::NelderMead<N>::Params params;
+  params.init_step = init_step;
+  params.convergence_var_thresh = conv;
+  params.max_iterations = max_iter;
+  dfo::NelderMead<N> optimizer(params);
+  Eigen::Matrix<double, N, 1> start;
+  for (int i = 0; i < N; i++) start[i] = x0[i];
+  const auto f = [&](const Eigen::Matrix<double, N, 1>& x) { return fn(x.data(), user); };
+  const auto result = optimizer.optimize(f, start);
+  for (int i = 0; i < N; i++) x_out[i] = result.x[i];
+  *y_out = result.y;
+  *iters_out = result.num_iterations;
+  return result.converged ? 1 : 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ref_project(const char* model, const double* intr, int n_intr, const double* dist, int n_dist, const double* p3, int64_t n, double* uv_out) {
+  auto cam = make_camera(model, intr, n_intr, dist, n_dist);
+  if (!cam) return -1;
+  for (int64_t i = 0; i < n; i++) {
+    const Eigen::Vector2d uv = cam->project(Eigen::Vector3d(p3[3 * i], p3[3 * i + 1], p3[3 * i + 2]));
+    uv_out[2 * i] = uv[0];
+    uv_out[2 * i + 1] = uv[1];
+  }
+  return 0;
+}
+
+// value + d(u,v)/d(x,y,z) through the Jet overload (generic_camera_base.hpp:40)
+int ref_project_jacobian(const char* model, const double* intr, int n_intr, const double* dist, int n_dist, const double* p3, int64_t n, double* uv_out, double* jac_out) {
+  auto cam = make_camera(model, intr, n_intr, dist, n_dist);
+  if (!cam) return -1;
+  typedef ceres::Jet<double, 7> J;
+  for (int64_t i = 0; i < n; i++) {
+    Eigen::Matrix<J, 3, 1> p;
+    for (int k = 0; k < 3; k++) p[k] = J(p3[3 * i + k], k);
+    const Eigen::Matrix<J, 2, 1> uv = (*cam)(p);
+    for (int r = 0; r < 2; r++) {
+      uv_out[2 * i + r] = uv[r].a;
+      for (int k = 0; k < 3; k++) jac_out[6 * i + 3 * r + k] = uv[r].v[k];
+    }
+  }
+  return 0;
+}
+
+// vlcal::NIDCost::operator()<double | Jet<double,7>>.  Returns 1 = true, 0 = false (non-finite NID), -1 = bad camera.
+int ref_nid_cost(const char* model, const double* intr, int n_intr, const double* dist, int n_dist, const double* image_f64, int rows, int cols, const double* points,
+                 const double* intensities, int64_t n, int bins, const double* se3, int want_grad, double* cost_out, double* grad_out) {
+  auto cam = make_camera(model, intr, n_intr, dist, n_dist);
+  if (!cam) return -1;
+  const cv::Mat image(rows, cols, CV_64FC1, const_cast<double*>(image_f64));
+  const vlcal::NIDCost cost(cam, image, make_frame(points, intensities, n), bins);
+  if (want_grad) {
+    typedef ceres::Jet<double, 7> J;
+    J params[7], residual;
+    for (int k = 0; k < 7; k++) params[k] = J(se3[k], k);
+    if (!cost(params, &residual)) return 0;
+    *cost_out = residual.a;
+    for (int k = 0; k < 7; k++) grad_out[k] = residual.v[k];
+    return 1;
+  }
+  double residual = 0.0;
+  if (!cost(se3, &residual)) return 0;
+  *cost_out = residual;
+  return 1;
+}
+
+int ref_estimate_camera_fov(const char* model, const double* intr, int n_intr, const double* dist, int n_dist, int width, int height, double* max_fov) {
+  auto cam = make_camera(model, intr, n_intr, dist, n_dist);
+  if (!cam) return -1;
+  Eigen::Vector2i size;
+  size[0] = width;
+  size[1] = height;
+  *max_fov = vlcal::estimate_camera_fov(cam, size);
+  return 0;
+}
+
+// vlcal::CostCalculatorNID::calculate; T: row-major 4x4 T_camera_lidar
+int ref_cost_calculator_nid(const char* model, const double* intr, int n_intr, const double* dist, int n_dist, const uint8_t* image, int rows, int cols, const double* points,
+                            const double* intensities, int64_t n, int bins, const double* T, double* cost_out) {
+  auto cam = make_camera(model, intr, n_intr, dist, n_dist);
+  if (!cam) return -1;
+  const cv::Mat img(rows, cols, CV_8UC1, const_cast<uint8_t*>(image));
+  auto data = std::make_shared<vlcal::VisualLiDARData>(img, make_frame(points, intensities, n));
+  vlcal::NIDCostParams params;
+  params.bins = bins;
+  vlcal::CostCalculatorNID calc(cam, data, params);
+  *cost_out = calc.calculate(Eigen::Isometry3d::FromRowMajor(T));
+  return 0;
+}
+
+// vlcal::ViewCulling::cull; returns the number of surviving points, their indices in indices_out
+int64_t ref_view_culling(const char* model, const double* intr, int n_intr, const double* dist, int n_dist, int width, int height, int enable_depth_buffer_culling,
+                         const double* points, int64_t n, const double* T, int* indices_out) {
+  auto cam = make_camera(model, intr, n_intr, dist, n_dist);
+  if (!cam) return -1;
+  std::vector<double> zeros(static_cast<size_t>(n), 0.0);
+  Eigen::Vector2i size;
+  size[0] = width;
+  size[1] = height;
+  vlcal::ViewCullingParams params;
+  params.enable_depth_buffer_culling = enable_depth_buffer_culling != 0;
+  const vlcal::ViewCulling culling(cam, size, params);
+  const auto culled = culling.cull(make_frame(points, zeros.data(), n), Eigen::Isometry3d::FromRowMajor(T));
+  for (size_t i = 0; i < culled->indices.size(); i++) indices_out[i] = culled->indices[i];
+  return static_cast<int64_t>(culled->indices.size());
+}
+
+// vlcal::generate_lidar_image
+int ref_generate_lidar_image(const char* model, const double* intr, int n_intr, const double* dist, int n_dist, int width, int height, const double* points,
+                             const double* intensities, int64_t n, const double* T, double* intensity_image, int32_t* index_image) {
+  auto cam = make_camera(model, intr, n_intr, dist, n_dist);
+  if (!cam) return -1;
+  Eigen::Vector2i size;
+  size[0] = width;
+  size[1] = height;
+  const auto images = vlcal::generate_lidar_image(cam, size, Eigen::Isometry3d::FromRowMajor(T), make_frame(points, intensities, n));
+  for (int y = 0; y < height; y++)
+    for (int x = 0; x < width; x++) {
+      intensity_image[static_cast<size_t>(y) * width + x] = images.first.at<double>(y, x);
+      index_image[static_cast<size_t>(y) * width + x] = images.second.at<std::int32_t>(y, x);
+    }
+  return 0;
+}
+
+// dfo::NelderMead<N>::optimize for N = 2 (estimate_fov.cpp) and N = 6 (visual_camera_calibration.cpp:121)
+int ref_nelder_mead(int n, double init_step, double conv_thresh, int max_iterations, double (*fn)(const double*, void*), void* user, const double* x0, double* x_out, double* y_out,
+                    int* iters_out) {
+  if (n == 2) return run_nelder_mead<2>(init_step, conv_thresh, max_iterations, fn, user, x0, x_out, y_out, iters_out);
+  if (n == 6) return run_nelder_mead<6>(init_step, conv_thresh, max_iterations, fn, user, x0, x_out, y_out, iters_out);
+  return -1;
+}
+
+}  // extern "C"

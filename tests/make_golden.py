@@ -1,7 +1,7 @@
 """Generates tests/golden/nid_golden.json from the C++ oracle AFTER it has been cross-checked against
-the independent Python oracle (tests/test_oracle.py).  The reference itself cannot be imported or
-compiled here (C++ with un-vendored Eigen/Ceres/Sophus/OpenCV), so these vectors pin the oracle
-against regressions; they are not outputs of the reference ("parity unpinned")."""
+the independent Python oracle (tests/test_oracle.py).  These vectors pin the oracle against regressions;
+they are oracle outputs.  Outputs of the reference's own sources (compiled against stand-in third-party
+headers) are in tests/golden/reference_cases.npz, written by tests/make_reference_golden.py."""
 import json
 import os
 import sys

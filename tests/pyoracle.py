@@ -1,6 +1,7 @@
 """Second, independent oracle for the C++ oracle -- TEST INFRASTRUCTURE ONLY.
 
-The reference has no tests or golden vectors for this path ("parity unpinned"), so the C++
+The reference has no tests or golden vectors for this path, so besides the build of its own sources
+against stand-in headers (oracle/_ref, tests/test_reference_build.py) the C++
 restatement in oracle/ is pinned by this vectorised numpy/torch statement of the same
 mathematics written from the equations, not from the C++ oracle:
 torch.float64 forward, torch.autograd for the 7-gradient.  Follows

@@ -1,0 +1,97 @@
+"""Committed fixtures holding OUTPUTS OF THE REFERENCE'S OWN SOURCES (tests/golden/reference_cases.npz, written
+by tests/make_reference_golden.py from oracle/_ref/libref.so -- the reference's nid_cost.hpp, camera models,
+cost_calculator_nid.cpp, view_culling.cpp and generate_lidar_image.cpp compiled unmodified against stand-in
+third-party headers).  Self-contained (inputs + outputs), so they travel to machines without the reference:
+
+* CPU: the oracle reproduces them (bit for bit on integers, to rounding on floats);
+* GPU (`-m gpu`): the HIP engine behind include/nidreg.h reproduces them within the parity bars
+  (NID 1e-10, gradient rtol 1e-7, integer results exact)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from direct_visual_lidar_calibration_amd import se3
+
+PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_cases.npz")
+
+
+def cases():
+    z = np.load(PATH)
+    out = []
+    for k in range(int(z["num_cases"])):
+        p = f"c{k}_"
+        c = {key[len(p):]: z[key] for key in z.files if key.startswith(p)}
+        c["model"] = str(c["model"])
+        c["intrinsics"] = [float(v) for v in c["intrinsics"]]
+        c["distortion"] = [float(v) for v in c["distortion"]]
+        c["W"], c["H"] = int(c["size"][0]), int(c["size"][1])
+        c["bins"] = int(c["bins"])
+        pts = np.ones((c["xyz"].shape[0], 4))
+        pts[:, :3] = c["xyz"].astype(np.float64)
+        c["points"] = pts
+        c["image_f64"] = c["image_u8"].astype(np.float64) * (1.0 / 255.0)
+        c["n"] = int(c["num_cost_points"])
+        c["T"] = se3.to_matrix(c["se3"])
+        out.append(c)
+    return out
+
+
+CASES = cases()
+IDS = [f"{c['model']}-{c['bins']}" for c in CASES]
+
+
+@pytest.mark.parametrize("c", CASES, ids=IDS)
+def test_oracle_reproduces_reference_outputs(c):
+    m, intr, dist = c["model"], c["intrinsics"], c["distortion"]
+    n = c["n"]
+    r = oracle_lib.nid_cost(m, intr, dist, c["image_f64"], c["points"][:n], c["intensities"][:n], c["bins"], c["se3"])
+    assert r["ok"] and abs(r["cost"] - float(c["ref_cost"])) <= 1e-15
+    assert np.allclose(r["grad"], c["ref_grad"], rtol=1e-13, atol=1e-16)
+    rd = oracle_lib.nid_cost(m, intr, dist, c["image_f64"], c["points"][:n], c["intensities"][:n], c["bins"], c["se3"], want_grad=False)
+    assert abs(rd["cost"] - float(c["ref_cost_double"])) <= 1e-15
+    fov = oracle_lib.estimate_camera_fov(m, intr, dist, c["W"], c["H"])
+    assert abs(fov - float(c["ref_fov"])) <= 1e-12
+    cn, _ = oracle_lib.cost_calculator_nid(m, intr, dist, c["image_u8"], c["points"], c["intensities"], c["bins"], float(c["ref_fov"]), c["T"])
+    assert abs(cn - float(c["ref_nearest_cost"])) <= 1e-15
+    pc = c["points"][:64, :3] @ c["T"][:3, :3].T + c["T"][:3, 3]
+    uv, jac = oracle_lib.project_jacobian(m, intr, dist, pc)
+    assert np.allclose(uv, c["ref_uv"], rtol=1e-14, atol=1e-12, equal_nan=True) and np.allclose(np.asarray(jac).reshape(-1, 2, 3), c["ref_jac"], rtol=1e-12, atol=1e-13, equal_nan=True)
+    if fov == float(c["ref_fov"]):  # these entry points estimate the FoV themselves
+        assert np.array_equal(oracle_lib.view_culling(m, intr, dist, c["W"], c["H"], c["points"], c["T"], True), c["ref_cull_depth"])
+        assert np.array_equal(oracle_lib.view_culling(m, intr, dist, c["W"], c["H"], c["points"], c["T"], False), c["ref_cull_nodepth"])
+        img, idx = oracle_lib.generate_lidar_image(m, intr, dist, c["W"], c["H"], c["points"], c["intensities"], c["T"])
+        assert np.array_equal(idx, c["ref_lidar_index"]) and np.array_equal(img, c["ref_lidar_intensity"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c", CASES, ids=IDS)
+def test_gpu_engine_reproduces_reference_outputs(c):
+    from direct_visual_lidar_calibration_amd import nid, render
+
+    m, intr, dist = c["model"], c["intrinsics"], c["distortion"]
+    n = c["n"]
+    proj = nid.create_camera(m, intr, dist)
+    cost = nid.NIDCost(proj, c["image_f64"], c["points"][:n], c["intensities"][:n], c["bins"])
+    ok, v, g = cost(c["se3"])
+    assert ok and abs(v - float(c["ref_cost"])) <= 1e-10
+    assert np.allclose(g, c["ref_grad"], rtol=1e-7, atol=1e-10)
+    ok, v, _ = cost(c["se3"], want_grad=False)
+    assert ok and abs(v - float(c["ref_cost_double"])) <= 1e-10
+    cost.close()
+    fov = float(c["ref_fov"])
+    calc = nid.CostCalculatorNID(proj, c["image_u8"], c["points"], c["intensities"], nid.NIDCostParams(c["bins"]), max_fov=fov)
+    assert abs(calc.calculate(c["T"]) - float(c["ref_nearest_cost"])) <= 1e-12  # integer histogram exact, entropy tail to rounding
+    calc.close()
+    assert abs(nid.estimate_camera_fov(proj, (c["W"], c["H"])) - fov) <= 1e-6
+    min_z = float(np.cos(fov))
+    for depth, key in ((True, "ref_cull_depth"), (False, "ref_cull_nodepth")):
+        vc = nid.ViewCulling(proj, (c["W"], c["H"]), nid.ViewCullingParams(depth), min_z=min_z)
+        assert np.array_equal(vc.cull(c["points"], c["T"]), c[key])
+    img, idx = render.generate_lidar_image(proj, (c["W"], c["H"]), c["T"], c["points"], c["intensities"], min_z=min_z)
+    assert np.array_equal(idx, c["ref_lidar_index"]) and np.array_equal(img, c["ref_lidar_intensity"])
+    pc = c["points"][:64, :3] @ c["T"][:3, :3].T + c["T"][:3, 3]
+    uv, jac = proj.project(pc, jacobian=True)
+    fin = np.isfinite(c["ref_uv"]).all(axis=1)
+    assert np.allclose(uv[fin], c["ref_uv"][fin], rtol=1e-12, atol=1e-9) and np.allclose(jac[fin], c["ref_jac"][fin], rtol=1e-9, atol=1e-9)
