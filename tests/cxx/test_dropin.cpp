@@ -12,6 +12,7 @@
 #include "vlcal_amd/generate_lidar_image.hpp"
 #include "vlcal_amd/nid_cost.hpp"
 #include "vlcal_amd/points_color_updater.hpp"
+#include "vlcal_amd/view_culling.hpp"
 
 struct MultiNIDCost {  // visual_camera_calibration.cpp:141-178 without the trust gate / OpenMP
   std::vector<std::shared_ptr<vlcal::NIDCost>> costs;
@@ -105,9 +106,16 @@ int main(int argc, char** argv) {
     inten_sum += lidar_intensity[q];
   }
 
+  // ViewCulling through its drop-in header (count + index checksum, depth buffer on)
+  const vlcal::ViewCulling culling(proj, W, H, vlcal::ViewCullingParams(), std::cos(max_fov));
+  const std::vector<int> kept = culling.cull_indices(frame, Tm);
+  double kept_sum = 0.0;
+  for (int i : kept) kept_sum += i;
+
   printf("%.17g", res.a);
   for (int k = 0; k < 7; k++) printf(" %.17g", res.v[k]);
   printf(" %.17g %.17g", c2, cn);
-  printf(" %.17g %ld %ld %.17g %.17g\n", color_sum, n_colored, idx_count, idx_sum, inten_sum);
+  printf(" %.17g %ld %ld %.17g %.17g", color_sum, n_colored, idx_count, idx_sum, inten_sum);
+  printf(" %zu %.17g\n", kept.size(), kept_sum);
   return 0;
 }

@@ -68,3 +68,5 @@ def test_dropin_matches_oracle(tmp_path):
         assert int(vals[12]) == int((lidx >= 0).sum()) and int(vals[12]) > 0
         assert vals[13] == float(lidx[lidx >= 0].astype(np.float64).sum())
         assert abs(vals[14] - float(li.sum())) <= 1e-9 * max(1.0, abs(vals[14]))
+        kept = oracle_lib.view_culling(s.model, s.intrinsics, s.distortion, s.width, s.height, s.points, T, True)
+        assert int(vals[15]) == kept.shape[0] and vals[16] == float(kept.astype(np.float64).sum())
