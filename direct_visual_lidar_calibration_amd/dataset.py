@@ -167,7 +167,7 @@ def _unfilter(raw, height, stride, bpp):
 
 
 def read_png(path):
-    """Decode a non-interlaced PNG (bit depth 8 or 16; gray, gray+alpha, RGB, RGBA, 8-bit palette).
+    """Decode a non-interlaced PNG (gray 1/2/4/8/16 bit, palette 1/2/4/8 bit, gray+alpha / RGB / RGBA 8/16 bit).
     Returns ``(array (H, W) or (H, W, C), bit_depth)`` with the file's own channel order (RGB)."""
     with open(path, "rb") as f:
         data = f.read()
@@ -195,11 +195,12 @@ def read_png(path):
     width, height, depth, color, _comp, _filt, interlace = ihdr
     if interlace != 0:
         raise ValueError(f"{path}: interlaced PNGs are not supported")
-    if color not in _PNG_CHANNELS or depth not in (8, 16) or (color == 3 and depth != 8):
+    sub_byte = depth in (1, 2, 4) and color in (0, 3)
+    if color not in _PNG_CHANNELS or not (depth in (8, 16) or sub_byte) or (color == 3 and depth == 16):
         raise ValueError(f"{path}: unsupported PNG colour type {color} / bit depth {depth}")
     ch = _PNG_CHANNELS[color]
-    bpp = ch * depth // 8
-    stride = width * bpp
+    bpp = max(1, ch * depth // 8)
+    stride = (width * ch * depth + 7) // 8
     raw = zlib.decompress(b"".join(idat))
     if len(raw) < height * (stride + 1):
         raise ValueError(f"{path}: truncated PNG image data")
@@ -207,6 +208,16 @@ def read_png(path):
     if depth == 16:
         img = rows.reshape(height, width * ch, 2)
         img = (img[:, :, 0].astype(np.uint16) << 8) | img[:, :, 1]
+    elif sub_byte:
+        # packed samples, most significant bits first; gray is expanded to 8 bits by replication
+        # (png_set_expand_gray_1_2_4_to_8, what cv::imread does), palette indices stay indices
+        bits = np.unpackbits(rows, axis=1)[:, : width * depth].reshape(height, width, depth)
+        img = np.zeros((height, width), dtype=np.uint8)
+        for k in range(depth):
+            img = (img << 1) | bits[:, :, k]
+        if color == 0:
+            img = (img.astype(np.uint16) * (255 // ((1 << depth) - 1))).astype(np.uint8)
+        depth = 8
     else:
         img = rows
     img = img.reshape(height, width, ch) if ch > 1 else img.reshape(height, width)

@@ -129,6 +129,28 @@ def test_png_decoder_all_filters_depths_and_colour_types(tmp_path):
     assert np.array_equal(dataset.read_png_gray(p), big)
     with pytest.raises(ValueError):
         dataset.read_png(__file__)
+    # packed 1 / 2 / 4-bit gray (expanded to 8 bits by replication) and a 4-bit palette image
+    for depth in (1, 2, 4):
+        w, h = 21, 5
+        vals = (rng.random((h, w)) * (1 << depth)).astype(np.uint8)
+        stride = (w * depth + 7) // 8
+        bits = np.zeros((h, stride * 8), dtype=np.uint8)
+        for k in range(depth):
+            bits[:, k : w * depth : depth] = (vals >> (depth - 1 - k)) & 1
+        packed = np.packbits(bits, axis=1)
+
+        def chunk(t, d):
+            return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+
+        raw = b"".join(b"\0" + packed[y].tobytes() for y in range(h))
+        p = str(tmp_path / f"g{depth}.png")
+        open(p, "wb").write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, 0, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+        assert np.array_equal(dataset.read_png_gray(p), vals * (255 // ((1 << depth) - 1)))
+        if depth == 4:
+            pal = (rng.random((16, 3)) * 256).astype(np.uint8)
+            open(p, "wb").write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 4, 3, 0, 0, 0)) + chunk(b"PLTE", pal.tobytes()) + chunk(b"IDAT", zlib.compress(raw))
+                               + chunk(b"IEND", b""))
+            assert np.array_equal(dataset.read_png(p)[0], pal[vals])
 
 
 def _write_synthetic_dir(path, n=15000, bags=1, seed=3, init_delta=(0.02, 0.4)):
