@@ -260,6 +260,22 @@ def main():
             f"median {t_med:.3f} s, scaled linearly x{scale:.1f}; host cpus={os.cpu_count()}",
             "ns_per_point": round(1e9 * t_med / ns, 1),
         }
+        # informational: the reference's OWN source (include/vlcal/costs/nid_cost.hpp, Jet<7>) when
+        # oracle/_ref/libref.so travelled with the snapshot -- compiled against the stand-in Eigen of
+        # oracle/shim/, so its speed is not real Eigen's; the headline CPU figure stays the port
+        try:
+            import ref_lib
+
+            if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref.so")):
+                tr = []
+                for k in range(2):
+                    t1 = time.perf_counter()
+                    ref_lib.nid_cost(scene.model, scene.intrinsics, scene.distortion, img64, sp, si, args.bins, poses[k], want_grad=True)
+                    tr.append(time.perf_counter() - t1)
+                cpu["reference_sources_value"] = round(1.0 / (min(tr) * scale), 6)
+                cpu["reference_sources_note"] = "vlcal::NIDCost::operator()<Jet<7>> compiled from the reference tree against stand-in third-party headers (oracle/_ref), 1 core"
+        except Exception as exc:  # never let the informational leg break the bench line
+            cpu["reference_sources_note"] = f"not timed: {exc}"
         # generous variant: same arithmetic, OpenMP over points on all host cores
         nthr = oracle_lib.num_threads()
         if nthr > 1:
