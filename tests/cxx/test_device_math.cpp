@@ -117,6 +117,75 @@ int main() {
       bad++;
     }
   }
+  // B-spline basis (nid_cost.hpp:29-33: C/6 applied to [1 s s^2 s^3]) and its derivative; pose transform
+  {
+    const double Cm[4][4] = {{1.0, -3.0, 3.0, -1.0}, {4.0, 0.0, -6.0, 3.0}, {1.0, 3.0, 3.0, -3.0}, {0.0, 0.0, 0.0, 1.0}};
+    double eb = 0, ed = 0, es = 0, emin = 1.0;
+    for (int i = 0; i <= 100000; i++) {
+      const double t = i == 100000 ? std::nextafter(1.0, 0.0) : i / 100000.0;
+      double b[4], d[4];
+      bspline<double>(t, b);
+      bspline_deriv<double>(t, d);
+      double sum = 0;
+      for (int k = 0; k < 4; k++) {
+        const double ref = (Cm[k][0] + Cm[k][1] * t + Cm[k][2] * t * t + Cm[k][3] * t * t * t) / 6.0;
+        const double dref = (Cm[k][1] + 2.0 * Cm[k][2] * t + 3.0 * Cm[k][3] * t * t) / 6.0;
+        eb = std::fmax(eb, std::fabs(b[k] - ref));
+        ed = std::fmax(ed, std::fabs(d[k] - dref));
+        emin = std::fmin(emin, b[k]);
+        sum += b[k];
+      }
+      es = std::fmax(es, std::fabs(sum - 1.0));
+    }
+    std::printf("bspline max err %.3g, derivative %.3g, partition of unity %.3g, min weight %.3g\n", eb, ed, es, emin);
+    // every weight must be >= +0: the fixed-point conversion reads the product's bit pattern (to_fixed_dn)
+    if (eb > 1e-15 || ed > 2e-15 || es > 1e-15 || emin < 0.0 || std::signbit(emin)) bad++;
+    float bf[4];
+    bspline<float>(0.37f, bf);
+    double b64[4];
+    bspline<double>(double(0.37f), b64);
+    for (int k = 0; k < 4; k++)
+      if (std::fabs(bf[k] - b64[k]) > 2e-7) bad++;
+    // p_cam = R p + t (fma chain) against the plain expression
+    PoseParams<double> pose;
+    std::mt19937_64 rng(5);
+    std::uniform_real_distribution<double> U(-1.0, 1.0);
+    for (int k = 0; k < 9; k++) pose.R[k] = U(rng);
+    for (int k = 0; k < 3; k++) pose.t[k] = U(rng);
+    double et = 0;
+    for (int i = 0; i < 100000; i++) {
+      const double x = 30 * U(rng), y = 30 * U(rng), z = 30 * U(rng);
+      double cx, cy, cz;
+      transform_fma<double>(pose, x, y, z, cx, cy, cz);
+      et = std::fmax(et, std::fabs(cx - (pose.R[0] * x + pose.R[1] * y + pose.R[2] * z + pose.t[0])));
+      et = std::fmax(et, std::fabs(cy - (pose.R[3] * x + pose.R[4] * y + pose.R[5] * z + pose.t[1])));
+      et = std::fmax(et, std::fabs(cz - (pose.R[6] * x + pose.R[7] * y + pose.R[8] * z + pose.t[2])));
+    }
+    std::printf("transform_fma max err %.3g\n", et);
+    if (et > 2e-14) bad++;
+  }
+  // FP32 geometry instantiation of the projections (NIDREG_PREC_FP32): float-accurate against the oracle
+  {
+    const double intr[4] = {1100, 1100, 960, 540}, dist[5] = {-0.04, 0.08, 1e-4, -3e-4, -0.04};
+    CamParams<float> cf;
+    for (int i = 0; i < 5; i++) cf.intr[i] = i < 4 ? float(intr[i]) : 0.f;
+    for (int i = 0; i < 8; i++) cf.dist[i] = i < 5 ? float(dist[i]) : 0.f;
+    oracle::PinholeProjection P;
+    std::mt19937_64 rng(6);
+    std::uniform_real_distribution<double> U(-1.0, 1.0);
+    double e = 0, ej = 0;
+    for (int i = 0; i < 100000; i++) {
+      const float z = float(0.5 + 15 * (U(rng) + 1.0)), x = float(z * 0.8 * U(rng)), y = float(z * 0.45 * U(rng));
+      float u, v, du[3], dv[3];
+      project_jac<MODEL_PLUMB_BOB, float>(cf, x, y, z, u, v, du, dv);
+      oracle::V3<oracle::Jet7> pj{oracle::Jet7(double(x), 0), oracle::Jet7(double(y), 1), oracle::Jet7(double(z), 2)};
+      const oracle::V2<oracle::Jet7> r = P(intr, dist, pj);
+      e = std::fmax(e, std::fmax(std::fabs(u - r.x.a), std::fabs(v - r.y.a)));
+      for (int k = 0; k < 3; k++) ej = std::fmax(ej, std::fmax(std::fabs(du[k] - r.x.v[k]), std::fabs(dv[k] - r.y.v[k])) / (1.0 + std::fabs(r.x.v[k]) + std::fabs(r.y.v[k])));
+    }
+    std::printf("fp32 plumb_bob: max |uv - ref| %.3g px, jacobian rel %.3g\n", e, ej);
+    if (e > 2e-3 || ej > 2e-5) bad++;
+  }
   // fast_atan2 / fast_rcp / fast_rsq accuracy
   {
     std::mt19937_64 rng(99);
