@@ -39,6 +39,23 @@ struct EntropyScalars {
   double status;   // 0 = finite, 1 = non-finite NID (functor returns false)
 };
 
+#ifdef NID_STAMP
+// development aid (tools/wg_timeline.hip): per-workgroup start / end wall-clock stamps (100 MHz) and hardware ids
+__device__ unsigned long long g_stamp[4 * 8192];
+__device__ __forceinline__ void stamp_begin() {
+  if (threadIdx.x == 0) {
+    g_stamp[4 * blockIdx.x + 0] = wall_clock64();
+    g_stamp[4 * blockIdx.x + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+  }
+}
+__device__ __forceinline__ void stamp_end() {
+  if (threadIdx.x == 0) g_stamp[4 * blockIdx.x + 1] = wall_clock64();
+}
+#else
+__device__ __forceinline__ void stamp_begin() {}
+__device__ __forceinline__ void stamp_end() {}
+#endif
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -162,6 +179,7 @@ __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_spline_hist(
   constexpr int kT = WIDE ? kWideThreads : kThreads;
   const int tid = threadIdx.x;
   const Chunk ch = chunks[blockIdx.x];
+  stamp_begin();
   for (int k = tid; k < tile_w; k += kT) tile[k] = 0;
   if (tid == 0) *s_inl = 0;
   if (tid < GW) s_colsum[tid] = 0;
@@ -247,6 +265,7 @@ __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_spline_hist(
   __syncthreads();
   if (tid < GW && s_colsum[tid]) atomicAdd(&hist[size_t(B) * size_t(B) + kTailWords + col0 + uint32_t(tid)], s_colsum[tid]);
   if (tid == 0 && *s_inl) atomicAdd(&hist[size_t(B) * size_t(B) + kTailInliers], u64(*s_inl));
+  stamp_end();
 }
 
 // ------------------------------------------------------------------------------------------
