@@ -77,3 +77,34 @@ def test_nelder_mead_minimises_and_counts_like_the_reference():
     assert np.allclose(calls[0], [0, 0]) and np.allclose(calls[1], [0.1, 0]) and np.allclose(calls[2], [0, 0.1])
     # the centroid is EVALUATED every iteration (nelder_mead.hpp:58): >= 2 evaluations per iteration
     assert r.num_evaluations >= 3 + 2 * r.num_iterations
+
+
+def test_bench_helpers_algorithmic_bytes_labels_and_committed_traffic():
+    """bench.py's bookkeeping (no GPU): SURVEY 8(d) byte formula, BASELINE config labels, and the PMC traffic
+    figure it reports is the one committed under profiles/ for the default workload."""
+    import argparse
+    import glob
+    import json
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    # 16 N + W H + 8 (B^2 + 2 B) + 64; config 2 = 162.6 MB
+    assert bench.algorithmic_bytes(10_000_000, 1920, 1080, 256) == 16 * 10_000_000 + 1920 * 1080 + 8 * (256 * 256 + 2 * 256) + 64
+    assert abs(bench.algorithmic_bytes(10_000_000, 1920, 1080, 256) / 1e6 - 162.6) < 0.05
+    ns = argparse.Namespace(points=10_000_000, camera="pinhole_1080p", bins=256, mode="pairs")
+    assert bench.baseline_config_label(ns) == "BASELINE configs[1]"
+    ns.camera, ns.points = "fisheye_1080p", 5_000_000
+    assert "configs[3]" in bench.baseline_config_label(ns)
+    ns.points = 123
+    assert bench.baseline_config_label(ns) == "custom workload"
+    files = sorted(glob.glob(os.path.join(root, "profiles", "*_traffic.json")))
+    assert files, "a PMC traffic summary must be committed under profiles/"
+    t = json.load(open(files[-1]))
+    got = bench.pmc_traffic("k_spline_grad", 10_000_000, 1920, 1080, 256, "fp64")
+    assert got == t["kernels"]["k_spline_grad"]["hbm_bytes_corrected"]
+    assert 0.95 < got / bench.algorithmic_bytes(10_000_000, 1920, 1080, 256) < 1.15  # no over-fetch
+    assert bench.pmc_traffic("k_spline_grad", 7, 1, 1, 16, "fp64") is None
