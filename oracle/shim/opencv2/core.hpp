@@ -46,6 +46,10 @@ public:
   T& at(int y, int x) { return *reinterpret_cast<T*>(data + size_t(y) * step + size_t(x) * sizeof(T)); }
   template <typename T>
   const T& at(int y, int x) const { return *reinterpret_cast<const T*>(data + size_t(y) * step + size_t(x) * sizeof(T)); }
+  template <typename T>
+  T* ptr(int y = 0) { return reinterpret_cast<T*>(data + size_t(y) * step); }
+  template <typename T>
+  const T* ptr(int y = 0) const { return reinterpret_cast<const T*>(data + size_t(y) * step); }
   Mat clone() const {
     Mat m(rows, cols, type_);
     for (int y = 0; y < rows; y++) std::memcpy(m.data + size_t(y) * m.step, data + size_t(y) * step, m.step);
