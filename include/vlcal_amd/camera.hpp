@@ -7,13 +7,18 @@
 #include <string>
 #include <vector>
 
+#include "../nidreg.h"
+
 #ifdef NIDREG_WITH_REFERENCE_DEPS
+// inside a reference checkout: the reference's own camera classes, with the three accessors of
+// integration/reference_camera.patch applied (camera::GenericCameraBase::nidreg_model_id() / _intrinsics() /
+// _distortion()); CPU project() stays the reference's, camera::create_camera stays src/camera/create_camera.cpp
 #include <Eigen/Core>
 #include <ceres/jet.h>
+#include <camera/create_camera.hpp>
+#include <camera/generic_camera_base.hpp>
 #else
 #include "standins.hpp"
-#endif
-#include "../nidreg.h"
 
 namespace camera {
 
@@ -73,3 +78,4 @@ inline GenericCameraBase::ConstPtr create_camera(const std::string& camera_model
 }
 
 }  // namespace camera
+#endif  // NIDREG_WITH_REFERENCE_DEPS

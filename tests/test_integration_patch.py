@@ -1,0 +1,90 @@
+"""INTEGRATION.md executed: integration/reference_camera.patch is applied to a scratch copy of the reference's
+two camera headers, and tests/cxx/test_integration.cpp is compiled in -DNIDREG_WITH_REFERENCE_DEPS mode together
+with the reference's own src/camera/create_camera.cpp -- i.e. the reference's camera factory and classes feeding
+this repository's vlcal::NIDCost.  CPU: the patch applies, everything compiles and links, the patched cameras
+report the right model ids / padded parameters and still project on the CPU.  GPU: the binary (built here, it
+travels with the snapshot) evaluates cost + Jacobian and matches the oracle.  Needs the reference tree to build."""
+import os
+import shutil
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+CSRC = os.path.join(ROOT, "direct_visual_lidar_calibration_amd", "csrc")
+EXE = os.path.join(ROOT, "tests", "cxx", "test_integration.bin")
+
+
+def build(scratch):
+    inc = os.path.join(scratch, "include", "camera")
+    os.makedirs(inc, exist_ok=True)
+    for name in ("generic_camera_base.hpp", "generic_camera.hpp"):
+        shutil.copy(os.path.join(REF, "include", "camera", name), inc)
+    subprocess.check_call(["patch", "-p1", "-s", "-d", scratch, "-i", os.path.join(ROOT, "integration", "reference_camera.patch")])
+    if not os.path.exists(os.path.join(CSRC, "libnidreg.so")):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    cmd = ["g++", "-std=c++17", "-O1", "-DNIDREG_WITH_REFERENCE_DEPS", "-Wno-sign-compare",
+           "-I", os.path.join(scratch, "include"),          # the two patched headers shadow the originals
+           "-I", os.path.join(ROOT, "oracle", "shim"),      # Eigen / ceres / OpenCV as this image knows them
+           "-I", os.path.join(REF, "include"), "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "cxx", "test_integration.cpp"), os.path.join(REF, "src", "camera", "create_camera.cpp"),
+           "-L", CSRC, "-lnidreg", f"-Wl,-rpath,{CSRC}", "-o", EXE]
+    subprocess.check_call(cmd)
+    return EXE
+
+
+def test_patch_applies_builds_and_cameras_expose_parameters(tmp_path):
+    if not os.path.isdir(os.path.join(REF, "include", "camera")):
+        pytest.skip("reference tree not present")
+    import oracle_lib
+
+    exe = build(str(tmp_path))
+    out = subprocess.check_output([exe, "--describe"]).decode().strip().splitlines()
+    ids = {"plumb_bob": 0, "fisheye": 1, "equidistant": 1, "omnidir": 2, "equirectangular": 3, "atan": 4, "rational_polynomial": 5}
+    assert len(out) == len(ids)
+    given = {"plumb_bob": ([210, 205, 160, 120], [-0.04, 0.08, 1e-4, -3e-4, -0.04]), "fisheye": ([140, 140, 160, 120], [-0.01, 0.002]), "equidistant": ([140, 140, 160, 120], []),
+             "omnidir": ([110, 110, 160, 160, 1.0], [-0.02, 0.003, 1e-4, -2e-4]), "equirectangular": ([384, 256], []), "atan": ([210, 205, 160, 120], [0.6]),
+             "rational_polynomial": ([210, 205, 160, 120], [0.05, -0.02, 1e-4, -2e-4, 0.01, 0.03, -0.01, 0.002])}
+    for line in out:
+        tok = line.split()
+        name, mid, vals = tok[0], int(tok[1]), np.array([float(v) for v in tok[2:]])
+        assert mid == ids[name]
+        intr, dist = given[name]
+        assert np.array_equal(vals[:5], np.pad(np.array(intr, dtype=float), (0, 5 - len(intr))))
+        assert np.array_equal(vals[5:13], np.pad(np.array(dist, dtype=float), (0, 8 - len(dist))))  # zero padded, surplus dropped
+        uv = oracle_lib.project("fisheye" if name == "equidistant" else name, intr, dist, np.array([[0.3, -0.2, 2.0]]))
+        assert np.array_equal(vals[13:15], uv[0])  # the reference's CPU projection is untouched by the patch
+
+
+@pytest.mark.gpu
+def test_reference_cameras_feed_the_gpu_cost(tmp_path):
+    if not os.path.exists(EXE):
+        pytest.skip("tests/cxx/test_integration.bin was not built (needs the reference tree; built by the CPU test)")
+    import oracle_lib
+    from direct_visual_lidar_calibration_amd import se3, synth
+    from test_gpu_parity import CAMERAS
+
+    for name, bins in (("plumb_bob", 256), ("equirectangular", 16)):
+        s = synth.make_scene(CAMERAS[name], num_points=15000, seed=33)
+        x = s.T_camera_lidar_init
+        intr = np.zeros(5)
+        intr[: len(s.intrinsics)] = s.intrinsics
+        dist = np.zeros(8)
+        dist[: len(s.distortion)] = s.distortion
+        path = tmp_path / f"{name}.bin"
+        with open(path, "wb") as f:
+            f.write(s.model.encode().ljust(64, b"\0"))
+            f.write(struct.pack("<6i", s.width, s.height, s.points.shape[0], bins, len(s.intrinsics), len(s.distortion)))
+            f.write(intr.tobytes() + dist.tobytes() + np.asarray(x, dtype=np.float64).tobytes() + struct.pack("<d", 0.0) + se3.to_matrix(x).astype(np.float64).tobytes())
+            f.write(np.ascontiguousarray(s.image_u8).tobytes())
+            f.write(np.ascontiguousarray(s.points, dtype=np.float64).tobytes())
+            f.write(np.ascontiguousarray(s.intensities, dtype=np.float64).tobytes())
+        vals = np.array([float(v) for v in subprocess.check_output([EXE, str(path)]).decode().split()])
+        ref = oracle_lib.nid_cost(s.model, s.intrinsics, s.distortion, s.image_f64, s.points, s.intensities, bins, x)
+        assert abs(vals[0] - ref["cost"]) <= 1e-10 and abs(vals[8] - ref["cost"]) <= 1e-10
+        assert np.allclose(vals[1:8], ref["grad"], rtol=1e-7, atol=1e-10)
