@@ -6,7 +6,8 @@
 // restatement, nid_oracle.cpp) with ref_* (this file) on seeded inputs.
 //
 // Reference translation units linked in: src/camera/create_camera.cpp, src/vlcal/calib/cost_calculator_nid.cpp,
-// src/vlcal/calib/view_culling.cpp, src/vlcal/preprocess/generate_lidar_image.cpp; header-only:
+// src/vlcal/calib/view_culling.cpp, src/vlcal/preprocess/generate_lidar_image.cpp,
+// src/vlcal/common/points_color_updater.cpp (glk / guik = stand-ins of the viewer side); header-only:
 // include/camera/*.hpp, include/vlcal/costs/nid_cost.hpp, include/dfo/nelder_mead.hpp.
 // NOT compiled: src/vlcal/common/estimate_fov.cpp (needs PCL for estimate_lidar_fov) -- its two camera
 // functions (:17-51) are restated below on top of the reference's own dfo::NelderMead<2>.
@@ -25,8 +26,13 @@
 #include <vlcal/calib/cost_calculator_nid.hpp>
 #include <vlcal/calib/view_culling.hpp>
 #include <vlcal/common/estimate_fov.hpp>
+#include <vlcal/common/points_color_updater.hpp>
 #include <vlcal/costs/nid_cost.hpp>
 #include <vlcal/preprocess/generate_lidar_image.hpp>
+
+// Iridescence's TURBO table is not available; the constructor's call (points_color_updater.cpp:34) gets a
+// placeholder, and the driver overwrites the public `intensity_colors` with the caller's colours
+Eigen::Vector4f glk::colormapf(glk::COLORMAP, float x) { return Eigen::Vector4f(x, x, x, 1.0f); }
 
 namespace vlcal {
 
@@ -203,6 +209,26 @@ int ref_generate_lidar_image(const char* model, const double* intr, int n_intr, 
       intensity_image[static_cast<size_t>(y) * width + x] = images.first.at<double>(y, x);
       index_image[static_cast<size_t>(y) * width + x] = images.second.at<std::int32_t>(y, x);
     }
+  return 0;
+}
+
+// vlcal::PointsColorUpdater::update (constructor :26-35 incl. its min_nz; colours read back from the stand-in
+// PointCloudBuffer).  intensity_colors: n x 4 floats.  colors_out: n x 4 floats.
+int ref_points_color_update(const char* model, const double* intr, int n_intr, const double* dist, int n_dist, const uint8_t* image, int rows, int cols, const double* points, int64_t n,
+                            const float* intensity_colors, const double* T, double blend_weight, float* colors_out, double* min_nz_out) {
+  auto cam = make_camera(model, intr, n_intr, dist, n_dist);
+  if (!cam) return -1;
+  const cv::Mat img(rows, cols, CV_8UC1, const_cast<uint8_t*>(image));
+  std::vector<double> zeros(static_cast<size_t>(n), 0.0);
+  vlcal::PointsColorUpdater updater(cam, img, make_frame(points, zeros.data(), n));
+  for (int64_t i = 0; i < n; i++)
+    for (int k = 0; k < 4; k++) updater.intensity_colors[static_cast<size_t>(i)][k] = intensity_colors[4 * i + k];
+  if (min_nz_out) *min_nz_out = updater.min_nz;
+  updater.update(Eigen::Isometry3d::FromRowMajor(T), blend_weight);
+  const auto& colors = updater.cloud_buffer->last_colors;
+  if (static_cast<int64_t>(colors.size()) != n) return -2;
+  for (int64_t i = 0; i < n; i++)
+    for (int k = 0; k < 4; k++) colors_out[4 * i + k] = colors[static_cast<size_t>(i)][k];
   return 0;
 }
 

@@ -20,10 +20,18 @@ struct FrameCPU : public Frame {
       for (int k = 0; k < 4; k++) points_storage[i][k] = xyzw[4 * i + k];
     bind();
   }
+  // frame_cpu.hpp:29: from a vector of D-vectors (w = 1 for D = 3)
+  template <typename T, int D, typename Alloc>
+  FrameCPU(const std::vector<Eigen::Matrix<T, D, 1>, Alloc>& pts) : points_storage(pts.size()) {
+    for (size_t i = 0; i < pts.size(); i++) {
+      for (int k = 0; k < 4; k++) points_storage[i][k] = k < D ? double(pts[i][k]) : 1.0;
+    }
+    bind();
+  }
   void bind() {
     num_points = points_storage.size();
     points = points_storage.data();
-    intensities = intensities_storage.data();
+    intensities = intensities_storage.empty() ? nullptr : intensities_storage.data();
   }
   std::vector<Eigen::Vector4d> points_storage;
   std::vector<double> intensities_storage;

@@ -52,8 +52,13 @@ for k, (model, intr, dist, W, H, bins, n, seed) in enumerate(CASES):
     fov = ref_lib.estimate_camera_fov(model, intr, dist, W, H)
     uv, jac = ref_lib.project(model, intr, dist, pts[:64, :3] @ T[:3, :3].T + T[:3, 3], jacobian=True)
     lidar_img, lidar_idx = ref_lib.generate_lidar_image(model, intr, dist, W, H, pts, inten, T)
+    ncol = 400  # every 5th point + the occluded / behind-camera tail would do; per-point independent, so a prefix + tail
+    csel = np.concatenate([np.arange(0, ncol), np.arange(pts.shape[0] - 100, pts.shape[0])])
+    icol = (np.floor(rng.random((csel.shape[0], 4)) * 64) / 64).astype(np.float32)
+    colors, min_nz = ref_lib.points_color_update(model, intr, dist, s.image_u8, pts[csel], icol, T, 0.7)
     p = f"c{k}_"
     out.update({
+        p + "color_points": csel, p + "intensity_colors": icol, p + "ref_colors": colors, p + "ref_min_nz": np.array(min_nz),
         p + "model": np.array(model), p + "intrinsics": np.array(intr), p + "distortion": np.array(dist, dtype=np.float64), p + "size": np.array([W, H]), p + "bins": np.array(bins),
         p + "image_u8": s.image_u8, p + "xyz": xyz, p + "intensities": inten, p + "num_cost_points": np.array(n_cost), p + "se3": x,
         p + "ref_cost": np.array(r["cost"]), p + "ref_grad": r["grad"], p + "ref_cost_double": np.array(rd["cost"]), p + "ref_fov": np.array(fov),

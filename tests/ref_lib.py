@@ -127,6 +127,24 @@ def generate_lidar_image(model, intrinsics, distortion, width, height, points, i
     return iimg, idx
 
 
+def points_color_update(model, intrinsics, distortion, image_u8, points, intensity_colors, T, blend_weight):
+    """vlcal::PointsColorUpdater (constructor + update) from src/vlcal/common/points_color_updater.cpp; the viewer
+    side (glk / guik) is a stand-in that hands the colours back.  Returns (colors n x 4 float32, min_nz)."""
+    img = np.ascontiguousarray(image_u8, dtype=np.uint8)
+    pts = np.ascontiguousarray(points, dtype=np.float64)
+    T = np.ascontiguousarray(T, dtype=np.float64).reshape(4, 4)
+    ic = np.ascontiguousarray(intensity_colors, dtype=np.float32).reshape(-1, 4)
+    out = np.empty((pts.shape[0], 4), dtype=np.float32)
+    min_nz = ctypes.c_double(0.0)
+    m, ip, ni, dp, nd, keep = _cam(model, intrinsics, distortion)
+    fp = ctypes.POINTER(ctypes.c_float)
+    rc = lib().ref_points_color_update(m, ip, ni, dp, nd, img.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), ctypes.c_int(img.shape[0]), ctypes.c_int(img.shape[1]), _dp(pts),
+                                       ctypes.c_int64(pts.shape[0]), ic.ctypes.data_as(fp), _dp(T), ctypes.c_double(blend_weight), out.ctypes.data_as(fp), ctypes.byref(min_nz))
+    if rc != 0:
+        raise ValueError(f"reference build: points_color_update failed ({rc})")
+    return out, min_nz.value
+
+
 _NM_FN = ctypes.CFUNCTYPE(ctypes.c_double, c_double_p, ctypes.c_void_p)
 
 

@@ -138,6 +138,23 @@ def test_fov_nearest_cost_culling_and_lidar_image_identical(model):
         pytest.fail(f"estimate_camera_fov differs in the last bits: {fov_ref!r} vs {fov_orc!r}")
 
 
+@pytest.mark.parametrize("model", ["plumb_bob", "fisheye", "omnidir", "equirectangular"])
+def test_points_color_updater_identical(model):
+    """src/vlcal/common/points_color_updater.cpp (constructor's min_nz, update's blend) vs the restatement; the
+    Vector4f * double products follow Eigen's scalar promotion (the double is converted to float first)."""
+    s = scene(model)
+    T = se3.to_matrix(s.T_camera_lidar_init)
+    rng = np.random.default_rng(8)
+    pts = np.concatenate([s.points, np.concatenate([-s.points[:500, :3], np.ones((500, 1))], -1)])  # some behind the camera
+    ic = rng.random((pts.shape[0], 4)).astype(np.float32)
+    for w in (0.7, 0.0, 1.0, 1.0 / 3.0):
+        c_ref, nz_ref = ref_lib.points_color_update(s.model, s.intrinsics, s.distortion, s.image_u8, pts, ic, T, w)
+        c_orc, nz_orc = oracle_lib.points_color_update(s.model, s.intrinsics, s.distortion, s.image_u8, pts, ic, T, w)
+        assert nz_ref == nz_orc
+        assert same(c_ref, c_orc)
+    assert (c_ref[:, 3] > 0).mean() > 0.1 and np.all(c_ref[9] == c_orc[9])
+
+
 def test_nelder_mead_trajectory_identical():
     def rosen2(x):
         return (1 - x[0]) ** 2 + 100 * (x[1] - x[0] ** 2) ** 2

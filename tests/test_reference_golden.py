@@ -58,6 +58,9 @@ def test_oracle_reproduces_reference_outputs(c):
     pc = c["points"][:64, :3] @ c["T"][:3, :3].T + c["T"][:3, 3]
     uv, jac = oracle_lib.project_jacobian(m, intr, dist, pc)
     assert np.allclose(uv, c["ref_uv"], rtol=1e-14, atol=1e-12, equal_nan=True) and np.allclose(np.asarray(jac).reshape(-1, 2, 3), c["ref_jac"], rtol=1e-12, atol=1e-13, equal_nan=True)
+    col, min_nz = oracle_lib.points_color_update(m, intr, dist, c["image_u8"], c["points"][c["color_points"]], c["intensity_colors"], c["T"], 0.7)
+    if min_nz == float(c["ref_min_nz"]):
+        assert np.array_equal(col, c["ref_colors"])
     if fov == float(c["ref_fov"]):  # these entry points estimate the FoV themselves
         assert np.array_equal(oracle_lib.view_culling(m, intr, dist, c["W"], c["H"], c["points"], c["T"], True), c["ref_cull_depth"])
         assert np.array_equal(oracle_lib.view_culling(m, intr, dist, c["W"], c["H"], c["points"], c["T"], False), c["ref_cull_nodepth"])
@@ -91,6 +94,11 @@ def test_gpu_engine_reproduces_reference_outputs(c):
         assert np.array_equal(vc.cull(c["points"], c["T"]), c[key])
     img, idx = render.generate_lidar_image(proj, (c["W"], c["H"]), c["T"], c["points"], c["intensities"], min_z=min_z)
     assert np.array_equal(idx, c["ref_lidar_index"]) and np.array_equal(img, c["ref_lidar_intensity"])
+    import test_render
+
+    upd = test_render._updater_with_min_nz(proj, c["image_u8"], c["points"][c["color_points"]], c["intensity_colors"], float(c["ref_min_nz"]))
+    assert np.array_equal(upd.update(c["T"], 0.7), c["ref_colors"])  # PointsColorUpdater::update, float for float
+    upd.close()
     pc = c["points"][:64, :3] @ c["T"][:3, :3].T + c["T"][:3, 3]
     uv, jac = proj.project(pc, jacobian=True)
     fin = np.isfinite(c["ref_uv"]).all(axis=1)
