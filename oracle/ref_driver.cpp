@@ -7,7 +7,9 @@
 //
 // Reference translation units linked in: src/camera/create_camera.cpp, src/vlcal/calib/cost_calculator_nid.cpp,
 // src/vlcal/calib/view_culling.cpp, src/vlcal/preprocess/generate_lidar_image.cpp,
-// src/vlcal/common/points_color_updater.cpp (glk / guik = stand-ins of the viewer side); header-only:
+// src/vlcal/common/points_color_updater.cpp (glk / guik = stand-ins of the viewer side),
+// src/vlcal/calib/visual_camera_calibration.cpp (outer loop, Nelder-Mead inner solve, MultiNIDCost; its BFGS solve
+// needs Ceres: ceres::Solve is an evaluate-and-record stand-in, gtsam::Pose3::Expmap / Sophus::SE3d restated); header-only:
 // include/camera/*.hpp, include/vlcal/costs/nid_cost.hpp, include/dfo/nelder_mead.hpp.
 // NOT compiled: src/vlcal/common/estimate_fov.cpp (needs PCL for estimate_lidar_fov) -- its two camera
 // functions (:17-51) are restated below on top of the reference's own dfo::NelderMead<2>.
@@ -19,16 +21,42 @@
 #include <string>
 #include <vector>
 
+#include <ceres/ceres.h>
 #include <ceres/jet.h>
 
 #include <camera/create_camera.hpp>
 #include <dfo/nelder_mead.hpp>
 #include <vlcal/calib/cost_calculator_nid.hpp>
 #include <vlcal/calib/view_culling.hpp>
+#include <vlcal/calib/visual_camera_calibration.hpp>
 #include <vlcal/common/estimate_fov.hpp>
 #include <vlcal/common/points_color_updater.hpp>
 #include <vlcal/costs/nid_cost.hpp>
 #include <vlcal/preprocess/generate_lidar_image.hpp>
+
+// ceres::Solve stand-in (oracle/shim/ceres/ceres.h): evaluate, record, leave the parameters alone
+namespace ceres {
+ProbeLog& probe_log() {
+  static ProbeLog log;
+  return log;
+}
+void Solve(const GradientProblemSolver::Options&, const GradientProblem& problem, double* parameters, GradientProblemSolver::Summary* summary) {
+  ProbeLog& log = probe_log();
+  const int n = problem.function->NumParameters();
+  std::vector<std::vector<double>> points;
+  points.emplace_back(parameters, parameters + n);
+  for (const auto& p : log.probes) points.push_back(p);
+  for (const auto& x : points) {
+    ProbeLog::Entry e;
+    e.cost_value = e.cost_grad = std::numeric_limits<double>::quiet_NaN();
+    e.grad.assign(n, std::numeric_limits<double>::quiet_NaN());
+    e.ok_value = problem.function->Evaluate(x.data(), &e.cost_value, nullptr);  // T = double instantiation
+    e.ok_grad = problem.function->Evaluate(x.data(), &e.cost_grad, e.grad.data());  // T = Jet<double, 7>
+    log.entries.push_back(e);
+  }
+  if (summary) summary->final_cost = log.entries.empty() ? 0.0 : log.entries.front().cost_grad;
+}
+}  // namespace ceres
 
 // Iridescence's TURBO table is not available; the constructor's call (points_color_updater.cpp:34) gets a
 // placeholder, and the driver overwrites the public `intensity_colors` with the caller's colours
@@ -229,6 +257,81 @@ int ref_points_color_update(const char* model, const double* intr, int n_intr, c
   if (static_cast<int64_t>(colors.size()) != n) return -2;
   for (int64_t i = 0; i < n; i++)
     for (int k = 0; k < 4; k++) colors_out[4 * i + k] = colors[static_cast<size_t>(i)][k];
+  return 0;
+}
+
+namespace {
+// the dataset of a VisualCameraCalibration from flat arrays: n_pairs images (rows x cols, 8 bit) and clouds
+std::vector<vlcal::VisualLiDARData::ConstPtr> make_dataset(int n_pairs, const uint8_t* const* images, int rows, int cols, const double* const* points, const double* const* intensities,
+                                                           const int64_t* num_points) {
+  std::vector<vlcal::VisualLiDARData::ConstPtr> dataset;
+  for (int i = 0; i < n_pairs; i++) {
+    const cv::Mat img(rows, cols, CV_8UC1, const_cast<uint8_t*>(images[i]));
+    dataset.emplace_back(std::make_shared<vlcal::VisualLiDARData>(img.clone(), make_frame(points[i], intensities[i], num_points[i])));
+  }
+  return dataset;
+}
+}  // namespace
+
+// vlcal::VisualCameraCalibration::calibrate with registration_type NID_NELDER_MEAD: the reference's own outer loop
+// (visual_camera_calibration.cpp:35-68) around its Nelder-Mead inner solve (:70-139).  T_in / T_out: row-major 4x4
+// T_camera_lidar.  Returns the number of callback invocations (new best cost found).
+int ref_calibrate_nelder_mead(const char* model, const double* intr, int n_intr, const double* dist, int n_dist, int n_pairs, const uint8_t* const* images, int rows, int cols,
+                              const double* const* points, const double* const* intensities, const int64_t* num_points, int bins, int max_outer_iterations, int max_inner_iterations,
+                              double init_step, double convergence, int disable_culling, const double* T_in, double* T_out) {
+  auto cam = make_camera(model, intr, n_intr, dist, n_dist);
+  if (!cam) return -1;
+  int callbacks = 0;
+  vlcal::VisualCameraCalibrationParams params;
+  params.registration_type = vlcal::RegistrationType::NID_NELDER_MEAD;
+  params.nid_bins = bins;
+  params.max_outer_iterations = max_outer_iterations;
+  params.max_inner_iterations = max_inner_iterations;
+  params.nelder_mead_init_step = init_step;
+  params.nelder_mead_convergence_criteria = convergence;
+  params.disable_z_buffer_culling = disable_culling != 0;
+  params.callback = [&](const Eigen::Isometry3d&) { callbacks++; };
+  vlcal::VisualCameraCalibration calib(cam, make_dataset(n_pairs, images, rows, cols, points, intensities, num_points), params);
+  const Eigen::Isometry3d T = calib.calibrate(Eigen::Isometry3d::FromRowMajor(T_in));
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) T_out[i * 4 + j] = T(i, j);
+  return callbacks;
+}
+
+// The reference's MultiNIDCost functor (a struct private to visual_camera_calibration.cpp:141-178), reached through
+// estimate_pose_bfgs: view culling at T_init, NIDCost per pair, MultiNIDCost(init) wrapped in
+// AutoDiffFirstOrderFunction<MultiNIDCost, 7>, handed to ceres::Solve -- which in this build only evaluates at the
+// start and at the `n_probes` probe parameter vectors ([qx qy qz qw tx ty tz], 7 doubles each) and records.
+// Outputs per evaluated point (1 + n_probes): ok_value, ok_grad (0/1), cost_value, cost_grad, grad[7].
+int ref_multi_nid_cost_probes(const char* model, const double* intr, int n_intr, const double* dist, int n_dist, int n_pairs, const uint8_t* const* images, int rows, int cols,
+                              const double* const* points, const double* const* intensities, const int64_t* num_points, int bins, int disable_culling, const double* T_init,
+                              const double* probes, int n_probes, int* ok_value, int* ok_grad, double* cost_value, double* cost_grad, double* grads, double* start_params) {
+  auto cam = make_camera(model, intr, n_intr, dist, n_dist);
+  if (!cam) return -1;
+  ceres::ProbeLog& log = ceres::probe_log();
+  log.probes.clear();
+  log.entries.clear();
+  for (int k = 0; k < n_probes; k++) log.probes.emplace_back(probes + 7 * k, probes + 7 * k + 7);
+  vlcal::VisualCameraCalibrationParams params;
+  params.registration_type = vlcal::RegistrationType::NID_BFGS;
+  params.nid_bins = bins;
+  params.max_outer_iterations = 1;
+  params.disable_z_buffer_culling = disable_culling != 0;
+  params.callback = [](const Eigen::Isometry3d&) {};
+  vlcal::VisualCameraCalibration calib(cam, make_dataset(n_pairs, images, rows, cols, points, intensities, num_points), params);
+  calib.calibrate(Eigen::Isometry3d::FromRowMajor(T_init));
+  if (static_cast<int>(log.entries.size()) != n_probes + 1) return -2;
+  for (int k = 0; k <= n_probes; k++) {
+    const auto& e = log.entries[static_cast<size_t>(k)];
+    ok_value[k] = e.ok_value ? 1 : 0;
+    ok_grad[k] = e.ok_grad ? 1 : 0;
+    cost_value[k] = e.cost_value;
+    cost_grad[k] = e.cost_grad;
+    for (int i = 0; i < 7; i++) grads[7 * k + i] = e.grad[static_cast<size_t>(i)];
+  }
+  // the starting parameters the reference derived from the 4x4 (Sophus::SE3d(matrix).data())
+  const Sophus::SE3d start(Eigen::Isometry3d::FromRowMajor(T_init).matrix());
+  for (int i = 0; i < 7; i++) start_params[i] = start.data()[i];
   return 0;
 }
 

@@ -1,6 +1,8 @@
 // TEST INFRASTRUCTURE ONLY -- stand-in for Iridescence's guik::LightViewer: invoke() runs the task at once
 // (the real viewer queues it for its render thread).
 #pragma once
+#include <string>
+
 #include <glk/pointcloud_buffer.hpp>
 
 namespace guik {
@@ -12,5 +14,6 @@ public:
   }
   template <typename F>
   void invoke(const F& f) { f(); }
+  void append_text(const std::string&) {}
 };
 }  // namespace guik

@@ -50,6 +50,16 @@ public:
   T* ptr(int y = 0) { return reinterpret_cast<T*>(data + size_t(y) * step); }
   template <typename T>
   const T* ptr(int y = 0) const { return reinterpret_cast<const T*>(data + size_t(y) * step); }
+  // convertTo(dst, CV_64FC1, alpha) from 8-bit: saturate_cast<double>(src * alpha)
+  void convertTo(Mat& dst, int rtype, double alpha = 1.0) const {
+    dst = Mat(rows, cols, rtype);
+    for (int y = 0; y < rows; y++)
+      for (int x = 0; x < cols; x++) {
+        const double v = (type_ == CV_8UC1 ? double(at<unsigned char>(y, x)) : at<double>(y, x)) * alpha;
+        if (rtype == CV_64FC1) dst.at<double>(y, x) = v;
+        else dst.at<unsigned char>(y, x) = static_cast<unsigned char>(v);
+      }
+  }
   Mat clone() const {
     Mat m(rows, cols, type_);
     for (int y = 0; y < rows; y++) std::memcpy(m.data + size_t(y) * m.step, data + size_t(y) * step, m.step);

@@ -145,6 +145,54 @@ def points_color_update(model, intrinsics, distortion, image_u8, points, intensi
     return out, min_nz.value
 
 
+def _dataset_tables(pairs):
+    imgs = [np.ascontiguousarray(p[0], dtype=np.uint8) for p in pairs]
+    pts = [np.ascontiguousarray(p[1], dtype=np.float64) for p in pairs]
+    ints = [np.ascontiguousarray(p[2], dtype=np.float64) for p in pairs]
+    n = len(pairs)
+    u8p = ctypes.POINTER(ctypes.c_uint8)
+    img_tab = (u8p * n)(*[a.ctypes.data_as(u8p) for a in imgs])
+    pts_tab = (c_double_p * n)(*[_dp(a) for a in pts])
+    int_tab = (c_double_p * n)(*[_dp(a) for a in ints])
+    nums = np.array([a.shape[0] for a in pts], dtype=np.int64)
+    return imgs, pts, ints, img_tab, pts_tab, int_tab, nums
+
+
+def calibrate_nelder_mead(model, intrinsics, distortion, pairs, T_init, bins=16, max_outer_iterations=10, max_inner_iterations=256, init_step=1e-3, convergence=1e-8,
+                          disable_culling=False):
+    """vlcal::VisualCameraCalibration::calibrate (NID_NELDER_MEAD) from src/vlcal/calib/visual_camera_calibration.cpp.
+    pairs = [(image_u8, points (n,4), intensities), ...].  Returns (T_camera_lidar 4x4, number of callback calls)."""
+    imgs, pts, ints, img_tab, pts_tab, int_tab, nums = _dataset_tables(pairs)
+    T_init = np.ascontiguousarray(T_init, dtype=np.float64).reshape(4, 4)
+    T_out = np.empty((4, 4))
+    m, ip, ni, dp, nd, keep = _cam(model, intrinsics, distortion)
+    rc = lib().ref_calibrate_nelder_mead(m, ip, ni, dp, nd, ctypes.c_int(len(pairs)), img_tab, ctypes.c_int(imgs[0].shape[0]), ctypes.c_int(imgs[0].shape[1]), pts_tab, int_tab,
+                                         nums.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), ctypes.c_int(bins), ctypes.c_int(max_outer_iterations), ctypes.c_int(max_inner_iterations),
+                                         ctypes.c_double(init_step), ctypes.c_double(convergence), ctypes.c_int(1 if disable_culling else 0), _dp(T_init), _dp(T_out))
+    if rc < 0:
+        raise ValueError("reference build: bad camera model")
+    return T_out, rc
+
+
+def multi_nid_cost_probes(model, intrinsics, distortion, pairs, T_init, probes, bins=16, disable_culling=False):
+    """The reference's MultiNIDCost (private to visual_camera_calibration.cpp) evaluated through its own
+    estimate_pose_bfgs wiring at the start and at `probes` ((k, 7) parameter vectors).  Returns a dict of arrays
+    over the 1 + k points: ok_value, ok_grad, cost_value, cost_grad, grad (.., 7) and the 7 start parameters."""
+    imgs, pts, ints, img_tab, pts_tab, int_tab, nums = _dataset_tables(pairs)
+    T_init = np.ascontiguousarray(T_init, dtype=np.float64).reshape(4, 4)
+    probes = np.ascontiguousarray(probes, dtype=np.float64).reshape(-1, 7)
+    k = probes.shape[0] + 1
+    okv, okg = np.zeros(k, dtype=np.int32), np.zeros(k, dtype=np.int32)
+    cv, cg, grads, start = np.empty(k), np.empty(k), np.empty((k, 7)), np.empty(7)
+    m, ip, ni, dp, nd, keep = _cam(model, intrinsics, distortion)
+    rc = lib().ref_multi_nid_cost_probes(m, ip, ni, dp, nd, ctypes.c_int(len(pairs)), img_tab, ctypes.c_int(imgs[0].shape[0]), ctypes.c_int(imgs[0].shape[1]), pts_tab, int_tab,
+                                         nums.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), ctypes.c_int(bins), ctypes.c_int(1 if disable_culling else 0), _dp(T_init), _dp(probes),
+                                         ctypes.c_int(probes.shape[0]), okv.ctypes.data_as(c_int_p), okg.ctypes.data_as(c_int_p), _dp(cv), _dp(cg), _dp(grads), _dp(start))
+    if rc != 0:
+        raise ValueError(f"reference build: multi_nid_cost_probes failed ({rc})")
+    return dict(ok_value=okv.astype(bool), ok_grad=okg.astype(bool), cost_value=cv, cost_grad=cg, grad=grads, start=start)
+
+
 _NM_FN = ctypes.CFUNCTYPE(ctypes.c_double, c_double_p, ctypes.c_void_p)
 
 

@@ -25,8 +25,8 @@ class OracleNearest:
         return oracle_lib.cost_calculator_nid(*self.a, T)[0]
 
 
-def oracle_cull(s):
-    return lambda pts, ints, T: oracle_lib.view_culling(s.model, s.intrinsics, s.distortion, s.width, s.height, pts, T, True)
+def oracle_cull(s, depth=True):
+    return lambda pts, ints, T: oracle_lib.view_culling(s.model, s.intrinsics, s.distortion, s.width, s.height, pts, T, depth)
 
 
 def run_oracle(s, reg, bins, n_outer=3):

@@ -155,6 +155,76 @@ def test_points_color_updater_identical(model):
     assert (c_ref[:, 3] > 0).mean() > 0.1 and np.all(c_ref[9] == c_orc[9])
 
 
+def _bags(n_bags, n_points, seed, init_delta):
+    return [synth.make_scene(CAMERAS["plumb_bob"], num_points=n_points, seed=seed + k, init_delta=init_delta) for k in range(n_bags)]
+
+
+def test_multi_nid_cost_functor_and_trust_gate_identical():
+    """The reference's MultiNIDCost (visual_camera_calibration.cpp:141-178: trust gate 0.2 m / 2 deg on
+    init^-1 * T, per-pair NIDCost, plain sum, false if any pair failed) reached through its own
+    estimate_pose_bfgs wiring (view culling at the initial pose, convertTo(CV_64FC1, 1/255), NIDCost per pair,
+    AutoDiffFirstOrderFunction<MultiNIDCost, 7>); ceres::Solve is the evaluate-and-record stand-in."""
+    bags = _bags(2, 6000, 50, (0.02, 0.4))
+    s = bags[0]
+    T = se3.to_matrix(s.T_camera_lidar_init)
+    pairs = [(b.image_u8, b.points, b.intensities) for b in bags]
+    x0 = se3.from_matrix(T)
+    rng = np.random.default_rng(0)
+    probes = [se3.plus(x0, rng.uniform(-1, 1, 6) * np.array([0.01, 0.01, 0.01, 0.004, 0.004, 0.004])) for _ in range(4)]
+    probes.append(se3.plus(x0, np.array([0.19, 0, 0, 0, 0, 0])))        # just inside the 0.2 m gate
+    probes.append(se3.plus(x0, np.array([0.25, 0, 0, 0, 0, 0])))        # outside
+    probes.append(se3.plus(x0, np.array([0, 0, 0, 0, 0.034, 0])))       # 1.95 deg: inside the 2 deg gate
+    probes.append(se3.plus(x0, np.array([0, 0, 0, 0.05, 0, 0])))        # 2.9 deg: outside
+    q = np.array(probes[0])
+    q[:4] *= 1.0002                                                       # un-normalised quaternion
+    probes.append(q)
+    for bins, depth in ((16, True), (64, False)):
+        r = ref_lib.multi_nid_cost_probes(s.model, s.intrinsics, s.distortion, pairs, T, probes, bins=bins, disable_culling=not depth)
+        assert np.allclose(r["start"], x0, rtol=0, atol=1e-15)  # Sophus::SE3d(matrix).data() vs se3.from_matrix
+        culled = []
+        for b in bags:
+            idx = oracle_lib.view_culling(s.model, s.intrinsics, s.distortion, s.width, s.height, b.points, T, depth)
+            culled.append((b.image_u8.astype(np.float64) * (1.0 / 255.0), b.points[idx], b.intensities[idx]))
+        oks = []
+        for k, x in enumerate([r["start"]] + probes):
+            ok, c, g = oracle_lib.multi_nid_cost(s.model, s.intrinsics, s.distortion, culled, bins, r["start"], x)
+            okd, cd, _ = oracle_lib.multi_nid_cost(s.model, s.intrinsics, s.distortion, culled, bins, r["start"], x, want_grad=False)
+            assert bool(r["ok_grad"][k]) == ok and bool(r["ok_value"][k]) == okd
+            oks.append(ok)
+            if ok:
+                assert r["cost_grad"][k] == c and same(r["grad"][k], g)
+                assert r["cost_value"][k] == cd
+        assert oks == [True] * 6 + [False, True, False, True]
+
+
+@pytest.mark.parametrize("n_bags,init_delta,disable_culling", [(1, (0.02, 0.4), False), (2, (0.03, 1.5), False), (2, (0.03, 1.5), True)])
+def test_outer_loop_with_nelder_mead_identical(n_bags, init_delta, disable_culling):
+    """vlcal::VisualCameraCalibration::calibrate with NID_NELDER_MEAD compiled from the reference
+    (visual_camera_calibration.cpp:35-68 outer loop, :70-139 inner solve: culling per outer iteration,
+    CostCalculatorNID per pair, init * Pose3::Expmap(x), dfo::NelderMead<6>) against this repository's host
+    driver (calibration.VisualCameraCalibration + dfo.NelderMead + se3.pose3_expmap) running on the oracle."""
+    from direct_visual_lidar_calibration_amd import calibration
+    from test_calibration import OracleNearest, oracle_cull
+
+    bags = _bags(n_bags, 5000, 60, init_delta)
+    s = bags[0]
+    T = se3.to_matrix(s.T_camera_lidar_init)
+    pairs = [(b.image_u8, b.points, b.intensities) for b in bags]
+    T_ref, n_cb = ref_lib.calibrate_nelder_mead(s.model, s.intrinsics, s.distortion, pairs, T, bins=16, disable_culling=disable_culling)
+    max_fov = oracle_lib.estimate_camera_fov(s.model, s.intrinsics, s.distortion, s.width, s.height)
+    calls = [0]
+    p = calibration.VisualCameraCalibrationParams(nid_bins=16, registration_type="nid_nelder_mead", disable_z_buffer_culling=disable_culling)
+    cull = oracle_cull(s, depth=not disable_culling)
+    cal = calibration.VisualCameraCalibration(pairs, p, nearest_cost_factory=lambda i, pt, it, b: OracleNearest(s, i, pt, it, b, max_fov), cull=cull,
+                                              callback=lambda x: calls.__setitem__(0, calls[0] + 1))
+    x = cal.calibrate(se3.from_matrix(T))
+    dt, dr = se3.delta_trans_rot(se3.from_matrix(T_ref), x)
+    assert dt <= 1e-9 and dr <= 1e-9, (dt, dr, cal.log)
+    assert calls[0] == n_cb
+    if init_delta[1] > 1.0:
+        assert len(cal.log) >= 2  # the outer loop did go round again
+
+
 def test_nelder_mead_trajectory_identical():
     def rosen2(x):
         return (1 - x[0]) ** 2 + 100 * (x[1] - x[0] ** 2) ** 2
