@@ -56,8 +56,11 @@ for k, (model, intr, dist, W, H, bins, n, seed) in enumerate(CASES):
     csel = np.concatenate([np.arange(0, ncol), np.arange(pts.shape[0] - 100, pts.shape[0])])
     icol = (np.floor(rng.random((csel.shape[0], 4)) * 64) / 64).astype(np.float32)
     colors, min_nz = ref_lib.points_color_update(model, intr, dist, s.image_u8, pts[csel], icol, T, 0.7)
+    # the reference's whole calibrate() (outer loop + Nelder-Mead inner solve) on this bag, from its own source
+    T_nm, n_callbacks = ref_lib.calibrate_nelder_mead(model, intr, dist, [(s.image_u8, pts, inten)], T, bins=min(bins, 64))
     p = f"c{k}_"
     out.update({
+        p + "ref_nm_T_camera_lidar": T_nm, p + "ref_nm_callbacks": np.array(n_callbacks), p + "nm_bins": np.array(min(bins, 64)),
         p + "color_points": csel, p + "intensity_colors": icol, p + "ref_colors": colors, p + "ref_min_nz": np.array(min_nz),
         p + "model": np.array(model), p + "intrinsics": np.array(intr), p + "distortion": np.array(dist, dtype=np.float64), p + "size": np.array([W, H]), p + "bins": np.array(bins),
         p + "image_u8": s.image_u8, p + "xyz": xyz, p + "intensities": inten, p + "num_cost_points": np.array(n_cost), p + "se3": x,
