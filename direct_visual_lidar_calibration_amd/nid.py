@@ -307,9 +307,12 @@ def estimate_direction(proj, pt_2d, device=0):
     """estimate_fov.cpp:17-34: invert the projection at one pixel with NelderMead<2> defaults."""
 
     def to_dir(x):
-        sa, ca = math.sin(x[0]), math.cos(x[0])
-        sb, cb = math.sin(x[1]), math.cos(x[1])
-        return np.array([sb, -sa * cb, ca * cb])  # AngleAxis(x0, X) * AngleAxis(x1, Y) * UnitZ
+        # AngleAxis(x0, X) * AngleAxis(x1, Y) * UnitZ through quaternions, as Eigen evaluates it
+        aw, ax = math.cos(0.5 * x[0]), math.sin(0.5 * x[0])
+        bw, by = math.cos(0.5 * x[1]), math.sin(0.5 * x[1])
+        qw, qx, qy, qz = aw * bw, ax * bw, aw * by, ax * by
+        ux, uy, uz = 2.0 * qy, -2.0 * qx, 0.0  # 2 (vec x ez)
+        return np.array([qw * ux + (qy * uz - qz * uy), qw * uy + (qz * ux - qx * uz), (1.0 + qw * uz) + (qx * uy - qy * ux)])
 
     def f(x):
         uv = proj.project(to_dir(x), device=device)

@@ -387,11 +387,24 @@ static NMResult nelder_mead_ref(int N, const NMParams& params, const std::functi
 
 // estimate_fov.cpp:17-34
 static V3<double> estimate_direction_ref(const CameraBase* proj, double u, double v) {
-  // AngleAxis(x0, UnitX) * AngleAxis(x1, UnitY) * UnitZ
+  // AngleAxis(x0, UnitX) * AngleAxis(x1, UnitY) * UnitZ, evaluated the way Eigen does: each AngleAxis becomes a
+  // quaternion (w = cos(angle/2), vec = sin(angle/2) axis), the two are multiplied (generic quaternion product),
+  // and the product rotates UnitZ by uv = vec x v; uv += uv; v + w uv + vec x uv
   const auto to_dir = [](const double* x) {
-    const double sa = std::sin(x[0]), ca = std::cos(x[0]);
-    const double sb = std::sin(x[1]), cb = std::cos(x[1]);
-    return V3<double>{sb, -sa * cb, ca * cb};
+    const double ha = 0.5 * x[0], hb = 0.5 * x[1];
+    const double aw = std::cos(ha), sa = std::sin(ha), bw = std::cos(hb), sb = std::sin(hb);
+    const double ax = sa * 1.0, ay = sa * 0.0, az = sa * 0.0;
+    const double bx = sb * 0.0, by = sb * 1.0, bz = sb * 0.0;
+    const double qw = aw * bw - ax * bx - ay * by - az * bz;
+    const double qx = aw * bx + ax * bw + ay * bz - az * by;
+    const double qy = aw * by + ay * bw + az * bx - ax * bz;
+    const double qz = aw * bz + az * bw + ax * by - ay * bx;
+    const double v[3] = {0.0, 0.0, 1.0};
+    double ux = qy * v[2] - qz * v[1], uy = qz * v[0] - qx * v[2], uz = qx * v[1] - qy * v[0];
+    ux += ux;
+    uy += uy;
+    uz += uz;
+    return V3<double>{(v[0] + qw * ux) + (qy * uz - qz * uy), (v[1] + qw * uy) + (qz * ux - qx * uz), (v[2] + qw * uz) + (qx * uy - qy * ux)};
   };
   const auto f = [&](const double* x) {
     const V3<double> dir = to_dir(x);

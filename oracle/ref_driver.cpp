@@ -11,8 +11,8 @@
 // src/vlcal/calib/visual_camera_calibration.cpp (outer loop, Nelder-Mead inner solve, MultiNIDCost; its BFGS solve
 // needs Ceres: ceres::Solve is an evaluate-and-record stand-in, gtsam::Pose3::Expmap / Sophus::SE3d restated); header-only:
 // include/camera/*.hpp, include/vlcal/costs/nid_cost.hpp, include/dfo/nelder_mead.hpp.
-// NOT compiled: src/vlcal/common/estimate_fov.cpp (needs PCL for estimate_lidar_fov) -- its two camera
-// functions (:17-51) are restated below on top of the reference's own dfo::NelderMead<2>.
+// src/vlcal/common/estimate_fov.cpp is compiled too (estimate_direction / estimate_camera_fov, :17-51, are what the
+// path uses; its estimate_lidar_fov needs PCL, whose stand-ins only make the file compile).
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -66,38 +66,6 @@ namespace vlcal {
 
 // visual_lidar_data.cpp:29 (that file also holds the PNG / PLY loading constructor: not compiled)
 VisualLiDARData::~VisualLiDARData() {}
-
-// estimate_fov.cpp:17-35.  AngleAxisd(x0, UnitX) * AngleAxisd(x1, UnitY) * UnitZ written out:
-// Ry(b) ez = (sin b, 0, cos b);  Rx(a) (x, y, z) = (x, cos a y - sin a z, sin a y + cos a z)
-Eigen::Vector3d estimate_direction(const camera::GenericCameraBase::ConstPtr& proj, const Eigen::Vector2d& pt_2d) {
-  const auto to_dir = [](const Eigen::Vector2d& x) {
-    const double sa = std::sin(x[0]), ca = std::cos(x[0]), sb = std::sin(x[1]), cb = std::cos(x[1]);
-    return Eigen::Vector3d(sb, -sa * cb, ca * cb);
-  };
-  const auto f = [&](const Eigen::Vector2d& x) {
-    const Eigen::Vector3d dir = to_dir(x);
-    const double err = (pt_2d - proj->project(dir)).squaredNorm();
-    return std::isfinite(err) ? err : std::numeric_limits<double>::max();
-  };
-  dfo::NelderMead<2>::Params params;
-  dfo::NelderMead<2> optimizer(params);
-  auto result = optimizer.optimize(f, Eigen::Vector2d::Zero());
-  return to_dir(result.x);
-}
-
-// estimate_fov.cpp:36-51
-double estimate_camera_fov(const camera::GenericCameraBase::ConstPtr& proj, const Eigen::Vector2i& image_size) {
-  const std::vector<Eigen::Vector2d> target_corners = {Eigen::Vector2d(0.0, 0.0), Eigen::Vector2d(image_size[0] / 2, 0.0), Eigen::Vector2d(0.0, image_size[1] / 2)};
-  double max_fov = 0.0;
-  for (const auto& corner : target_corners) {
-    const auto dir = estimate_direction(proj, corner);
-    const double fov = std::acos(dir.normalized().z());
-    if (fov > max_fov) {
-      max_fov = fov;
-    }
-  }
-  return max_fov;
-}
 
 }  // namespace vlcal
 
