@@ -595,9 +595,18 @@ NID_HD void transform_fma(const PoseParams<real>& pose, real x, real y, real z, 
 // weight -> unsigned fixed point with `frac` fractional bits in ONE instruction: the x-weights are
 // pre-multiplied by dn = 2^(frac - 1074), so the product bxs * by is a SUBNORMAL double whose bit
 // pattern (exponent field 0) IS the integer round-to-nearest(bx' * by * 2^frac) -- no magic add, no mask.
-// (bx' = bx rounded to 2^-frac by the pre-scaling: total quantisation <= 0.75 units of 2^-frac instead
-// of 0.5; still deterministic and order independent.)  gfx950 handles fp64 denormals at full rate.
-__device__ __forceinline__ u64 to_fixed_dn(double bx_scaled, double by) { return u64(__double_as_longlong(bx_scaled * by)); }
+// (bx' = bx rounded to 2^-frac by the pre-scaling: total quantisation <= 0.5 max(by) + 0.5 = 0.84 units of
+// 2^-frac instead of 0.5 -- checked on the host by tests/cxx/test_device_math.cpp; still deterministic and order independent.)  gfx950 handles fp64 denormals at full rate.
+NID_HD u64 to_fixed_dn(double bx_scaled, double by) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return u64(__double_as_longlong(bx_scaled * by));
+#else
+  const double p = bx_scaled * by;  // host build (tests): same IEEE product, subnormals honoured by default on x86-64
+  u64 bits;
+  __builtin_memcpy(&bits, &p, sizeof bits);
+  return bits;
+#endif
+}
 
 
 // The bin image is stored in STRIPS of four rows with the four vertically adjacent pixels of a
@@ -608,16 +617,24 @@ __device__ __forceinline__ u64 to_fixed_dn(double bx_scaled, double by) { return
 struct __attribute__((aligned(4))) StripQuad {
   uint32_t c[4];
 };
-__device__ __forceinline__ void load_patch(const uint8_t* __restrict__ img, int pitch, int kx, int ky, uint32_t* cols) {
+// v_alignbyte_b32: bytes [sh, sh + 3] of the 8-byte value hi:lo
+NID_HD uint32_t align_bytes(uint32_t hi, uint32_t lo, uint32_t sh) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_alignbyte(hi, lo, sh);
+#else
+  return uint32_t(((uint64_t(hi) << 32) | lo) >> (8u * (sh & 3u)));
+#endif
+}
+NID_HD void load_patch(const uint8_t* __restrict__ img, int pitch, int kx, int ky, uint32_t* cols) {
   const uint32_t stride = uint32_t(pitch) * 4u;
   const uint32_t base = (uint32_t(ky) >> 2) * stride + uint32_t(kx) * 4u;
   const StripQuad s0 = *reinterpret_cast<const StripQuad*>(img + base);
   const StripQuad s1 = *reinterpret_cast<const StripQuad*>(img + base + stride);
   const uint32_t sh = uint32_t(ky) & 3u;
 #pragma unroll
-  for (int a = 0; a < 4; a++) cols[a] = __builtin_amdgcn_alignbyte(s1.c[a], s0.c[a], sh);
+  for (int a = 0; a < 4; a++) cols[a] = align_bytes(s1.c[a], s0.c[a], sh);
 }
-__device__ __forceinline__ uint32_t load_pixel(const uint8_t* __restrict__ img, int pitch, int x, int y) {
+NID_HD uint32_t load_pixel(const uint8_t* __restrict__ img, int pitch, int x, int y) {
   return img[(uint32_t(y) >> 2) * uint32_t(pitch) * 4u + uint32_t(x) * 4u + (uint32_t(y) & 3u)];
 }
 

@@ -6,7 +6,9 @@
 // Prints one line per model: max |uv - uv_ref| (pixels), max relative Jacobian error; exit 1 on failure.
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <random>
+#include <vector>
 
 #include "../../direct_visual_lidar_calibration_amd/csrc/nid_device.hpp"
 #include "../../oracle/cameras.hpp"
@@ -163,6 +165,63 @@ int main() {
     }
     std::printf("transform_fma max err %.3g\n", et);
     if (et > 2e-14) bad++;
+  }
+  // fixed point in one multiply (to_fixed_dn): x-weights pre-scaled by 2^(frac - 1074), so that bits(bx' * by) is
+  // the integer round(bx' * by * 2^frac); error <= 0.5 max(by) + 0.5 = 0.834 units of 2^-frac, exact zeros, sign bit never set
+  {
+    std::mt19937_64 rng(11);
+    std::uniform_real_distribution<double> U(0.0, 1.0);
+    double worst = 0, worst_sum = 0;
+    for (int frac = 34; frac <= 40; frac += 2) {
+      const double dn = std::ldexp(1.0, frac - 1074), unit = std::ldexp(1.0, frac);
+      for (int i = 0; i < 200000; i++) {
+        double bx[4], by[4];
+        bspline<double>(i == 0 ? 0.0 : (i == 1 ? std::nextafter(1.0, 0.0) : U(rng)), bx);
+        bspline<double>(i == 2 ? 0.0 : U(rng), by);
+        double sum = 0;
+        for (int a = 0; a < 4; a++) {
+          const double bxs = bx[a] * dn;
+          for (int b = 0; b < 4; b++) {
+            const u64 bits = to_fixed_dn(bxs, by[b]);
+            if (bits >> 63) bad++;
+            worst = std::fmax(worst, std::fabs(double(bits) - bx[a] * by[b] * unit));
+            sum += double(bits);
+          }
+        }
+        worst_sum = std::fmax(worst_sum, std::fabs(sum - unit));  // partition of unity: 16 taps add up to 1.0
+      }
+      if (to_fixed_dn(0.0 * dn, 0.7) != 0 || to_fixed_dn(0.3 * dn, 0.0) != 0 || to_fixed_dn(0.5 * 0.0, 0.25) != 0) bad++;  // outliers add exact zeros
+    }
+    std::printf("to_fixed_dn: max |fixed - exact| %.3f units, max |sum of 16 taps - 1| %.1f units\n", worst, worst_sum);
+    if (worst > 0.8334 || worst_sum > 12.0) bad++;
+  }
+  // strip-tiled padded bin image: padded pixel (x, y) at (y >> 2) * 4 * pitch + 4 x + (y & 3); load_patch returns, for
+  // knot (kx, ky), byte b of cols[a] = padded pixel (kx + a, ky + b) = source pixel (clamp(kx + a - 1), clamp(ky + b - 1))
+  {
+    const int W = 53, H = 38;
+    const int pitch = ((W + 8) + 3) & ~3, nstrips = (H + 3 + 3) / 4 + 1;
+    std::mt19937 rng(12);
+    std::vector<uint8_t> src(size_t(W) * H), img(size_t(pitch) * 4 * nstrips + 64, 0);
+    for (auto& v : src) v = uint8_t(rng() & 255);
+    for (int py = 0; py < nstrips * 4; py++)
+      for (int px = 0; px < pitch; px++) {
+        const int sy = std::min(std::max(py - 1, 0), H - 1), sx = std::min(std::max(px - 1, 0), W - 1);
+        img[size_t(py >> 2) * pitch * 4 + size_t(px) * 4 + (py & 3)] = src[size_t(sy) * W + sx];
+      }
+    int wrong = 0;
+    for (int ky = 0; ky < H; ky++)
+      for (int kx = 0; kx < W; kx++) {
+        uint32_t cols[4];
+        load_patch(img.data(), pitch, kx, ky, cols);
+        for (int a = 0; a < 4; a++)
+          for (int b = 0; b < 4; b++) {
+            const int sx = std::min(std::max(kx + a - 1, 0), W - 1), sy = std::min(std::max(ky + b - 1, 0), H - 1);
+            if (((cols[a] >> (8 * b)) & 0xffu) != src[size_t(sy) * W + sx]) wrong++;
+          }
+        if (load_pixel(img.data(), pitch, kx + 1, ky + 1) != src[size_t(ky) * W + kx]) wrong++;
+      }
+    std::printf("load_patch / load_pixel on the strip-tiled image: %d mismatches\n", wrong);
+    if (wrong) bad++;
   }
   // FP32 geometry instantiation of the projections (NIDREG_PREC_FP32): float-accurate against the oracle
   {
