@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--mode", default="pairs", choices=["pairs", "shard"])
     ap.add_argument("--columns-per-group", type=int, default=0)
     ap.add_argument("--target-blocks", type=int, default=0)
-    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="points of the workload the CPU oracle is timed on (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="points of the workload the CPU oracle is timed on (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -243,9 +243,9 @@ def main():
         img64 = scene.image_f64
         ts = []
         t_budget = time.time()
-        for k in range(5):
+        for k in range(8):  # ~10 s of CPU work on the default sample (2M points x 8 evaluations), capped at 25 s
             t1 = time.perf_counter()
-            r = oracle_lib.nid_cost(scene.model, scene.intrinsics, scene.distortion, img64, sp, si, args.bins, poses[k], want_grad=True, threads=1)
+            r = oracle_lib.nid_cost(scene.model, scene.intrinsics, scene.distortion, img64, sp, si, args.bins, poses[k % len(poses)], want_grad=True, threads=1)
             ts.append(time.perf_counter() - t1)
             if time.time() - t_budget > 25.0:
                 break
