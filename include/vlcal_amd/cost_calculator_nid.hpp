@@ -11,6 +11,7 @@
 #include "camera.hpp"
 #ifdef NIDREG_WITH_REFERENCE_DEPS
 #include <Eigen/Geometry>
+#include <vlcal/common/estimate_fov.hpp>
 #include <vlcal/common/visual_lidar_data.hpp>
 #endif
 
@@ -33,6 +34,12 @@ struct NIDCostParams {
 
 class CostCalculatorNID : public CostCalculator {
 public:
+#ifdef NIDREG_WITH_REFERENCE_DEPS
+  // the reference's own constructor signature (cost_calculator_nid.hpp:20, cost_calculator_nid.cpp:13-17):
+  // max_fov from the reference's estimate_camera_fov, so visual_camera_calibration.cpp:84 compiles unchanged
+  CostCalculatorNID(const camera::GenericCameraBase::ConstPtr& proj, const VisualLiDARData::ConstPtr& data, const NIDCostParams& params = NIDCostParams())
+  : CostCalculatorNID(proj, data, params, estimate_camera_fov(proj, {data->image.cols, data->image.rows})) {}
+#endif
   CostCalculatorNID(const camera::GenericCameraBase::ConstPtr& proj, const VisualLiDARData::ConstPtr& data, const NIDCostParams& params, const double max_fov,
                     const int device_id = 0, const int precision = NIDREG_PREC_FP64)
   {

@@ -15,8 +15,12 @@
 
 #include "camera.hpp"
 #ifdef NIDREG_WITH_REFERENCE_DEPS
+#include <cmath>
+
 #include <Eigen/Geometry>
+#include <vlcal/common/estimate_fov.hpp>
 #include <vlcal/common/frame.hpp>
+#include <vlcal/common/frame_cpu.hpp>
 #endif
 
 namespace vlcal {
@@ -31,6 +35,13 @@ class ViewCulling {
 public:
   ViewCulling(const camera::GenericCameraBase::ConstPtr& proj, const int width, const int height, const ViewCullingParams& params, const double min_z, const int device_id = 0)
   : params(params), proj(proj), width(width), height(height), min_z(min_z), device_id(device_id) {}
+#ifdef NIDREG_WITH_REFERENCE_DEPS
+  // the reference's own signatures (view_culling.hpp:23-27): min_z from the reference's estimate_camera_fov and
+  // cull() = sample(points, surviving indices), so visual_camera_calibration.cpp:73,78,193,201 compile unchanged
+  ViewCulling(const camera::GenericCameraBase::ConstPtr& proj, const Eigen::Vector2i& image_size, const ViewCullingParams& params)
+  : ViewCulling(proj, image_size[0], image_size[1], params, std::cos(estimate_camera_fov(proj, image_size))) {}
+  FrameCPU::Ptr cull(const Frame::ConstPtr& points, const Eigen::Isometry3d& T_camera_lidar) const { return sample(points, cull_indices(points, T_camera_lidar)); }
+#endif
   ~ViewCulling() {}
 
   std::vector<int> cull_indices(const Frame::ConstPtr& points, const Eigen::Isometry3d& T_camera_lidar) const {

@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
 CSRC = os.path.join(ROOT, "direct_visual_lidar_calibration_amd", "csrc")
 EXE = os.path.join(ROOT, "tests", "cxx", "test_integration.bin")
+EXE_CAL = os.path.join(ROOT, "tests", "cxx", "test_integration_calibrate.bin")
 
 
 def build(scratch):
@@ -36,6 +37,56 @@ def build(scratch):
            "-L", CSRC, "-lnidreg", f"-Wl,-rpath,{CSRC}", "-o", EXE]
     subprocess.check_call(cmd)
     return EXE
+
+
+def build_calibrate(scratch):
+    """The reference's unmodified visual_camera_calibration.cpp against the drop-in headers (integration/include first)."""
+    build(scratch)  # patched camera headers + libnidreg.so
+    cmd = ["g++", "-std=c++17", "-O1", "-DNIDREG_WITH_REFERENCE_DEPS", "-Wno-sign-compare", "-Wl,--allow-multiple-definition",
+           "-I", os.path.join(scratch, "include"), "-I", os.path.join(ROOT, "integration", "include"), "-I", os.path.join(ROOT, "oracle", "shim"),
+           "-I", os.path.join(REF, "include"), "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "cxx", "test_integration_calibrate.cpp"), os.path.join(REF, "src", "vlcal", "calib", "visual_camera_calibration.cpp"),
+           os.path.join(REF, "src", "camera", "create_camera.cpp"), os.path.join(REF, "src", "vlcal", "common", "estimate_fov.cpp"),
+           "-L", CSRC, "-lnidreg", f"-Wl,-rpath,{CSRC}", "-o", EXE_CAL]
+    subprocess.check_call(cmd)
+    return EXE_CAL
+
+
+def test_reference_calibration_driver_compiles_against_the_dropin_headers(tmp_path):
+    """visual_camera_calibration.cpp, unmodified, with <vlcal/costs/nid_cost.hpp>, <vlcal/calib/cost_calculator_nid.hpp>
+    and <vlcal/calib/view_culling.hpp> forwarded to include/vlcal_amd/: the reference's constructor calls and functor
+    uses (:73-85, :147-173, :193-216) are source compatible with the drop-in classes, and the program links."""
+    if not os.path.isdir(os.path.join(REF, "include", "camera")):
+        pytest.skip("reference tree not present")
+    exe = build_calibrate(str(tmp_path))
+    assert os.path.exists(exe)
+    assert subprocess.run([exe]).returncode == 2  # usage error path: starts and exits without touching the GPU
+    from direct_visual_lidar_calibration_amd import _lib
+
+    if _lib.load().nidreg_device_count() == 0:
+        # without a GPU the reference's calibrate() runs up to its first engine call -- estimate_camera_fov through the
+        # reference's own Nelder-Mead and CPU projection, then ViewCulling through the drop-in -- and fails loudly there
+        r = subprocess.run([exe, _scene_file(tmp_path), "16"], capture_output=True, text=True)
+        assert r.returncode != 0 and "no HIP device" in r.stderr, (r.returncode, r.stderr[-300:])
+
+
+def _scene_file(tmp_path):
+    from test_reference_golden import CASES
+
+    c = CASES[0]
+    intr = np.zeros(5)
+    intr[: len(c["intrinsics"])] = c["intrinsics"]
+    dist = np.zeros(8)
+    dist[: len(c["distortion"])] = c["distortion"]
+    path = tmp_path / "scene_cal.bin"
+    with open(path, "wb") as f:
+        f.write(c["model"].encode().ljust(64, b"\0"))
+        f.write(struct.pack("<6i", c["W"], c["H"], c["points"].shape[0], int(c["nm_bins"]), len(c["intrinsics"]), len(c["distortion"])))
+        f.write(intr.tobytes() + dist.tobytes() + np.asarray(c["se3"], dtype=np.float64).tobytes() + struct.pack("<d", 0.0) + c["T"].astype(np.float64).tobytes())
+        f.write(np.ascontiguousarray(c["image_u8"]).tobytes())
+        f.write(np.ascontiguousarray(c["points"], dtype=np.float64).tobytes())
+        f.write(np.ascontiguousarray(c["intensities"], dtype=np.float64).tobytes())
+    return str(path)
 
 
 def test_patch_applies_builds_and_cameras_expose_parameters(tmp_path):
@@ -88,3 +139,24 @@ def test_reference_cameras_feed_the_gpu_cost(tmp_path):
         ref = oracle_lib.nid_cost(s.model, s.intrinsics, s.distortion, s.image_f64, s.points, s.intensities, bins, x)
         assert abs(vals[0] - ref["cost"]) <= 1e-10 and abs(vals[8] - ref["cost"]) <= 1e-10
         assert np.allclose(vals[1:8], ref["grad"], rtol=1e-7, atol=1e-10)
+
+
+@pytest.mark.gpu
+def test_reference_calibrate_drives_the_gpu_engine(tmp_path):
+    """The reference's own VisualCameraCalibration::calibrate (Nelder-Mead route) running on the GPU engine through the
+    drop-in headers ends where the reference's CPU build ends (fixture).  The binary is built where the reference tree
+    is mounted and travels with the snapshot.  Not yet run on a GPU (the round's GPU budget was spent when it was
+    written): opt in with NIDREG_RUN_UNVALIDATED=1."""
+    if not os.environ.get("NIDREG_RUN_UNVALIDATED"):
+        pytest.skip("not yet validated on a GPU; set NIDREG_RUN_UNVALIDATED=1 to run")
+    if not os.path.exists(EXE_CAL):
+        pytest.skip("tests/cxx/test_integration_calibrate.bin was not built (needs the reference tree)")
+    from direct_visual_lidar_calibration_amd import se3
+    from test_reference_golden import CASES
+
+    c = CASES[0]
+    path = _scene_file(tmp_path)
+    vals = [float(v) for v in subprocess.check_output([EXE_CAL, str(path), str(int(c["nm_bins"]))]).decode().split()]
+    T = np.array(vals[:16]).reshape(4, 4)
+    dt, dr = se3.delta_trans_rot(se3.from_matrix(c["ref_nm_T_camera_lidar"]), se3.from_matrix(T))
+    assert dt <= 1e-3 and dr <= 1e-3, (dt, dr)
