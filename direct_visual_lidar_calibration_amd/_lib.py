@@ -55,6 +55,8 @@ class NidregDesc(ctypes.Structure):
         ("ext_stream", ctypes.c_void_p),
         ("ext_hist", ctypes.c_void_p),
         ("ext_out", ctypes.c_void_p),
+        ("num_devices", ctypes.c_int32),
+        ("device_ids", ctypes.c_int32 * 16),
     ]
 
 
@@ -63,7 +65,7 @@ EXPORTS = [
     "nidreg_eval_iso_multi", "nidreg_get_hist", "nidreg_get_hist_fixed", "nidreg_project", "nidreg_project_model", "nidreg_view_culling", "nidreg_hist_words", "nidreg_shard_hist",
     "nidreg_shard_entropy", "nidreg_shard_grad", "nidreg_shard_finish", "nidreg_set_timing", "nidreg_get_timing", "nidreg_get_info", "nidreg_last_error",
     "nidreg_version", "nidreg_colorizer_create", "nidreg_colorizer_update", "nidreg_colorizer_device_colors", "nidreg_colorizer_destroy", "nidreg_generate_lidar_image",
-    "nidreg_equalize_intensities",
+    "nidreg_equalize_intensities", "nidreg_num_shards", "nidreg_shard_devices", "nidreg_trim", "nidreg_eval_batch",
 ]
 
 _lib = None
@@ -90,6 +92,7 @@ def load():
     lib.nidreg_create_from_cloud.argtypes = [ctypes.POINTER(NidregDesc), ctypes.c_void_p, c_double_p, ctypes.c_double, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
     lib.nidreg_eval.argtypes = [ctypes.c_void_p, c_double_p, c_double_p, c_double_p]
     lib.nidreg_eval_iso.argtypes = [ctypes.c_void_p, c_double_p, c_double_p]
+    lib.nidreg_eval_batch.argtypes = [ctypes.c_void_p, c_double_p, ctypes.c_int, c_double_p, c_double_p]
     lib.nidreg_eval_multi.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, c_double_p, c_double_p, c_double_p, c_double_p]
     lib.nidreg_eval_iso_multi.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, c_double_p, c_double_p]
     lib.nidreg_get_hist.argtypes = [ctypes.c_void_p, c_double_p, c_double_p, c_double_p]
@@ -117,8 +120,26 @@ def load():
     lib.nidreg_generate_lidar_image.argtypes = [ctypes.c_int, c_double_p, c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_double_p, ctypes.c_int64, c_double_p,
                                                 ctypes.c_int64, c_double_p, c_double_p, ctypes.POINTER(ctypes.c_int32)]
     lib.nidreg_equalize_intensities.argtypes = [ctypes.c_int, c_double_p, ctypes.c_int64]
+    lib.nidreg_num_shards.argtypes = [ctypes.c_void_p]
+    lib.nidreg_shard_devices.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+    lib.nidreg_trim.restype = None
+    lib.nidreg_trim.argtypes = []
     _lib = lib
     return lib
+
+
+def kernel_source_hash():
+    """sha256 (16 hex digits) over the sources libnidreg.so is built from: stamps PMC summaries so that bench.py never
+    reports counter traffic measured on a different kernel build."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(CSRC_DIR, "*.hip")) + glob.glob(os.path.join(CSRC_DIR, "*.hpp")) + [os.path.join(CSRC_DIR, "Makefile")]):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def last_error():

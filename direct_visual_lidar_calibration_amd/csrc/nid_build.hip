@@ -25,8 +25,8 @@ __device__ __forceinline__ int cast_int_dev(double d) {  // x86 cvttsd2si semant
 }
 
 __global__ __launch_bounds__(256) void k_build_keys(
-  const double* __restrict__ pts, const double* __restrict__ intensities, const unsigned char* __restrict__ keep, long long n, int B, int GW, unsigned long long* __restrict__ keys,
-  unsigned int* __restrict__ idx, int* __restrict__ not_lossless) {
+  const double* __restrict__ pts, const double* __restrict__ intensities, const unsigned char* __restrict__ keep, long long n, int B, int GW, int input_order,
+  unsigned long long* __restrict__ keys, unsigned int* __restrict__ idx, int* __restrict__ not_lossless) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   idx[i] = (unsigned int)i;
@@ -37,6 +37,10 @@ __global__ __launch_bounds__(256) void k_build_keys(
   const double x = pts[4 * i], y = pts[4 * i + 1], z = pts[4 * i + 2];
   if ((double(float(x)) != x && x == x) || (double(float(y)) != y && y == y) || (double(float(z)) != z && z == z)) *not_lossless = 1;
   const int b = max(0, min(B - 1, cast_int_dev(intensities[i] * double(B))));
+  if (input_order) {  // NIDREG_FLAG_INPUT_ORDER: the caller's order inside each column group
+    keys[i] = ((unsigned long long)(unsigned int)(b / GW) << 41) | (unsigned long long)(unsigned int)i;
+    return;
+  }
   const double az = atan2(y, x);
   const double el = atan2(z, sqrt(x * x + y * y));
   unsigned int qa = (unsigned int)fmin(65535.0, fmax(0.0, (az + 3.14159265358979323846) * (65535.0 / (2.0 * 3.14159265358979323846))));
@@ -45,7 +49,7 @@ __global__ __launch_bounds__(256) void k_build_keys(
   unsigned int m = 0;
 #pragma unroll
   for (int bb = 0; bb < 16; bb++) m |= (((qa >> bb) & 1u) << (2 * bb)) | (((qe >> bb) & 1u) << (2 * bb + 1));
-  // low 9 bits of the upper word carry the exact column (B <= 256) so the gather need not recompute it
+  // [column group : 23][column : 9][Morton code : 32]
   keys[i] = ((unsigned long long)(unsigned int)(b / GW) << 41) | ((unsigned long long)(unsigned int)b << 32) | m;
 }
 
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(256) void k_build_bounds(const unsigned long long* 
 }
 
 template <typename Rec>
-__global__ __launch_bounds__(256) void k_build_gather(const double* __restrict__ pts, const unsigned long long* __restrict__ keys, const unsigned int* __restrict__ idx, long long kept, Rec* __restrict__ recs) {
+__global__ __launch_bounds__(256) void k_build_gather(const double* __restrict__ pts, const double* __restrict__ intensities, const unsigned int* __restrict__ idx, long long kept, int B, Rec* __restrict__ recs) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= kept) return;
   const unsigned int s = idx[i];
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(256) void k_build_gather(const double* __restrict__
   r.x = decltype(r.x)(pts[4 * (long long)s]);
   r.y = decltype(r.y)(pts[4 * (long long)s + 1]);
   r.z = decltype(r.z)(pts[4 * (long long)s + 2]);
-  r.bin = decltype(r.bin)((keys[i] >> 32) & 0x1ffu);
+  r.bin = decltype(r.bin)(max(0, min(B - 1, cast_int_dev(intensities[s] * double(B)))));  // nid_cost.hpp:49, as in k_build_keys
   recs[i] = r;
 }
 
@@ -85,9 +89,57 @@ __global__ __launch_bounds__(256) void k_build_gather(const double* __restrict__
     if (e != hipSuccess) goto done; \
   } while (0)
 
+// ---- scratch arena ------------------------------------------------------------------------
+ScratchArena& ScratchArena::of(int device) {
+  static ScratchArena arenas[64];
+  return arenas[device >= 0 && device < 64 ? device : 0];
+}
+hipError_t ScratchArena::reserve(size_t bytes) {
+  cur_ = 0;
+  if (bytes <= cap_) return hipSuccess;
+  if (base_) (void)hipFree(base_);
+  base_ = nullptr;
+  cap_ = 0;
+  const size_t want = bytes + bytes / 8 + (1u << 20);  // head-room: the next outer iteration's cloud is about the same size
+  hipError_t e = hipMalloc(&base_, want);
+  if (e != hipSuccess) return e;
+  cap_ = want;
+  return hipSuccess;
+}
+void* ScratchArena::carve(size_t bytes) {
+  const size_t at = (cur_ + 255) & ~size_t(255);
+  if (at + bytes > cap_) return nullptr;
+  cur_ = at + bytes;
+  return static_cast<char*>(base_) + at;
+}
+void ScratchArena::release() {
+  if (base_) (void)hipFree(base_);
+  base_ = nullptr;
+  cap_ = cur_ = 0;
+}
+
+namespace {
+size_t sort_scratch_bytes(long long n) {
+  size_t tmp_bytes = 0;
+  unsigned long long* k = nullptr;
+  unsigned int* v = nullptr;
+  if (n > 0) (void)rocprim::radix_sort_pairs(nullptr, tmp_bytes, k, k, v, v, size_t(n), 0, 64, hipStream_t(nullptr));
+  return tmp_bytes;
+}
+inline size_t al(size_t b) { return (b + 255) & ~size_t(255); }
+}  // namespace
+
+size_t build_scratch_bytes(long long n, bool cull, int W, int H) {
+  if (n <= 0) return 4096;
+  size_t b = 0;
+  if (cull) b += al(size_t(n)) + al(size_t(n) * 4) + al(size_t(W) * H * 4);
+  b += 2 * al(size_t(n) * 8) + 2 * al(size_t(n) * 4) + al(4096) + al(sort_scratch_bytes(n));
+  return b + 4096;
+}
+
 hipError_t build_records_device(
-  const double* d_pts, const double* d_intensities, long long n, const CullArgs* cull, int B, int GW, int NG, bool force_rec32, void** d_recs_out, int* rec64_out,
-  std::vector<int64_t>& gcount, hipStream_t stream) {
+  const double* d_pts, const double* d_intensities, long long n, const CullArgs* cull, int B, int GW, int NG, bool force_rec32, bool input_order, ScratchArena& arena,
+  void** d_recs_out, int* rec64_out, std::vector<int64_t>& gcount, hipStream_t stream) {
   hipError_t e = hipSuccess;
   unsigned char* d_keep = nullptr;
   int* d_pix = nullptr;
@@ -105,26 +157,38 @@ hipError_t build_records_device(
   gcount.assign(size_t(NG) + 1, 0);
   *d_recs_out = nullptr;
   *rec64_out = 0;
+  if (size_t(NG) + 2 > 1024) return hipErrorInvalidValue;  // d_first is one 4 KB carve
+
+#define CARVE(ptr, type, bytes)                              \
+  do {                                                       \
+    ptr = static_cast<type>(arena.carve(bytes));             \
+    if (!ptr) {                                              \
+      e = hipErrorOutOfMemory;                               \
+      goto done;                                             \
+    }                                                        \
+  } while (0)
 
   if (n > 0) {
     if (cull) {
-      BUILD_TRY(hipMalloc(&d_keep, size_t(n)));
-      BUILD_TRY(hipMalloc(&d_pix, size_t(n) * sizeof(int)));
-      BUILD_TRY(hipMalloc(&d_zbuf, size_t(cull->W) * cull->H * sizeof(unsigned int)));
+      CARVE(d_keep, unsigned char*, size_t(n));
+      CARVE(d_pix, int*, size_t(n) * sizeof(int));
+      CARVE(d_zbuf, unsigned int*, size_t(cull->W) * cull->H * sizeof(unsigned int));
       BUILD_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_zbuf), 0x7f800000, size_t(cull->W) * cull->H, stream));
       BUILD_TRY(launch_cull(cull->model, cull->intr, cull->dist, d_pts, 4, n, cull->T, cull->W, cull->H, cull->min_z, cull->depth, d_pix, d_zbuf, d_keep, stream));
     }
-    BUILD_TRY(hipMalloc(&d_keys, size_t(n) * 8));
-    BUILD_TRY(hipMalloc(&d_keys2, size_t(n) * 8));
-    BUILD_TRY(hipMalloc(&d_idx, size_t(n) * 4));
-    BUILD_TRY(hipMalloc(&d_idx2, size_t(n) * 4));
-    BUILD_TRY(hipMalloc(&d_first, (size_t(NG) + 2) * sizeof(int)));
+    CARVE(d_keys, unsigned long long*, size_t(n) * 8);
+    CARVE(d_keys2, unsigned long long*, size_t(n) * 8);
+    CARVE(d_idx, unsigned int*, size_t(n) * 4);
+    CARVE(d_idx2, unsigned int*, size_t(n) * 4);
+    CARVE(d_first, int*, 4096);
     BUILD_TRY(hipMemsetAsync(d_first, 0xff, (size_t(NG) + 1) * sizeof(int), stream));
     BUILD_TRY(hipMemsetAsync(d_first + NG + 1, 0, sizeof(int), stream));
-    hipLaunchKernelGGL(k_build_keys, dim3(grid), dim3(256), 0, stream, d_pts, d_intensities, d_keep, n, B, GW, d_keys, d_idx, d_first + NG + 1);
+    hipLaunchKernelGGL(k_build_keys, dim3(grid), dim3(256), 0, stream, d_pts, d_intensities, d_keep, n, B, GW, input_order ? 1 : 0, d_keys, d_idx, d_first + NG + 1);
     BUILD_TRY(hipGetLastError());
+    // key = [group : 23][column : 9][Morton code : 32], or [group : 23][input index : 41] to keep the caller's order inside
+    // a group; removed points carry all-ones and sort last
     BUILD_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_keys, d_keys2, d_idx, d_idx2, size_t(n), 0, 64, stream));
-    BUILD_TRY(hipMalloc(&d_tmp, tmp_bytes));
+    CARVE(d_tmp, void*, tmp_bytes > 0 ? tmp_bytes : 256);
     BUILD_TRY(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_keys, d_keys2, d_idx, d_idx2, size_t(n), 0, 64, stream));
     hipLaunchKernelGGL(k_build_bounds, dim3(grid), dim3(256), 0, stream, d_keys2, n, NG, d_first);
     BUILD_TRY(hipGetLastError());
@@ -148,9 +212,9 @@ hipError_t build_records_device(
     if (kept > 0) {
       const unsigned g2 = unsigned((kept + 255) / 256);
       if (rec64)
-        hipLaunchKernelGGL(k_build_gather<Rec64>, dim3(g2), dim3(256), 0, stream, d_pts, d_keys2, d_idx2, kept, static_cast<Rec64*>(d_recs));
+        hipLaunchKernelGGL(k_build_gather<Rec64>, dim3(g2), dim3(256), 0, stream, d_pts, d_intensities, d_idx2, kept, B, static_cast<Rec64*>(d_recs));
       else
-        hipLaunchKernelGGL(k_build_gather<Rec32>, dim3(g2), dim3(256), 0, stream, d_pts, d_keys2, d_idx2, kept, static_cast<Rec32*>(d_recs));
+        hipLaunchKernelGGL(k_build_gather<Rec32>, dim3(g2), dim3(256), 0, stream, d_pts, d_intensities, d_idx2, kept, B, static_cast<Rec32*>(d_recs));
       BUILD_TRY(hipGetLastError());
       BUILD_TRY(hipStreamSynchronize(stream));
     }
@@ -159,19 +223,39 @@ hipError_t build_records_device(
   d_recs = nullptr;
   *rec64_out = rec64;
 done:
-  if (d_keep) (void)hipFree(d_keep);
-  if (d_pix) (void)hipFree(d_pix);
-  if (d_zbuf) (void)hipFree(d_zbuf);
-  if (d_keys) (void)hipFree(d_keys);
-  if (d_keys2) (void)hipFree(d_keys2);
-  if (d_idx) (void)hipFree(d_idx);
-  if (d_idx2) (void)hipFree(d_idx2);
-  if (d_first) (void)hipFree(d_first);
-  if (d_tmp) (void)hipFree(d_tmp);
+#undef CARVE
   if (d_recs) (void)hipFree(d_recs);
   return e;
 }
 
+// ------------------------------------------------------------------------------------------
+// bin image: bin_image = min(int(pix * bins), bins - 1) with a lower clamp at 0 where the reference would index
+// out of bounds (nid_cost.hpp:78-79) for CV_64FC1 input; max(0, min(bins - 1, int(u8 / 255.0 * bins)))
+// (cost_calculator_nid.cpp:43-46) for CV_8UC1 input -- the same IEEE double operations as the host code they
+// replace.  One thread per padded pixel, written in the strip-tiled layout of load_patch.
+namespace {
+__global__ __launch_bounds__(256) void k_build_bin_image(const unsigned char* __restrict__ src, int is_f64, long long row_stride, int W, int H, int B, int pitch, int rows, uint8_t* __restrict__ dst) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)pitch * rows) return;
+  const int py = int(i / pitch), px = int(i % pitch);
+  const int sy = min(max(py - 1, 0), H - 1), sx = min(max(px - 1, 0), W - 1);
+  int b;
+  if (is_f64) {
+    const double v = *reinterpret_cast<const double*>(src + size_t(sy) * size_t(row_stride) + size_t(sx) * 8);
+    b = max(0, min(cast_int_dev(v * double(B)), B - 1));
+  } else {
+    const double v = double(src[size_t(sy) * size_t(row_stride) + size_t(sx)]) / 255.0;
+    b = max(0, min(B - 1, cast_int_dev(v * double(B))));
+  }
+  dst[size_t(py >> 2) * size_t(pitch) * 4 + size_t(px) * 4 + size_t(py & 3)] = uint8_t(b);
+}
+}  // namespace
+
+hipError_t build_bin_image_device(const void* d_src, int is_f64, long long row_stride, int W, int H, int B, int pitch, int nstrips, uint8_t* d_img, hipStream_t stream) {
+  const long long total = (long long)pitch * nstrips * 4;
+  hipLaunchKernelGGL(k_build_bin_image, dim3(unsigned((total + 255) / 256)), dim3(256), 0, stream, static_cast<const unsigned char*>(d_src), is_f64, row_stride, W, H, B, pitch, nstrips * 4, d_img);
+  return hipGetLastError();
+}
 
 // ------------------------------------------------------------------------------------------
 // Intensity rank equalisation (src/vlcal/preprocess/preprocess.cpp:464-473, preprocess_map.cpp): sort the

@@ -44,6 +44,22 @@ NID_HD float m_floor(float x) { return floorf(x); }
 NID_HD double m_floor(double x) { return floor(x); }
 NID_HD float m_val(float x) { return x; }
 NID_HD double m_val(double x) { return x; }
+// x - floor(x) for x >= 0 in one instruction (v_fract); for such x the subtraction is exact, so this equals
+// x - floor(x) bit for bit, and int(x) (truncation) is floor(x): knot and fraction cost two operations, not three
+NID_HD double m_fract(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_fract(x);
+#else
+  return x - floor(x);
+#endif
+}
+NID_HD float m_fract(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_fractf(x);
+#else
+  return x - floorf(x);
+#endif
+}
 
 // ------------------------------------------------------------------------------------------
 // forward-mode dual number with three partials (d/dx, d/dy, d/dz of the camera-frame point).
@@ -524,8 +540,56 @@ NID_HD void project_jac(const CamParams<real>& c, real x, real y, real z, real& 
   }
 }
 
+// Gradient pass, two halves around the tap loop.  project_fwd: the projected point (the histogram pass's own
+// expression, so both passes agree on every knot) plus what the backward half needs; project_bwd: the
+// vector-Jacobian product gp = (gx, gy) . d(u, v)/d(x, y, z).  For the pinhole family (plumb_bob,
+// rational_polynomial) the 2x3 Jacobian is never formed: with A = d(dx, dy)/d(px, py) (symmetric off-diagonal),
+//   h = A^T (fx gx, fy gy),  gp = (h0 / z, h1 / z, -(gp0 px + gp1 py))
+// -- 10 operations instead of 18 for the explicit Jacobian and its contraction.  The other models keep their
+// closed-form 2x3 Jacobians (project_jac) and contract them here.
+template <typename real>
+struct ProjCtx {
+  real a[6];  // pinhole family: iz, px, py, A00, off, A11;  otherwise du[0..2], dv[0..2]
+};
+template <int MODEL, typename real>
+NID_HD void project_fwd(const CamParams<real>& c, real x, real y, real z, real& u, real& v, ProjCtx<real>& ctx) {
+  if (MODEL == MODEL_PLUMB_BOB || MODEL == MODEL_RATIONAL) {
+    project<MODEL, real, real, true>(c, x, y, z, u, v);
+    const real iz = fast_rcp(z);
+    const real px = x * iz, py = y * iz;
+    real a00, a01, a10, a11;
+    CamParams<real> unit = c;  // the distortion Jacobian without the focal lengths (they scale gx, gy instead)
+    unit.intr[0] = real(1);
+    unit.intr[1] = real(1);
+    radtan_jac<MODEL, real>(unit, px, py, a00, a01, a10, a11);
+    ctx.a[0] = iz;
+    ctx.a[1] = px;
+    ctx.a[2] = py;
+    ctx.a[3] = a00;
+    ctx.a[4] = a01;  // == a10
+    ctx.a[5] = a11;
+  } else {
+    project_jac<MODEL, real>(c, x, y, z, u, v, ctx.a, ctx.a + 3);
+  }
+}
+template <int MODEL, typename real>
+NID_HD void project_bwd(const CamParams<real>& c, const ProjCtx<real>& ctx, real gx, real gy, real* gp) {
+  if (MODEL == MODEL_PLUMB_BOB || MODEL == MODEL_RATIONAL) {
+    const real gxf = gx * c.intr[0], gyf = gy * c.intr[1];
+    const real h0 = fma(gxf, ctx.a[3], gyf * ctx.a[4]);
+    const real h1 = fma(gxf, ctx.a[4], gyf * ctx.a[5]);
+    gp[0] = h0 * ctx.a[0];
+    gp[1] = h1 * ctx.a[0];
+    gp[2] = -fma(gp[0], ctx.a[1], gp[1] * ctx.a[2]);
+  } else {
+    gp[0] = fma(gx, ctx.a[0], gy * ctx.a[3]);
+    gp[1] = fma(gx, ctx.a[1], gy * ctx.a[4]);
+    gp[2] = fma(gx, ctx.a[2], gy * ctx.a[5]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
-// device point records (written once per handle by the host-side bucketing)
+// device point records (written once per handle by the device-side build, nid_build.hip)
 struct Rec32 {  // 16 B: one PLY record (float xyz) + the pose-independent histogram column
   float x, y, z;
   uint32_t bin;
@@ -560,28 +624,60 @@ struct Chunk {  // one workgroup's slice of the bucketed cloud
   uint32_t pad;
 };
 
-// uniform cubic B-spline basis, the reference's 4x4 coefficient matrix / 6 (nid_cost.hpp:29-33),
-// evaluated as C * [1 s s^2 s^3]^T in the same term order
+// uniform cubic B-spline basis, the reference's 4x4 coefficient matrix / 6 (nid_cost.hpp:29-33), written in the
+// two mirror variables s and t = 1 - s (b2(s) = b1(t), b3(s) = b0(t)):
+//   b0 = t^3 / 6,  b1 = 2/3 - s^2 + s^3 / 2,  b2 = 2/3 - t^2 + t^3 / 2,  b3 = s^3 / 6
+// -- 11 operations for the four weights, 6 more for the four derivatives, every one an explicit mul / fma: all
+// translation units are built with -ffp-contract=off so that a point gets the same arithmetic whichever unrolled
+// slot / chunk / GPU processes it (the histogram is bit-identical across tilings).
+// Every weight is >= +0 by construction (products of non-negative factors; b1, b2 >= 1/6): the subnormal
+// fixed-point trick (to_fixed_dn) needs sign bit 0 on every weight.
 template <typename real>
 NID_HD void bspline(real s, real* b) {
-  // explicit fma: all translation units are built with -ffp-contract=off so that every point gets
-  // the same arithmetic no matter which unrolled slot / chunk / GPU processes it (the histogram is
-  // bit-identical across tilings); the fusions we want are therefore written out
-  const real s2 = s * s, s3 = s2 * s;
-  const real k16 = real(1.0 / 6.0), k36 = real(3.0 / 6.0), k46 = real(4.0 / 6.0);
-  const real t = real(1) - s;  // b0 = (1-s)^3 / 6, written so that it can never round below +0: the
-  b[0] = k16 * (t * t * t);     // subnormal fixed-point trick (to_fixed_dn) needs sign bit 0 on every weight
-  b[1] = fma(k36, s3, k46 - s2);
-  b[2] = fma(-k36, s3, fma(k36, s2, fma(k36, s, k16)));
-  b[3] = k16 * s3;
+  const real k16 = real(1.0 / 6.0), k46 = real(4.0 / 6.0);
+  const real t = real(1) - s;
+  const real s2 = s * s, t2 = t * t;
+  b[0] = t2 * (t * k16);
+  b[1] = fma(s2, fma(real(0.5), s, real(-1)), k46);
+  b[2] = fma(t2, fma(real(0.5), t, real(-1)), k46);
+  b[3] = s2 * (s * k16);
 }
+// d/ds of the above: -t^2/2,  s (3/2 s - 2),  t (2 - 3/2 t),  s^2/2
 template <typename real>
 NID_HD void bspline_deriv(real s, real* d) {
-  const real s2 = s * s;
-  d[0] = fma(real(-0.5), s2, s - real(0.5));
-  d[1] = fma(real(1.5), s2, real(-2) * s);
-  d[2] = fma(real(-1.5), s2, s + real(0.5));
-  d[3] = real(0.5) * s2;
+  const real t = real(1) - s;
+  d[0] = real(-0.5) * (t * t);
+  d[1] = s * fma(real(1.5), s, real(-2));
+  d[2] = t * fma(real(-1.5), t, real(2));
+  d[3] = real(0.5) * (s * s);
+}
+
+// The x-weights of the histogram pass come out of the polynomial ALREADY in fixed-point units: its constants are
+// pre-multiplied by the unit (one set per kernel, uniform -- or zeroed per lane for an outlier / padding slot, which
+// then adds exact zeros), so b'[a] = b[a] * unit needs no multiply of its own and bits(b'[a] * by[b]) is the integer
+// weight (to_fixed_dn).  All of this arithmetic happens in the SUBNORMAL range, i.e. on the integer grid of 2^-1074:
+// the constants are k, 3k, 4k, 6k grid steps with k = round(2^frac / 6), so they are exact, the fixed-point unit is
+// U = 6k (within 3 of 2^frac; nidreg.hip fixed_unit) and no constant carries a rounding bias into the histogram;
+// each operation rounds to the grid (<= ~1.4 units per weight instead of 0.5, unbiased, deterministic, order
+// independent).
+struct BsplineScale {
+  double k16, k46, k05, k1;  // U/6, 4U/6, U/2, U as subnormal doubles (k, 4k, 3k, 6k grid steps)
+};
+NID_HD BsplineScale bspline_scale(double k16) {
+  BsplineScale K;
+  K.k16 = k16;
+  K.k46 = 4.0 * k16;  // exact: small integers times a grid value
+  K.k05 = 3.0 * k16;
+  K.k1 = 6.0 * k16;
+  return K;
+}
+NID_HD void bspline_scaled(double s, const BsplineScale& K, double* b) {
+  const double t = 1.0 - s;
+  const double s2 = s * s, t2 = t * t;
+  b[0] = t2 * (t * K.k16);
+  b[1] = fma(s2, fma(K.k05, s, -K.k1), K.k46);
+  b[2] = fma(t2, fma(K.k05, t, -K.k1), K.k46);
+  b[3] = s2 * (s * K.k16);
 }
 
 // p_cam = R p + t with fused multiply-adds (SPLINE kernels)

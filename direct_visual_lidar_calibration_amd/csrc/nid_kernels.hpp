@@ -166,6 +166,11 @@ __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_spline_hist(
   int GW, int cshift, double dn_scale, u64* __restrict__ hist) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u64* tile = reinterpret_cast<u64*>(smem);
+  if (WIDE) {  // the specialisation's tiling is fixed: compile-time constants instead of three SGPRs
+    B = 256;
+    GW = 1;
+    cshift = kWideShift;
+  }
   const int tile_n = GW * B;
   // every histogram cell has 2^cshift lane-private copies, interleaved so that lane l only ever
   // touches copy (l mod 2^cshift): with 16 copies the 16 lanes the LDS services per cycle hit 16
@@ -189,58 +194,85 @@ __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_spline_hist(
   const uint32_t col0 = ch.group * uint32_t(GW);
   const uint32_t lane_copy = uint32_t(tid) & cmask;
   unsigned int inl = 0;
+  const BsplineScale KU = bspline_scale(dn_scale);  // uniform: the x-weight polynomial's constants in fixed-point units
+  // record stream: uniform base (SGPR pair) + 32-bit byte offsets per lane
+  const char* rec_base = reinterpret_cast<const char*>(pts + ch.start);
 
-  // kUnroll records per thread are fetched before any of them is processed (memory-level
-  // parallelism), and the per-point body is branch-free: an outlier (or a slot past the end of the
-  // chunk) runs the same instructions with its knot clamped into the image and its x-weights zeroed,
-  // so it adds exact zeros.  That lets the scheduler interleave the kUnroll independent points.
+  // One point: floor knot, cubic B-spline weights per axis (x-weights already in fixed-point units), the 4x4 tap
+  // patch of the strip-tiled bin image as two 16-byte loads, 16 ds_add_u64 into the lane-private copy.
+  // K is the uniform constant set when every lane of the wave holds an inlier (the common case after view
+  // culling), a per-lane set zeroed for outliers / padding slots otherwise: the same arithmetic either way, so
+  // the bits a point contributes do not depend on its wave neighbours (tiling independence).
+  auto taps = [&](real uc, real vc, uint32_t bin, const BsplineScale& K) {
+    const int kx = int(uc), ky = int(vc);  // uc, vc >= 0: truncation is the floor knot (nid_cost.hpp:52)
+    double bxs[4];
+    real by[4];
+    // |.|: a projected coordinate of exactly -0.0 passes `>= 0`, and a -0.0 fraction would put a sign bit into a
+    // weight (to_fixed_dn reads bit patterns); the modifier folds into the consuming instructions
+    bspline_scaled(double(m_abs(m_fract(uc))), K, bxs);
+    bspline<real>(m_abs(m_fract(vc)), by);
+    u64* col = tile + ((((bin - col0) * uint32_t(B)) << cshift) + lane_copy);
+    // padded bin image: tap (a,b) of knot (kx,ky) is padded pixel (kx + a, ky + b) (edge-replicated,
+    // which is the reference's clamp of knots_x / knots_y, nid_cost.hpp:70-73)
+    uint32_t cols[4];  // the two strip loads are issued before the first LDS atomic
+    load_patch(img, pitch, kx, ky, cols);
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+#pragma unroll
+      for (int a = 0; a < 4; a++) {
+        if (WIDE) {
+          typedef __attribute__((address_space(3))) u64 lds_u64_t;
+          const uint32_t addr = __builtin_amdgcn_perm(cols[a], lane_copy << 3, 0x0c0c0000u | (uint32_t(4 + b) << 8));  // [0, 0, byte b of cols[a], copy * 8]
+          __hip_atomic_fetch_add((lds_u64_t*)(uintptr_t)addr, to_fixed_dn(bxs[a], double(by[b])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+          const uint32_t r = (cols[a] >> (8 * b)) & 0xffu;
+          atomicAdd(&col[r << cshift], to_fixed_dn(bxs[a], double(by[b])));  // v_mul_f64 + ds_add_u64
+        }
+      }
+    }
+  };
+
+  // kUnroll records per thread are fetched before any of them is processed (memory-level parallelism); the
+  // geometry of all of them comes first, then -- wave-uniform choice -- the tap code with uniform or per-lane
+  // constants.  Both are branch-free per point, so the scheduler interleaves the kUnroll independent points.
   for (uint32_t base = 0; base < ch.count; base += kT * kUnroll) {
     real xs[kUnroll], ys[kUnroll], zs[kUnroll];
     uint32_t bins_[kUnroll];
 #pragma unroll
     for (int k = 0; k < kUnroll; k++) {
       const uint32_t ii = min(base + uint32_t(k) * kT + tid, ch.count - 1u);
-      load_rec<real>(pts + ch.start + ii, xs[k], ys[k], zs[k], bins_[k]);
+      load_rec<real>(reinterpret_cast<const Rec*>(rec_base + size_t(ii * uint32_t(sizeof(Rec)))), xs[k], ys[k], zs[k], bins_[k]);
     }
+    real us[kUnroll], vs[kUnroll];
+    bool ins[kUnroll];
+    bool all_in = true;
 #pragma unroll
     for (int k = 0; k < kUnroll; k++) {
       const bool valid = base + uint32_t(k) * kT + tid < ch.count;
       real cx, cy, cz;
       transform_fma<real>(pose, xs[k], ys[k], zs[k], cx, cy, cz);
-      real u, v;
-      project<MODEL, real, real, true>(cam, cx, cy, cz, u, v);
+      project<MODEL, real, real, true>(cam, cx, cy, cz, us[k], vs[k]);
       // floor(u) in [0,W) and floor(v) in [0,H); NaN / inf / overflow compare false -> outlier
       // (the reference's int conversion sends those to INT_MIN, nid_cost.hpp:52-58)
-      const bool in = valid && (u >= real(0)) && (u < fW) && (v >= real(0)) && (v < fH);
-      inl += in ? 1u : 0u;
-      const real uc = in ? u : real(0), vc = in ? v : real(0);
-      const real fu = m_floor(uc), fv = m_floor(vc);
-      const int kx = int(fu), ky = int(fv);
-      real bx[4], by[4];
-      bspline<real>(uc - fu, bx);
-      bspline<real>(vc - fv, by);
-      const double keep = in ? dn_scale : 0.0;  // 2^(frac - 1074); an outlier / padding slot adds exact zeros
-      double bxs[4];
+      ins[k] = bool(int(valid) & int(us[k] >= real(0)) & int(us[k] < fW) & int(vs[k] >= real(0)) & int(vs[k] < fH));  // no short circuit: branch-free
+      inl += ins[k] ? 1u : 0u;
+      all_in = bool(int(all_in) & int(ins[k]));
+    }
+    if (__builtin_amdgcn_ballot_w64(!all_in) == 0) {
 #pragma unroll
-      for (int a = 0; a < 4; a++) bxs[a] = double(bx[a]) * keep;
-      u64* col = tile + ((((bins_[k] - col0) * uint32_t(B)) << cshift) + lane_copy);
-      // padded bin image: tap (a,b) of knot (kx,ky) is padded pixel (kx + a, ky + b) (edge-replicated,
-      // which is the reference's clamp of knots_x / knots_y, nid_cost.hpp:70-73)
-      uint32_t cols[4];  // the two strip loads are issued before the first LDS atomic
-      load_patch(img, pitch, kx, ky, cols);
+      for (int k = 0; k < kUnroll; k++) taps(us[k], vs[k], bins_[k], KU);
+    } else {
 #pragma unroll
-      for (int b = 0; b < 4; b++) {
-#pragma unroll
-        for (int a = 0; a < 4; a++) {
-          if (WIDE) {
-            typedef __attribute__((address_space(3))) u64 lds_u64_t;
-            const uint32_t addr = __builtin_amdgcn_perm(cols[a], lane_copy << 3, 0x0c0c0000u | (uint32_t(4 + b) << 8));  // [0, 0, byte b of cols[a], copy * 8]
-            __hip_atomic_fetch_add((lds_u64_t*)(uintptr_t)addr, to_fixed_dn(bxs[a], double(by[b])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          } else {
-            const uint32_t r = (cols[a] >> (8 * b)) & 0xffu;
-            atomicAdd(&col[r << cshift], to_fixed_dn(bxs[a], double(by[b])));  // v_mul_f64 + ds_add_u64
-          }
-        }
+      for (int k = 0; k < kUnroll; k++) {
+        // an outlier (or a slot past the end of the chunk) runs the same instructions with its knot at pixel (0,0)
+        // and zeroed constants: it adds exact zeros
+        const bool in = ins[k];
+        BsplineScale KL;
+        KL.k16 = in ? KU.k16 : 0.0;
+        KL.k46 = in ? KU.k46 : 0.0;
+        KL.k05 = in ? KU.k05 : 0.0;
+        KL.k1 = in ? KU.k1 : 0.0;
+        taps(in ? us[k] : real(0), in ? vs[k] : real(0), bins_[k], KL);
       }
     }
   }
@@ -468,6 +500,97 @@ __global__ __launch_bounds__(kThreads) void k_entropy(
     entropy_final_body(hist, B, int(gridDim.x), inv_unit, part_hj, row_part, col_sum, phi_q, hist_image_out, hist_points_out, scal, out, out_host, tag, s_red);
 }
 
+// ------------------------------------------------------------------------------------------
+// One pair whose points are sharded over several GPUs: NID is nonlinear in the histogram,
+// so the per-shard fixed-point partial histograms are summed (exactly: they are integers) before the
+// entropy tail.  All shards are driven by ONE host process (nidreg.hip, ShardSet), every buffer below is
+// fine-grained device memory mapped into every peer, and the all-reduce is ONE kernel per shard, launched
+// on the shard's stream right behind its histogram kernel -- a one-shot reduce-scatter + all-gather over
+// the point-to-point xGMI links (each shard pulls its 1/n slice from every peer, pushes the sums back to
+// every peer; 2 x (n-1)/n x 514 KB per GPU at 256 bins), with no host round trip and no stream-level
+// cross-device dependency (hipStreamWaitEvent across devices costs more than the kernels it orders):
+//   phase 0  "my partial histogram is complete" (it is: the previous kernel on this stream wrote it) ->
+//            push the evaluation number into every peer's flag block; wait for every peer's number
+//   reduce   slice `me` of the words: sum over the shards' partials, store the sum into every shard's FULL buffer
+//   phase 1  last workgroup: system-scope release, push "my slice is delivered" to every peer, then wait for every
+//            peer's phase-1 number -- the kernel ends only when this shard's FULL buffer is complete, so the
+//            entropy / gradient kernels queued behind it need nothing else.
+// Flag waits are bounded (wall clock): a lost peer sets *err instead of hanging the GPU.
+constexpr int kMaxShards = 16;
+struct ExchangeArgs {
+  const u64* part[kMaxShards];  // this evaluation's partial histogram of every shard
+  u64* full[kMaxShards];        // all-reduced histogram buffer of every shard
+  u64* flags[kMaxShards];       // flag block of every shard: [2][kMaxShards] words, [phase][source shard]
+  int n, me;
+  int words;
+  u64 seq;
+};
+
+__device__ __forceinline__ u64 load_sys(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void store_sys(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+// waits until flag word `p` reaches `seq`; false after ~timeout_ticks of the 100 MHz wall clock
+__device__ __forceinline__ bool wait_flag(const u64* p, u64 seq, unsigned long long timeout_ticks) {
+  const unsigned long long t0 = wall_clock64();
+  while (load_sys(p) < seq) {
+    __builtin_amdgcn_s_sleep(2);
+    if (wall_clock64() - t0 > timeout_ticks) return false;
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(kThreads) void k_shard_exchange(ExchangeArgs a, unsigned int* counter, double* err_out, double* err_host, unsigned long long timeout_ticks) {
+  __shared__ int s_flag;
+  __shared__ int s_bad;
+  const int tid = threadIdx.x;
+  if (tid == 0) s_bad = 0;
+  __syncthreads();
+  if (blockIdx.x == 0 && tid < a.n) store_sys(&a.flags[tid][0 * kMaxShards + a.me], a.seq);
+  if (tid < a.n && !wait_flag(&a.flags[a.me][0 * kMaxShards + tid], a.seq, timeout_ticks)) s_bad = 1;
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  const int lo = int((long long)a.words * a.me / a.n), hi = int((long long)a.words * (a.me + 1) / a.n);
+  for (int k = lo + int(blockIdx.x) * kThreads + tid; k < hi; k += int(gridDim.x) * kThreads) {
+    u64 v[kMaxShards];
+#pragma unroll
+    for (int p = 0; p < kMaxShards; p++) v[p] = p < a.n ? load_sys(a.part[p] + k) : 0;  // independent loads, all links at once
+    u64 sum = 0;
+#pragma unroll
+    for (int p = 0; p < kMaxShards; p++) sum += v[p];
+#pragma unroll
+    for (int q = 0; q < kMaxShards; q++)
+      if (q < a.n) store_sys(a.full[q] + k, sum);
+  }
+  // every workgroup's stores -> one lane: system-scope release -> ticket; the last one announces and waits
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned int t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (t == gridDim.x - 1u) ? 1 : 0;
+    if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_flag = last;
+  }
+  __syncthreads();
+  if (s_bad && tid == 0) {
+    *err_out = 1.0;
+    if (err_host) *err_host = 1.0;
+  }
+  if (!s_flag) return;
+  if (tid < a.n) store_sys(&a.flags[tid][1 * kMaxShards + a.me], a.seq);
+  if (tid < a.n && !wait_flag(&a.flags[a.me][1 * kMaxShards + tid], a.seq, timeout_ticks)) {
+    *err_out = 1.0;
+    if (err_host) *err_host = 1.0;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+}
+
+// self-test pattern of the exchange (ShardSet creation): part[k] = f(shard, round, k)
+__global__ void k_shard_pattern(u64* part, int words, u64 shard, u64 round) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < words) part[k] = (shard + 1) * 1000003ull + round * 7919ull + u64(k) * (shard + 3);
+}
+
 #endif  // NID_COMMON_KERNELS
 
 // ------------------------------------------------------------------------------------------
@@ -518,13 +641,14 @@ __global__ __launch_bounds__(kThreads) void k_spline_grad(
 #pragma unroll
   for (int k = 0; k < 12; k++) acc[k] = 0.0;
 
+  const char* rec_base = reinterpret_cast<const char*>(pts + ch.start);  // uniform base + 32-bit byte offsets per lane
   for (uint32_t base = 0; base < ch.count; base += kThreads * kUnroll) {
     real xs[kUnroll], ys[kUnroll], zs[kUnroll];
     uint32_t bins_[kUnroll];
 #pragma unroll
     for (int k = 0; k < kUnroll; k++) {
       const uint32_t ii = min(base + uint32_t(k) * kThreads + tid, ch.count - 1u);
-      load_rec<real>(pts + ch.start + ii, xs[k], ys[k], zs[k], bins_[k]);
+      load_rec<real>(reinterpret_cast<const Rec*>(rec_base + size_t(ii * uint32_t(sizeof(Rec)))), xs[k], ys[k], zs[k], bins_[k]);
     }
 #pragma unroll
     for (int k = 0; k < kUnroll; k++) {
@@ -533,17 +657,18 @@ __global__ __launch_bounds__(kThreads) void k_spline_grad(
       const real x = xs[k], y = ys[k], z = zs[k];
       real cx, cy, cz;
       transform_fma<real>(pose, x, y, z, cx, cy, cz);
-      real uu, vv, du[3], dv[3];
-      project_jac<MODEL, real>(cam, cx, cy, cz, uu, vv, du, dv);
+      real uu, vv;
+      ProjCtx<real> ctx;
+      project_fwd<MODEL, real>(cam, cx, cy, cz, uu, vv, ctx);
       const bool in = (uu >= real(0)) && (uu < fW) && (vv >= real(0)) && (vv < fH);
       if (in) {
-        const real fu = m_floor(uu), fv = m_floor(vv);
-        const int kx = int(fu), ky = int(fv);
+        const int kx = int(uu), ky = int(vv);  // uu, vv >= 0 here: truncation is the floor knot
+        const real sx = m_abs(m_fract(uu)), sy = m_abs(m_fract(vv));  // |.| as in the histogram pass: identical fractions
         real bx[4], by[4], dbx[4], dby[4];
-        bspline<real>(uu - fu, bx);
-        bspline<real>(vv - fv, by);
-        bspline_deriv<real>(uu - fu, dbx);
-        bspline_deriv<real>(vv - fv, dby);
+        bspline<real>(sx, bx);
+        bspline<real>(sy, by);
+        bspline_deriv<real>(sx, dbx);
+        bspline_deriv<real>(sy, dby);
         typedef __attribute__((address_space(3))) const double lds_f64_t;
         const double* gcol = gtile + ((((bins_[k] - col0) * uint32_t(B)) << cshift) + lane_copy);
         uint32_t cols[4];
@@ -562,9 +687,9 @@ __global__ __launch_bounds__(kThreads) void k_spline_grad(
           gx = fma(sa, by[b], gx);
           gy = fma(sb, dby[b], gy);
         }
-        const double gp0 = double(fma(gx, du[0], gy * dv[0]));
-        const double gp1 = double(fma(gx, du[1], gy * dv[1]));
-        const double gp2 = double(fma(gx, du[2], gy * dv[2]));
+        real gpr[3];
+        project_bwd<MODEL, real>(cam, ctx, gx, gy, gpr);
+        const double gp0 = double(gpr[0]), gp1 = double(gpr[1]), gp2 = double(gpr[2]);
         const double dx = double(x), dy = double(y), dz = double(z);
         acc[0] = fma(gp0, dx, acc[0]);
         acc[1] = fma(gp0, dy, acc[1]);

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <vector>
 
 namespace nidreg {
@@ -74,10 +75,38 @@ struct CullArgs {
   int depth;
 };
 
+// Per-device scratch arena for handle construction: the reference builds a new NIDCost per pair per outer
+// iteration (visual_camera_calibration.cpp:199-208), and hipMalloc / hipFree of the temporaries (upload
+// staging, sort keys, rocPRIM scratch) used to cost more than the kernels.  One grow-only allocation per
+// device, carved linearly; the lock is held for the whole construction (the reference constructs its cost
+// objects sequentially).  nidreg_trim() releases it.
+class ScratchArena {
+ public:
+  static ScratchArena& of(int device);
+  void lock() { mu_.lock(); }
+  void unlock() { mu_.unlock(); }
+  hipError_t reserve(size_t bytes);  // grow to >= bytes (invalidates earlier carves), rewinds the cursor
+  void* carve(size_t bytes);         // 256-byte aligned; nullptr when the reservation is exhausted
+  void release();                    // hipFree (called with the lock held)
+ private:
+  std::mutex mu_;
+  void* base_ = nullptr;
+  size_t cap_ = 0, cur_ = 0;
+};
+
+// scratch bytes build_records_device carves for n input points (+ a W x H depth buffer when culling)
+size_t build_scratch_bytes(long long n, bool cull, int W, int H);
+
 // [cull ->] bucket -> Morton sort -> gather on the device (nid_build.hip).  d_pts: n x 4 doubles (x y z 1),
-// cull nullable.  Returns the record buffer (caller owns), its type, and the column-group offsets.
+// cull nullable.  input_order: keep the caller's order inside each column group (stable sort on the group bits
+// only) instead of the Morton order.  Temporaries come from `arena` (reserved by the caller for at least
+// build_scratch_bytes).  Returns the record buffer (hipMalloc, caller owns), its type, and the column-group offsets.
 hipError_t build_records_device(
-  const double* d_pts, const double* d_intensities, long long n, const CullArgs* cull, int B, int GW, int NG, bool force_rec32, void** d_recs_out, int* rec64_out,
-  std::vector<int64_t>& gcount, hipStream_t stream);
+  const double* d_pts, const double* d_intensities, long long n, const CullArgs* cull, int B, int GW, int NG, bool force_rec32, bool input_order, ScratchArena& arena,
+  void** d_recs_out, int* rec64_out, std::vector<int64_t>& gcount, hipStream_t stream);
+
+// bin image (nid_device.hpp load_patch layout: strips of four rows, padded by 1 left/top and >= 2 right/bottom,
+// edge replicated) from the caller's CV_64FC1 / CV_8UC1 image already uploaded to d_src (row stride in bytes)
+hipError_t build_bin_image_device(const void* d_src, int is_f64, long long row_stride, int W, int H, int B, int pitch, int nstrips, uint8_t* d_img, hipStream_t stream);
 
 }  // namespace nidreg

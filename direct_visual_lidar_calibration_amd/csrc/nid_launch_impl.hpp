@@ -1,5 +1,9 @@
 // nid_launch_impl.hpp -- bodies of the launch wrappers; included by exactly one TU per `real`.
 #pragma once
+#include <mutex>
+#include <utility>
+#include <vector>
+
 #include "nid_kernels.hpp"
 #include "nid_launch.hpp"
 
@@ -26,10 +30,23 @@ static IsoParams<real> make_iso(const PassArgs& a) {
   return p;
 }
 
+// A kernel that needs more than 64 KB of dynamic LDS must be told so once per (kernel, device); doing it on every
+// launch put a runtime call on the critical path of each evaluation of the headline configuration.
 template <typename K>
 static hipError_t ensure_lds(K kernel, size_t bytes) {
-  if (bytes > 64 * 1024) return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes));
-  return hipSuccess;
+  if (bytes <= 64 * 1024) return hipSuccess;
+  static std::mutex mu;
+  static std::vector<std::pair<const void*, std::pair<int, size_t>>> done;  // (kernel, (device, bytes granted))
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const void* key = reinterpret_cast<const void*>(kernel);
+  std::lock_guard<std::mutex> lk(mu);
+  for (const auto& d : done)
+    if (d.first == key && d.second.first == dev && d.second.second >= bytes) return hipSuccess;
+  e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes));
+  if (e == hipSuccess) done.push_back(std::make_pair(key, std::make_pair(dev, bytes)));
+  return e;
 }
 
 #define NID_MODEL_SWITCH(MACRO)                       \

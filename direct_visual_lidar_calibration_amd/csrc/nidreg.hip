@@ -10,11 +10,15 @@
 
 #include <algorithm>
 #include <atomic>
+#include <array>
 #include <climits>
+#include <condition_variable>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -76,7 +80,13 @@ struct nidreg_handle {
   Chunk* d_chunks = nullptr;
   Chunk* d_chunks_hist = nullptr;
   uint8_t* d_img = nullptr;
-  u64* d_hist = nullptr;      // histogram of the current / most recent evaluation
+  u64* d_hist = nullptr;      // histogram of the current / most recent evaluation (accumulation target of pass A)
+  // a shard of a ShardSet accumulates its PARTIAL histogram into d_hist; the set's exchange kernel leaves the sum
+  // over all shards in d_hist_full, which is what the entropy and gradient kernels then read (NULL = d_hist itself)
+  u64* d_hist_full = nullptr;
+  bool finegrained = false;   // histogram buffers are fine-grained device memory (mapped into peer GPUs)
+  struct ShardSet* set = nullptr;  // non-NULL on the leader (shard 0) of a set: nidreg_eval* fan out over the shards
+  bool is_shard = false;
   // double buffering of the histogram (own buffers only): evaluation k accumulates into one buffer and
   // its k_entropy zeroes the OTHER one for evaluation k + 1, so no memset sits on the critical path
   u64* d_hist_buf[2] = {nullptr, nullptr};
@@ -85,6 +95,7 @@ struct nidreg_handle {
   bool own_hist = false;
   double* d_out = nullptr;
   bool own_out = false;
+  void* d_scratch = nullptr;  // ONE allocation carved into the per-evaluation scratch below (zeroed at creation)
   double* d_part_hj = nullptr;
   u64* d_row_part = nullptr;
   double* d_phi_q = nullptr;
@@ -96,6 +107,7 @@ struct nidreg_handle {
   double* d_out_host = nullptr;  // device address of h_out (NULL when results live in ext_out)
   unsigned int* d_counters = nullptr;  // [0] entropy ticket, [1] gradient ticket
   double seq = 0.0;                    // completion tag of the evaluation in flight (host-mapped polling)
+  uint64_t seq_bits = 0;               // its bit pattern (what the acquire load of the tag compares against)
   unsigned int evals_since_reap = 0;
 
   size_t lds_hist = 0, lds_grad = 0, lds_entropy = 0;
@@ -109,11 +121,46 @@ struct nidreg_handle {
   double last_t[3] = {0, 0, 0};
 };
 
+// One LiDAR-camera pair whose points are split over several GPUs (BASELINE north_star: "disjoint point slices with a
+// final all-reduce of the 2D histogram over xGMI"), driven by ONE host process: shard g lives on device g's own
+// nidreg_handle; per evaluation every shard runs  histogram -> k_shard_exchange (one-shot peer-to-peer all-reduce of the
+// fixed-point histogram, nid_kernels.hpp) -> entropy -> gradient  on its own stream, launched by its own host thread
+// (the caller for shard 0), and the host adds the n 7-double gradient partials (the chain rule is linear in them).
+// The cost is computed redundantly -- and bit-identically: same integer histogram -- on every shard.
+struct ShardSet {
+  std::vector<nidreg_handle*> shards;  // [0] = the leader (owns this set), the rest are owned by the set
+  std::vector<u64*> flags;             // per shard: fine-grained [2][kMaxShards] flag block on its device
+  ExchangeArgs xargs[2][kMaxShards];   // per histogram buffer parity, per shard
+  u64 seq = 0;
+  unsigned long long timeout_ticks = 300000000ull;  // 3 s of the 100 MHz wall clock
+  // worker threads (one per shard >= 1): spin briefly on `gen`, then sleep on the condition variable
+  std::vector<std::thread> workers;
+  std::atomic<uint64_t> gen{0};
+  std::atomic<int> pending{0};
+  std::atomic<int> sleepers{0};
+  std::atomic<bool> stop{false};
+  std::mutex mu;
+  std::condition_variable cv;
+  // job of the current generation
+  int job_mode = 0;  // NIDREG_MODE_*
+  bool job_grad = false;
+  double job_pose[16];
+  std::vector<int> rc;
+  std::vector<std::array<double, 8>> res;  // cost, grad7
+};
+
 namespace {
+
+void free_shard_set(ShardSet* set);
 
 void free_handle(nidreg_handle* h) {
   if (!h) return;
+  if (h->set) {
+    free_shard_set(h->set);  // stops the workers and frees the other shards
+    h->set = nullptr;
+  }
   (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->d_pts) (void)hipFree(h->d_pts);
   if (h->d_chunks) (void)hipFree(h->d_chunks);
   if (h->d_chunks_hist) (void)hipFree(h->d_chunks_hist);
@@ -122,20 +169,23 @@ void free_handle(nidreg_handle* h) {
     if (h->d_hist_buf[0]) (void)hipFree(h->d_hist_buf[0]);
     if (h->d_hist_buf[1]) (void)hipFree(h->d_hist_buf[1]);
   }
+  if (h->d_hist_full) (void)hipFree(h->d_hist_full);
   if (h->own_out && h->d_out) (void)hipFree(h->d_out);
-  if (h->d_part_hj) (void)hipFree(h->d_part_hj);
-  if (h->d_row_part) (void)hipFree(h->d_row_part);
-  if (h->d_phi_q) (void)hipFree(h->d_phi_q);
-  if (h->d_hist_image) (void)hipFree(h->d_hist_image);
-  if (h->d_hist_points) (void)hipFree(h->d_hist_points);
-  if (h->d_scal) (void)hipFree(h->d_scal);
-  if (h->d_partials) (void)hipFree(h->d_partials);
+  if (h->d_scratch) (void)hipFree(h->d_scratch);
   if (h->h_out) (void)hipHostFree(h->h_out);
-  if (h->d_counters) (void)hipFree(h->d_counters);
   for (int i = 0; i < 6; i++)
     if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
+}
+
+inline u64* hist_source(const nidreg_handle* h) { return h->d_hist_full ? h->d_hist_full : h->d_hist; }
+
+// The fixed-point unit of the SPLINE histogram: U = 6 round(2^frac / 6) -- within 3 of 2^frac, and a multiple of 6
+// so that the B-spline constants U/6, U/2, 4U/6, U are integers (nid_device.hpp bspline_scale).  NEAREST counts: 1.
+inline double fixed_unit(const nidreg_handle* h) {
+  if (h->mode == NIDREG_MODE_NEAREST || h->frac_bits == 0) return 1.0;
+  return 6.0 * std::rint(std::ldexp(1.0, h->frac_bits) / 6.0);
 }
 
 void fill_pass_args(const nidreg_handle* h, PassArgs& a) {
@@ -155,8 +205,8 @@ void fill_pass_args(const nidreg_handle* h, PassArgs& a) {
   a.wide = h->wide;
   std::memcpy(a.intr, h->intr, sizeof(a.intr));
   std::memcpy(a.dist, h->dist, sizeof(a.dist));
-  a.magic = std::ldexp(1.0, h->frac_bits - 1074);  // subnormal pre-scale of the x-weights (to_fixed_dn)
-  a.inv_unit = std::ldexp(1.0, -h->frac_bits);
+  a.magic = std::ldexp(fixed_unit(h) / 6.0, -1074);  // U/6 grid steps as a subnormal double: the x-weight constants (bspline_scale)
+  a.inv_unit = 1.0 / fixed_unit(h);
   a.cos_fov = std::cos(h->max_fov);
   a.hist = h->d_hist;
   a.phi_q = h->d_phi_q;
@@ -170,6 +220,11 @@ void fill_pass_args(const nidreg_handle* h, PassArgs& a) {
   a.stream = h->stream;
   a.lds_hist = h->lds_hist;
   a.lds_grad = h->lds_grad;
+}
+
+inline void bump_seq(nidreg_handle* h) {
+  h->seq += 1.0;
+  std::memcpy(&h->seq_bits, &h->seq, sizeof(h->seq_bits));
 }
 
 // R = I + 2 w [v]x + 2 [v]x^2 from the un-normalised quaternion (Sophus SO3 * point expanded)
@@ -245,9 +300,9 @@ int launch_hist_nearest(nidreg_handle* h, const double* T) {
 }
 
 int launch_entropy(nidreg_handle* h, double tag) {
-  const double inv_unit = std::ldexp(1.0, -h->frac_bits);
+  const double inv_unit = 1.0 / fixed_unit(h);
   hipLaunchKernelGGL(
-    k_entropy, dim3(h->NEB), dim3(kThreads), 0, h->stream, h->d_hist, h->bins, kEntropyCols, inv_unit, h->d_part_hj, h->d_row_part, h->d_phi_q, h->d_hist_image,
+    k_entropy, dim3(h->NEB), dim3(kThreads), 0, h->stream, hist_source(h), h->bins, kEntropyCols, inv_unit, h->d_part_hj, h->d_row_part, h->d_phi_q, h->d_hist_image,
     h->d_hist_points, h->d_scal, h->d_out, h->d_out_host, tag, h->d_counters, h->own_hist ? h->d_hist_buf[h->hist_cur ^ 1] : nullptr, h->hist_words);
   HIP_TRY(hipGetLastError());
   if (h->own_hist) h->hist_zeroed[h->hist_cur ^ 1] = true;  // zeroed by this k_entropy for the next evaluation
@@ -257,6 +312,7 @@ int launch_entropy(nidreg_handle* h, double tag) {
 int launch_grad(nidreg_handle* h) {
   PassArgs a;
   fill_pass_args(h, a);
+  a.hist = hist_source(h);  // the finished (for a shard: all-reduced) histogram
   // same pose as the histogram pass of this evaluation
   std::memcpy(a.R, h->last_R, sizeof(a.R));
   std::memcpy(a.t, h->last_t, sizeof(a.t));
@@ -277,7 +333,7 @@ int launch_grad(nidreg_handle* h) {
 int eval_launch(nidreg_handle* h, const double* se3, bool want_grad) {
   if (h->mode != NIDREG_MODE_SPLINE) return fail(NIDREG_ERR_INVALID, "nidreg_eval: handle was created in NEAREST mode");
   HIP_TRY(hipSetDevice(h->device));
-  h->seq += 1.0;
+  bump_seq(h);
   if (h->timing) HIP_TRY(hipEventRecord(h->ev[0], h->stream));
   int rc = launch_hist_spline(h, se3);
   if (rc) return rc;
@@ -303,14 +359,25 @@ int eval_finish(nidreg_handle* h, double* cost, double* grad7) {
     // the finalising workgroup wrote the results and then this evaluation's tag into host-mapped memory:
     // poll the tag (a few us cheaper than hipStreamSynchronize); look at the stream now and then so that a
     // faulted kernel cannot hang the caller, and so the runtime can retire finished commands
-    volatile double* flag = h->h_out + 15;
+    // (acquire load of the tag, then plain loads of the payload; the spin backs off so that N in-flight
+    // handles -- one OpenMP thread per pair in the reference -- do not burn N cores at full speed)
+    const double* flag = h->h_out + 15;
     unsigned long long spins = 0;
-    while (*flag != h->seq) {
-      if ((++spins & 0x3fffull) == 0) {
+    while (__atomic_load_n(reinterpret_cast<const uint64_t*>(flag), __ATOMIC_ACQUIRE) != h->seq_bits) {
+      ++spins;
+      if (spins < 64) {
+        __builtin_ia32_pause();
+      } else if (spins < 512) {  // ~0.3 ms of paused spinning covers a 10M-point evaluation
+        for (int k = 0; k < 16; k++) __builtin_ia32_pause();
+      } else {
+        struct timespec ts = {0, 20000};  // 20 us naps once the wait is long (>~100 us): the kernels are still running
+        nanosleep(&ts, nullptr);
+      }
+      if ((spins & 0xffull) == 0) {
         const hipError_t q = hipStreamQuery(h->stream);
         if (q == hipSuccess) {
-          if (*flag != h->seq) HIP_TRY(hipStreamSynchronize(h->stream));
-          if (*flag != h->seq) return fail(NIDREG_ERR_HIP, "nidreg_eval: stream drained but the completion tag is missing");
+          if (__atomic_load_n(reinterpret_cast<const uint64_t*>(flag), __ATOMIC_ACQUIRE) != h->seq_bits) HIP_TRY(hipStreamSynchronize(h->stream));
+          if (__atomic_load_n(reinterpret_cast<const uint64_t*>(flag), __ATOMIC_ACQUIRE) != h->seq_bits) return fail(NIDREG_ERR_HIP, "nidreg_eval: stream drained but the completion tag is missing");
           break;
         }
         if (q != hipErrorNotReady) return fail(NIDREG_ERR_HIP, std::string("nidreg_eval: ") + hipGetErrorString(q));
@@ -332,7 +399,7 @@ int eval_finish(nidreg_handle* h, double* cost, double* grad7) {
 int iso_launch(nidreg_handle* h, const double* T) {
   if (h->mode != NIDREG_MODE_NEAREST) return fail(NIDREG_ERR_INVALID, "nidreg_eval_iso: handle was created in SPLINE mode");
   HIP_TRY(hipSetDevice(h->device));
-  h->seq += 1.0;
+  bump_seq(h);
   if (h->timing) HIP_TRY(hipEventRecord(h->ev[0], h->stream));
   int rc = launch_hist_nearest(h, T);
   if (rc) return rc;
@@ -416,7 +483,11 @@ struct nidreg_cloud {
 
 namespace {
 
-int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T_cull, double min_z, int enable_depth, nidreg_handle** out) {
+struct CreateOpts {
+  bool shard = false;  // one shard of a ShardSet: fine-grained histogram buffers + the all-reduced copy
+};
+
+int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T_cull, double min_z, int enable_depth, const CreateOpts& opts, nidreg_handle** out) {
   if (!d || !out) return fail(NIDREG_ERR_INVALID, "nidreg_create: null argument");
   *out = nullptr;
   if (d->struct_size != int32_t(sizeof(nidreg_desc))) return fail(NIDREG_ERR_INVALID, "nidreg_create: struct_size mismatch");
@@ -488,46 +559,52 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
   while ((int64_t(1) << nbits) <= scaleN) nbits++;
   h->frac_bits = d->mode == NIDREG_MODE_NEAREST ? 0 : std::min(40, 62 - nbits);
 
-  // ---- bin image, padded by 1 (left/top) and >= 2 (right/bottom), edge replicated:
-  // bin_image = min(int(pix * bins), bins - 1) (nid_cost.hpp:78-79) for CV_64FC1 input;
-  // max(0, min(bins-1, int(u8 / 255.0 * bins))) (cost_calculator_nid.cpp:43-46) for CV_8UC1 input.
+  // ---- everything below is built ON THE DEVICE from one upload of the caller's arrays (the reference constructs
+  // a cost object per pair per outer iteration, visual_camera_calibration.cpp:199-208, so construction time counts):
+  // the bin image, then [ViewCulling::cull ->] histogram column + Morton key -> rocPRIM radix sort -> record gather
+  // (nid_build.hip).  Temporaries live in the per-device scratch arena.
   const int W = h->W, H = h->H;
   h->pitch = ((W + 8) + 3) & ~3;  // padded width in pixels
   const int PH = H + 3;
   const int nstrips = (PH + 3) / 4 + 1;  // rows are stored in strips of four (nid_device.hpp load_patch)
-  std::vector<uint8_t> img(size_t(h->pitch) * 4 * nstrips + 64, 0);
-  {
-    uint8_t lut[256];
-    for (int k = 0; k < 256; k++) lut[k] = uint8_t(std::max(0, std::min(B - 1, cast_int(k / 255.0 * B))));
-    const uint8_t* base = static_cast<const uint8_t*>(d->image);
-    for (int py = 0; py < nstrips * 4; py++) {
-      const int sy = std::min(std::max(py - 1, 0), H - 1);
-      uint8_t* dst = img.data() + size_t(py >> 2) * size_t(h->pitch) * 4 + size_t(py & 3);
-      if (d->image_dtype == NIDREG_IMAGE_F64) {
-        const double* row = reinterpret_cast<const double*>(base + size_t(sy) * d->image_row_stride);
-        for (int px = 0; px < h->pitch; px++) {
-          const int sx = std::min(std::max(px - 1, 0), W - 1);
-          dst[size_t(px) * 4] = uint8_t(std::max(0, std::min(cast_int(row[sx] * B), B - 1)));
-        }
-      } else {
-        const uint8_t* row = base + size_t(sy) * d->image_row_stride;
-        for (int px = 0; px < h->pitch; px++) {
-          const int sx = std::min(std::max(px - 1, 0), W - 1);
-          dst[size_t(px) * 4] = lut[row[sx]];
-        }
-      }
-    }
+  const size_t img_bytes = size_t(h->pitch) * 4 * nstrips + 64;
+  const bool img_f64 = d->image_dtype == NIDREG_IMAGE_F64;
+  if (d->image_dtype != NIDREG_IMAGE_F64 && d->image_dtype != NIDREG_IMAGE_U8) {
+    free_handle(h);
+    return fail(NIDREG_ERR_INVALID, "nidreg_create: bad image_dtype");
   }
-  CREATE_TRY(hipMalloc(&h->d_img, img.size()));
-  CREATE_TRY(hipMemcpy(h->d_img, img.data(), img.size(), hipMemcpyHostToDevice));
-
-  // ---- points: bin_points = max(0, min(bins-1, int(intensity * bins))) (nid_cost.hpp:49,
-  // cost_calculator_nid.cpp:47) is pose independent -> bucket by column group (stable), so a
-  // workgroup owns GW histogram columns.  Records are float32 when that is lossless or when the
-  // caller asked for FP32 geometry; otherwise double.
+  const size_t src_row = size_t(W) * (img_f64 ? 8 : 1);
+  if (d->image_row_stride < int64_t(src_row)) {
+    free_handle(h);
+    return fail(NIDREG_ERR_INVALID, "nidreg_create: image_row_stride smaller than a row");
+  }
+  const int64_t pstride = d->point_stride > 0 ? d->point_stride : 32;
+  if (!cloud && n_in > 0 && (pstride < 32 || pstride % 8 != 0)) {
+    free_handle(h);
+    return fail(NIDREG_ERR_INVALID, "nidreg_create: point_stride must be a multiple of 8 and >= 32 ((x y z 1) doubles)");
+  }
   std::vector<int64_t> gcount;
-  if (cloud) {
-    // device path: [ViewCulling::cull ->] bucket -> Morton sort -> gather, all on the GPU (nid_build.hip)
+  {
+    ScratchArena& arena = ScratchArena::of(h->device);
+    std::lock_guard<ScratchArena> guard(arena);
+    const size_t up_img = ((src_row * size_t(H)) + 255) & ~size_t(255);
+    const size_t up_pts = cloud ? 0 : ((size_t(std::max<int64_t>(n_in, 1)) * 32 + 255) & ~size_t(255));
+    const size_t up_int = cloud ? 0 : ((size_t(std::max<int64_t>(n_in, 1)) * 8 + 255) & ~size_t(255));
+    CREATE_TRY(arena.reserve(up_img + up_pts + up_int + build_scratch_bytes(n_in, T_cull != nullptr, W, H) + 4096));
+
+    // bin image: bin_image = min(int(pix * bins), bins - 1) (nid_cost.hpp:78-79) for CV_64FC1 input;
+    // max(0, min(bins-1, int(u8 / 255.0 * bins))) (cost_calculator_nid.cpp:43-46) for CV_8UC1 input;
+    // padded by 1 (left/top) and >= 2 (right/bottom), edge replicated (= the clamp of knots_x / knots_y, :70-73)
+    void* d_src = arena.carve(up_img);
+    CREATE_TRY(hipMalloc(&h->d_img, img_bytes));
+    CREATE_TRY(hipMemcpy2D(d_src, src_row, d->image, size_t(d->image_row_stride), src_row, size_t(H), hipMemcpyHostToDevice));
+    CREATE_TRY(build_bin_image_device(d_src, img_f64 ? 1 : 0, (long long)src_row, W, H, B, h->pitch, nstrips, h->d_img, nullptr));
+
+    // points: bin_points = max(0, min(bins-1, int(intensity * bins))) (nid_cost.hpp:49, cost_calculator_nid.cpp:47)
+    // is pose independent -> records are bucketed by column group, so a workgroup owns GW histogram columns;
+    // inside a group they follow a Morton curve of the LiDAR-frame bearing (any order gives the same bits -- the
+    // sums are integers --, a spatially coherent one makes a wave's gathers share cache lines for ANY pose).
+    // Records are float32 when that is lossless or FP32 geometry was requested; otherwise double.
     CullArgs ca;
     if (T_cull) {
       ca.model = d->model_id;
@@ -539,128 +616,31 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
       ca.min_z = min_z;
       ca.depth = enable_depth ? 1 : 0;
     }
+    const double* d_cloud_pts = cloud ? cloud->d_pts : nullptr;
+    const double* d_cloud_int = cloud ? cloud->d_int : nullptr;
+    if (!cloud) {
+      double* up_p = static_cast<double*>(arena.carve(up_pts));
+      double* up_i = static_cast<double*>(arena.carve(up_int));
+      if (n_in > 0) {
+        if (pstride == 32) {
+          CREATE_TRY(hipMemcpy(up_p, d->points, size_t(n_in) * 32, hipMemcpyHostToDevice));
+        } else {
+          CREATE_TRY(hipMemcpy2D(up_p, 32, d->points, size_t(pstride), 32, size_t(n_in), hipMemcpyHostToDevice));
+        }
+        CREATE_TRY(hipMemcpy(up_i, d->intensities, size_t(n_in) * 8, hipMemcpyHostToDevice));
+      }
+      d_cloud_pts = up_p;
+      d_cloud_int = up_i;
+    }
     void* recs = nullptr;
     int rec64 = 0;
-    CREATE_TRY(build_records_device(cloud->d_pts, cloud->d_int, cloud->n, T_cull ? &ca : nullptr, B, GW, h->NG, d->precision == NIDREG_PREC_FP32, &recs, &rec64, gcount, nullptr));
+    CREATE_TRY(build_records_device(d_cloud_pts, d_cloud_int, n_in, T_cull ? &ca : nullptr, B, GW, h->NG, d->precision == NIDREG_PREC_FP32, (d->flags & NIDREG_FLAG_INPUT_ORDER) != 0,
+                                    arena, &recs, &rec64, gcount, nullptr));
     h->d_pts = recs;
     h->rec64 = rec64;
     N = gcount[size_t(h->NG)];
     h->num_points = N;
-  } else {
-    const char* pbase = reinterpret_cast<const char*>(d->points);
-    const int64_t pstride = d->point_stride > 0 ? d->point_stride : 32;
-    const bool spatial = !(d->flags & NIDREG_FLAG_INPUT_ORDER);
-    const int nthreads = int(std::max(1u, std::min(32u, std::thread::hardware_concurrency())));
-    auto parallel_for = [&](int64_t n, const std::function<void(int64_t, int64_t, int)>& fn) {
-      const int T = int(std::min<int64_t>(nthreads, std::max<int64_t>(1, n / 65536)));
-      if (T <= 1) {
-        fn(0, n, 0);
-        return;
-      }
-      std::vector<std::thread> th;
-      for (int t = 0; t < T; t++) th.emplace_back([&, t]() { fn(n * t / T, n * (t + 1) / T, t); });
-      for (auto& x : th) x.join();
-    };
-
-    // pass 1 (parallel): histogram column, float-representability, Morton code of the bearing
-    std::vector<uint32_t> bin(N), mort(spatial ? N : 0);
-    std::vector<int> lossless_t(nthreads, 1);
-    std::vector<std::vector<int64_t>> gcount_t(nthreads, std::vector<int64_t>(h->NG, 0));
-    parallel_for(N, [&](int64_t lo, int64_t hi, int t) {
-      bool ll = true;
-      std::vector<int64_t>& gc = gcount_t[t];
-      for (int64_t i = lo; i < hi; i++) {
-        const double* p = reinterpret_cast<const double*>(pbase + i * pstride);
-        if (ll) {
-          for (int k = 0; k < 3; k++)
-            if (double(float(p[k])) != p[k] && p[k] == p[k]) ll = false;
-        }
-        const int b = std::max(0, std::min(B - 1, cast_int(d->intensities[i] * B)));
-        bin[i] = uint32_t(b);
-        gc[b / GW]++;
-        if (spatial) {
-          // bearing cell: the sums are order independent (fixed point), so any order gives the same
-          // bits; a spatially coherent one makes the 64 lanes of a wave gather from neighbouring image
-          // lines for ANY pose (camera and LiDAR are rigidly mounted: a compact patch of bearings stays a
-          // compact patch of pixels)
-          const double az = std::atan2(p[1], p[0]);
-          const double el = std::atan2(p[2], std::sqrt(p[0] * p[0] + p[1] * p[1]));
-          uint32_t qa = uint32_t(std::min(65535.0, std::max(0.0, (az + M_PI) * (65535.0 / (2.0 * M_PI)))));
-          uint32_t qe = uint32_t(std::min(65535.0, std::max(0.0, (el + 0.5 * M_PI) * (65535.0 / M_PI))));
-          if (!(az == az) || !(el == el)) qa = qe = 0;
-          uint32_t m = 0;
-          for (int bb = 0; bb < 16; bb++) m |= (((qa >> bb) & 1u) << (2 * bb)) | (((qe >> bb) & 1u) << (2 * bb + 1));
-          mort[i] = m;
-        }
-      }
-      lossless_t[t] = ll ? 1 : 0;
-    });
-    bool lossless = true;
-    for (int t = 0; t < nthreads; t++) lossless = lossless && lossless_t[t];
-    gcount.assign(size_t(h->NG) + 1, 0);
-    for (int g = 0; g < h->NG; g++) {
-      int64_t c = 0;
-      for (int t = 0; t < nthreads; t++) c += gcount_t[t][g];
-      gcount[g + 1] = gcount[g] + c;
-    }
-    h->rec64 = (d->precision == NIDREG_PREC_FP64 && !lossless) ? 1 : 0;
-    const size_t rec_bytes = h->rec64 ? sizeof(Rec64) : sizeof(Rec32);
-    {
-      // order[k] = source index of the k-th device record: stable bucketing by column group, then (default)
-      // each group sorted by Morton code; NIDREG_FLAG_INPUT_ORDER keeps the caller's order inside groups.
-      std::vector<uint32_t> order(N);
-      {
-        std::vector<int64_t> cursor(gcount.begin(), gcount.end() - 1);
-        for (int64_t i = 0; i < N; i++) order[cursor[bin[i] / GW]++] = uint32_t(i);
-      }
-      if (spatial) {
-        std::atomic<int> next_group(0);
-        auto worker = [&]() {
-          std::vector<std::pair<uint32_t, uint32_t>> tmp;
-          for (;;) {
-            const int g = next_group.fetch_add(1);
-            if (g >= h->NG) break;
-            const int64_t lo = gcount[g], hi = gcount[g + 1];
-            tmp.resize(size_t(hi - lo));
-            for (int64_t k = lo; k < hi; k++) tmp[size_t(k - lo)] = std::make_pair(mort[order[k]], order[k]);
-            std::sort(tmp.begin(), tmp.end());
-            for (int64_t k = lo; k < hi; k++) order[k] = tmp[size_t(k - lo)].second;
-          }
-        };
-        const int T = N > 200000 ? std::min(nthreads, h->NG) : 1;
-        if (T <= 1) {
-          worker();
-        } else {
-          std::vector<std::thread> th;
-          for (int t = 0; t < T; t++) th.emplace_back(worker);
-          for (auto& x : th) x.join();
-        }
-      }
-      std::vector<unsigned char> recs(size_t(std::max<int64_t>(N, 1)) * rec_bytes);
-      parallel_for(N, [&](int64_t lo, int64_t hi, int) {
-        for (int64_t dst = lo; dst < hi; dst++) {
-          const int64_t i = order[dst];
-          const double* p = reinterpret_cast<const double*>(pbase + i * pstride);
-          if (h->rec64) {
-            Rec64 r;
-            r.x = p[0];
-            r.y = p[1];
-            r.z = p[2];
-            r.bin = bin[i];
-            std::memcpy(recs.data() + size_t(dst) * rec_bytes, &r, rec_bytes);
-          } else {
-            Rec32 r;
-            r.x = float(p[0]);
-            r.y = float(p[1]);
-            r.z = float(p[2]);
-            r.bin = bin[i];
-            std::memcpy(recs.data() + size_t(dst) * rec_bytes, &r, rec_bytes);
-          }
-        }
-      });
-      CREATE_TRY(hipMalloc(&h->d_pts, recs.size() + 64));
-      CREATE_TRY(hipMemcpy(h->d_pts, recs.data(), recs.size(), hipMemcpyHostToDevice));
-    }
+    CREATE_TRY(hipStreamSynchronize(nullptr));  // the bin-image kernel, before the arena is handed to the next construction
   }
 
   // ---- chunk tables: each chunk = one workgroup, points of one column group only.  By default a pass
@@ -714,8 +694,19 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
   if (d->ext_hist) {
     h->d_hist = static_cast<u64*>(d->ext_hist);
   } else {
-    CREATE_TRY(hipMalloc(&h->d_hist_buf[0], size_t(h->hist_words) * sizeof(u64)));
-    CREATE_TRY(hipMalloc(&h->d_hist_buf[1], size_t(h->hist_words) * sizeof(u64)));
+    if (opts.shard) {
+      // shards of one pair exchange their histograms directly between GPUs: fine-grained (coherent) device
+      // memory, mapped into every peer by the ShardSet
+      h->finegrained = true;
+      h->is_shard = true;
+      CREATE_TRY(hipExtMallocWithFlags(reinterpret_cast<void**>(&h->d_hist_buf[0]), size_t(h->hist_words) * sizeof(u64), hipDeviceMallocFinegrained));
+      CREATE_TRY(hipExtMallocWithFlags(reinterpret_cast<void**>(&h->d_hist_buf[1]), size_t(h->hist_words) * sizeof(u64), hipDeviceMallocFinegrained));
+      CREATE_TRY(hipExtMallocWithFlags(reinterpret_cast<void**>(&h->d_hist_full), size_t(h->hist_words) * sizeof(u64), hipDeviceMallocFinegrained));
+      CREATE_TRY(hipMemset(h->d_hist_full, 0, size_t(h->hist_words) * sizeof(u64)));
+    } else {
+      CREATE_TRY(hipMalloc(&h->d_hist_buf[0], size_t(h->hist_words) * sizeof(u64)));
+      CREATE_TRY(hipMalloc(&h->d_hist_buf[1], size_t(h->hist_words) * sizeof(u64)));
+    }
     CREATE_TRY(hipMemset(h->d_hist_buf[1], 0, size_t(h->hist_words) * sizeof(u64)));
     h->d_hist = h->d_hist_buf[0];
     h->hist_cur = 0;
@@ -730,13 +721,35 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
   }
   CREATE_TRY(hipMemset(h->d_out, 0, NIDREG_OUT_DOUBLES * sizeof(double)));
   CREATE_TRY(hipMemset(h->d_hist, 0, size_t(h->hist_words) * sizeof(u64)));
-  CREATE_TRY(hipMalloc(&h->d_part_hj, size_t(h->NEB) * sizeof(double)));
-  CREATE_TRY(hipMalloc(&h->d_row_part, size_t(h->NEB) * B * sizeof(u64)));
-  CREATE_TRY(hipMalloc(&h->d_phi_q, size_t(B) * sizeof(double)));
-  CREATE_TRY(hipMalloc(&h->d_hist_image, size_t(B) * sizeof(double)));
-  CREATE_TRY(hipMalloc(&h->d_hist_points, size_t(B) * sizeof(double)));
-  CREATE_TRY(hipMalloc(&h->d_scal, sizeof(EntropyScalars)));
-  CREATE_TRY(hipMalloc(&h->d_partials, std::max<size_t>(h->nchunks, 1) * 12 * sizeof(double)));
+  {
+    // one allocation, carved (256-byte aligned) and zeroed: nidreg_get_hist before the first evaluation then
+    // reads zeros, not uninitialised memory
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+      const size_t at = off;
+      off = (off + bytes + 255) & ~size_t(255);
+      return at;
+    };
+    const size_t o_part_hj = carve(size_t(h->NEB) * sizeof(double));
+    const size_t o_row_part = carve(size_t(h->NEB) * B * sizeof(u64));
+    const size_t o_phi_q = carve(size_t(B) * sizeof(double));
+    const size_t o_hist_image = carve(size_t(B) * sizeof(double));
+    const size_t o_hist_points = carve(size_t(B) * sizeof(double));
+    const size_t o_scal = carve(sizeof(EntropyScalars));
+    const size_t o_partials = carve(std::max<size_t>(h->nchunks, 1) * 12 * sizeof(double));
+    const size_t o_counters = carve(8 * sizeof(unsigned int));
+    CREATE_TRY(hipMalloc(&h->d_scratch, off));
+    CREATE_TRY(hipMemset(h->d_scratch, 0, off));
+    char* base = static_cast<char*>(h->d_scratch);
+    h->d_part_hj = reinterpret_cast<double*>(base + o_part_hj);
+    h->d_row_part = reinterpret_cast<u64*>(base + o_row_part);
+    h->d_phi_q = reinterpret_cast<double*>(base + o_phi_q);
+    h->d_hist_image = reinterpret_cast<double*>(base + o_hist_image);
+    h->d_hist_points = reinterpret_cast<double*>(base + o_hist_points);
+    h->d_scal = reinterpret_cast<EntropyScalars*>(base + o_scal);
+    h->d_partials = reinterpret_cast<double*>(base + o_partials);
+    h->d_counters = reinterpret_cast<unsigned int*>(base + o_counters);
+  }
   CREATE_TRY(hipHostMalloc(&h->h_out, NIDREG_OUT_DOUBLES * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
   std::memset(h->h_out, 0, NIDREG_OUT_DOUBLES * sizeof(double));
   if (!d->ext_out) {
@@ -745,11 +758,316 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
     CREATE_TRY(hipHostGetDevicePointer(&dp, h->h_out, 0));
     h->d_out_host = static_cast<double*>(dp);
   }
-  CREATE_TRY(hipMalloc(&h->d_counters, 4 * sizeof(unsigned int)));
-  CREATE_TRY(hipMemset(h->d_counters, 0, 4 * sizeof(unsigned int)));
   for (int i = 0; i < 6; i++) CREATE_TRY(hipEventCreate(&h->ev[i]));
 #undef CREATE_TRY
   *out = h;
+  return NIDREG_OK;
+}
+
+// ---- sharded pairs ----------------------------------------------------------------------------------------------
+
+// NIDREG_DEVICES="0,1,2,3": spread every SPLINE / NEAREST handle built from host arrays over these devices without
+// touching the caller -- this is how the reference's unchanged `new NIDCost(proj, image, points, bins)`
+// (visual_camera_calibration.cpp:206) uses all GPUs of a node for a one-bag dataset
+std::vector<int> shard_devices(const nidreg_desc* d) {
+  std::vector<int> ids;
+  if (d->num_devices > 1) {
+    for (int i = 0; i < d->num_devices && i < NIDREG_MAX_DEVICES; i++) ids.push_back(d->device_ids[i]);
+    return ids;
+  }
+  if (d->num_devices == 1) return ids;  // explicit single device
+  if (const char* env = std::getenv("NIDREG_DEVICES")) {
+    const char* p = env;
+    while (*p) {
+      char* end = nullptr;
+      const long v = std::strtol(p, &end, 10);
+      if (end == p) break;
+      ids.push_back(int(v));
+      p = (*end == ',') ? end + 1 : end;
+      if (*end != ',' && *end != 0) break;
+    }
+    if (ids.size() < 2) ids.clear();
+  }
+  return ids;
+}
+bool wants_shards(const nidreg_desc* d) { return !d->ext_hist && !d->ext_out && !d->ext_stream && !(d->flags & NIDREG_FLAG_EXT_STREAM) && shard_devices(d).size() > 1; }
+
+int launch_exchange(ShardSet* set, int g) {
+  nidreg_handle* h = set->shards[size_t(g)];
+  ExchangeArgs a = set->xargs[h->hist_cur][g];
+  a.seq = set->seq;
+  const int grid = std::max(1, std::min(16, (a.words / a.n + kThreads - 1) / kThreads));
+  hipLaunchKernelGGL(k_shard_exchange, dim3(grid), dim3(kThreads), 0, h->stream, a, h->d_counters + 2, h->d_out + 10, h->d_out_host ? h->d_out_host + 10 : nullptr, set->timeout_ticks);
+  HIP_TRY(hipGetLastError());
+  return NIDREG_OK;
+}
+
+// one shard's part of one evaluation: launches + completion wait; called concurrently for different shards
+int run_shard(ShardSet* set, int g) {
+  nidreg_handle* h = set->shards[size_t(g)];
+  HIP_TRY(hipSetDevice(h->device));
+  bump_seq(h);
+  if (h->timing) HIP_TRY(hipEventRecord(h->ev[0], h->stream));
+  int rc;
+  if (set->job_mode == NIDREG_MODE_SPLINE) {
+    rc = launch_hist_spline(h, set->job_pose);
+  } else {
+    rc = launch_hist_nearest(h, set->job_pose);
+  }
+  if (rc) return rc;
+  if (h->timing) HIP_TRY(hipEventRecord(h->ev[2], h->stream));
+  rc = launch_exchange(set, g);
+  if (rc) return rc;
+  const bool grad = set->job_mode == NIDREG_MODE_SPLINE && set->job_grad;
+  rc = launch_entropy(h, grad ? 0.0 : h->seq);  // timing: the "entropy" interval of a shard includes the exchange
+  if (rc) return rc;
+  if (h->timing) HIP_TRY(hipEventRecord(h->ev[3], h->stream));
+  if (grad) {
+    rc = launch_grad(h);  // records ev[4]
+    if (rc) return rc;
+  } else if (h->timing) {
+    HIP_TRY(hipEventRecord(h->ev[4], h->stream));
+  }
+  if (h->timing) HIP_TRY(hipEventRecord(h->ev[5], h->stream));
+  h->ev_grad = grad;
+  std::array<double, 8>& r = set->res[size_t(g)];
+  rc = eval_finish(h, &r[0], grad ? &r[1] : nullptr);
+  if (rc >= 0 && h->h_out[10] != 0.0) return fail(NIDREG_ERR_HIP, "sharded evaluation: the histogram exchange timed out waiting for a peer GPU");
+  return rc;
+}
+
+void shard_worker(ShardSet* set, int g) {
+  uint64_t seen = 0;
+  for (;;) {
+    // wait for the next generation: a few hundred microseconds of paused spinning (an optimiser calls back to back),
+    // then sleep
+    unsigned spins = 0;
+    while (set->gen.load(std::memory_order_acquire) == seen && !set->stop.load(std::memory_order_acquire)) {
+      if (++spins < 20000) {
+        for (int k = 0; k < 8; k++) __builtin_ia32_pause();
+      } else {
+        std::unique_lock<std::mutex> lk(set->mu);
+        set->sleepers.fetch_add(1);
+        set->cv.wait(lk, [&] { return set->gen.load(std::memory_order_acquire) != seen || set->stop.load(std::memory_order_acquire); });
+        set->sleepers.fetch_sub(1);
+      }
+    }
+    if (set->stop.load(std::memory_order_acquire)) return;
+    seen = set->gen.load(std::memory_order_acquire);
+    set->rc[size_t(g)] = run_shard(set, g);
+    set->pending.fetch_sub(1, std::memory_order_release);
+  }
+}
+
+// the whole set: one evaluation.  mode SPLINE: pose = se3[7]; NEAREST: pose = row-major 4x4
+int set_eval(ShardSet* set, int mode, const double* pose, double* cost, double* grad7) {
+  const int n = int(set->shards.size());
+  if (set->shards[0]->mode != mode) return fail(NIDREG_ERR_INVALID, mode == NIDREG_MODE_SPLINE ? "nidreg_eval: handle was created in NEAREST mode" : "nidreg_eval_iso: handle was created in SPLINE mode");
+  set->seq++;
+  set->job_mode = mode;
+  set->job_grad = grad7 != nullptr;
+  std::memcpy(set->job_pose, pose, (mode == NIDREG_MODE_SPLINE ? 7 : 16) * sizeof(double));
+  set->pending.store(n - 1, std::memory_order_relaxed);
+  set->gen.fetch_add(1, std::memory_order_release);
+  if (set->sleepers.load() > 0) {
+    std::lock_guard<std::mutex> lk(set->mu);
+    set->cv.notify_all();
+  }
+  set->rc[0] = run_shard(set, 0);
+  unsigned spins = 0;
+  while (set->pending.load(std::memory_order_acquire) > 0) {
+    if (++spins < 4096) {
+      __builtin_ia32_pause();
+    } else {
+      struct timespec ts = {0, 20000};
+      nanosleep(&ts, nullptr);
+    }
+  }
+  bool all_ok = true;
+  for (int g = 0; g < n; g++) {
+    if (set->rc[size_t(g)] < 0) return fail(set->rc[size_t(g)], "sharded evaluation failed on shard " + std::to_string(g) + " (device " + std::to_string(set->shards[size_t(g)]->device) + ")");
+    if (set->rc[size_t(g)] == NIDREG_FALSE) all_ok = false;
+  }
+  if (cost) *cost = set->res[0][0];  // identical bits on every shard (same integer histogram, same arithmetic)
+  if (grad7) {
+    for (int k = 0; k < 7; k++) {
+      double t = 0.0;
+      for (int g = 0; g < n; g++) t += set->res[size_t(g)][size_t(1 + k)];  // fixed order: run-to-run reproducible
+      grad7[k] = t;
+    }
+  }
+  return all_ok ? NIDREG_OK : NIDREG_FALSE;
+}
+
+void free_shard_set(ShardSet* set) {
+  if (!set) return;
+  set->stop.store(true, std::memory_order_release);
+  {
+    std::lock_guard<std::mutex> lk(set->mu);
+    set->cv.notify_all();
+  }
+  for (auto& t : set->workers)
+    if (t.joinable()) t.join();
+  for (size_t g = 0; g < set->shards.size(); g++) {
+    nidreg_handle* h = set->shards[g];
+    if (h) {
+      (void)hipSetDevice(h->device);
+      if (h->stream) (void)hipStreamSynchronize(h->stream);
+    }
+  }
+  for (size_t g = 0; g < set->flags.size(); g++) {
+    if (set->flags[g]) {
+      (void)hipSetDevice(set->shards[g]->device);
+      (void)hipFree(set->flags[g]);
+    }
+  }
+  for (size_t g = 1; g < set->shards.size(); g++) free_handle(set->shards[g]);
+  delete set;
+}
+
+// exchange self-test at creation: two rounds of a known pattern through the real kernel; the second round has
+// different values at the same addresses, so a peer read served from a stale cache line cannot pass
+int shard_self_test(ShardSet* set) {
+  const int n = int(set->shards.size());
+  const int words = int(set->shards[0]->hist_words);
+  std::vector<u64> got(static_cast<size_t>(words));
+  for (u64 round = 1; round <= 2; round++) {
+    set->seq++;
+    for (int g = 0; g < n; g++) {
+      nidreg_handle* h = set->shards[size_t(g)];
+      HIP_TRY(hipSetDevice(h->device));
+      HIP_TRY(begin_histogram(h));
+      hipLaunchKernelGGL(k_shard_pattern, dim3((words + 255) / 256), dim3(256), 0, h->stream, h->d_hist, words, u64(g), round);
+      HIP_TRY(hipGetLastError());
+      const int rc = launch_exchange(set, g);
+      if (rc) return rc;
+    }
+    for (int g = 0; g < n; g++) {
+      nidreg_handle* h = set->shards[size_t(g)];
+      HIP_TRY(hipSetDevice(h->device));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      double err = 0.0;
+      HIP_TRY(hipMemcpy(&err, h->d_out + 10, sizeof(double), hipMemcpyDeviceToHost));
+      if (err != 0.0) return fail(NIDREG_ERR_HIP, "sharded handle: exchange self-test timed out on device " + std::to_string(h->device) + " (peer access between the GPUs is not working)");
+      HIP_TRY(hipMemcpy(got.data(), h->d_hist_full, got.size() * sizeof(u64), hipMemcpyDeviceToHost));
+      for (int k = 0; k < words; k++) {
+        u64 want = 0;
+        for (int p = 0; p < n; p++) want += (u64(p) + 1) * 1000003ull + round * 7919ull + u64(k) * (u64(p) + 3);
+        if (got[size_t(k)] != want)
+          return fail(NIDREG_ERR_HIP, "sharded handle: exchange self-test mismatch on device " + std::to_string(h->device) + " word " + std::to_string(k) + " round " + std::to_string(round));
+      }
+      // leave the buffers as an evaluation expects them: the partial just used is dirty
+      h->hist_zeroed[h->hist_cur] = false;
+      HIP_TRY(hipMemsetAsync(h->d_hist_full, 0, got.size() * sizeof(u64), h->stream));
+    }
+  }
+  for (int g = 0; g < n; g++) {
+    nidreg_handle* h = set->shards[size_t(g)];
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  return NIDREG_OK;
+}
+
+int create_sharded(const nidreg_desc* d, nidreg_handle** out) {
+  *out = nullptr;
+  const std::vector<int> ids = shard_devices(d);
+  const int n = int(ids.size());
+  if (n > kMaxShards) return fail(NIDREG_ERR_INVALID, "nidreg_create: at most 16 shards");
+  if (d->num_points < 0 || (d->num_points > 0 && (!d->points || !d->intensities))) return fail(NIDREG_ERR_INVALID, "nidreg_create: null points");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(NIDREG_ERR_NO_DEVICE, "nidreg_create: no HIP device (the NID core has no CPU path)");
+  for (int id : ids)
+    if (id < 0 || id >= ndev) return fail(NIDREG_ERR_INVALID, "nidreg_create: device id " + std::to_string(id) + " out of range (NIDREG_DEVICES / desc.device_ids)");
+  // peer mappings, both directions, before any buffer is allocated
+  for (int i = 0; i < n; i++) {
+    for (int j = 0; j < n; j++) {
+      if (ids[size_t(i)] == ids[size_t(j)]) continue;
+      int can = 0;
+      HIP_TRY(hipDeviceCanAccessPeer(&can, ids[size_t(i)], ids[size_t(j)]));
+      if (!can) return fail(NIDREG_ERR_HIP, "nidreg_create: device " + std::to_string(ids[size_t(i)]) + " cannot map the memory of device " + std::to_string(ids[size_t(j)]));
+      HIP_TRY(hipSetDevice(ids[size_t(i)]));
+      const hipError_t e = hipDeviceEnablePeerAccess(ids[size_t(j)], 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(NIDREG_ERR_HIP, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+      (void)hipGetLastError();
+    }
+  }
+  ShardSet* set = new ShardSet();
+  set->shards.assign(size_t(n), nullptr);
+  set->flags.assign(size_t(n), nullptr);
+  set->rc.assign(size_t(n), 0);
+  set->res.assign(size_t(n), std::array<double, 8>());
+  if (const char* t = std::getenv("NIDREG_SHARD_TIMEOUT_MS")) set->timeout_ticks = 100000ull * (unsigned long long)std::max(1L, std::strtol(t, nullptr, 10));
+  const int64_t N = d->num_points;
+  const int64_t pstride = d->point_stride > 0 ? d->point_stride : 32;
+  auto bail = [&](int rc) {
+    nidreg_handle* lead = set->shards[0];
+    if (lead) {
+      lead->set = set;
+      free_handle(lead);  // frees the set (and through it the other shards)
+    } else {
+      free_shard_set(set);
+    }
+    return rc;
+  };
+  // contiguous, disjoint, exhaustive point slices; every shard uses the fixed-point unit of the WHOLE cloud.
+  // The shards are built concurrently (upload + sort per device).
+  {
+    std::vector<std::thread> th;
+    std::vector<int> rcs(size_t(n), 0);
+    std::vector<std::string> errs(static_cast<size_t>(n));
+    for (int g = 0; g < n; g++) {
+      th.emplace_back([&, g]() {
+        nidreg_desc sd = *d;
+        const int64_t lo = N * g / n, hi = N * (g + 1) / n;
+        sd.device_id = ids[size_t(g)];
+        sd.num_devices = 1;
+        sd.num_points = hi - lo;
+        sd.points = reinterpret_cast<const double*>(reinterpret_cast<const char*>(d->points) + lo * pstride);
+        sd.intensities = d->intensities + lo;
+        sd.scale_points = std::max<int64_t>(N, d->scale_points);
+        CreateOpts o;
+        o.shard = true;
+        rcs[size_t(g)] = create_impl(&sd, nullptr, nullptr, 0.0, 0, o, &set->shards[size_t(g)]);
+        if (rcs[size_t(g)]) errs[size_t(g)] = g_last_error;
+      });
+    }
+    for (auto& t : th) t.join();
+    for (int g = 0; g < n; g++)
+      if (rcs[size_t(g)]) return bail(fail(rcs[size_t(g)], "shard " + std::to_string(g) + ": " + errs[size_t(g)]));
+  }
+  for (int g = 0; g < n; g++) {
+    nidreg_handle* h = set->shards[size_t(g)];
+    hipError_t e = hipSetDevice(h->device);
+    if (e == hipSuccess) e = hipExtMallocWithFlags(reinterpret_cast<void**>(&set->flags[size_t(g)]), 2 * kMaxShards * sizeof(u64), hipDeviceMallocFinegrained);
+    if (e == hipSuccess) e = hipMemset(set->flags[size_t(g)], 0, 2 * kMaxShards * sizeof(u64));
+    if (e != hipSuccess) return bail(fail(NIDREG_ERR_HIP, std::string("sharded handle: flag block: ") + hipGetErrorString(e)));
+  }
+  for (int par = 0; par < 2; par++) {
+    for (int g = 0; g < n; g++) {
+      ExchangeArgs& a = set->xargs[par][g];
+      std::memset(&a, 0, sizeof(a));
+      for (int p = 0; p < n; p++) {
+        a.part[p] = set->shards[size_t(p)]->d_hist_buf[par];
+        a.full[p] = set->shards[size_t(p)]->d_hist_full;
+        a.flags[p] = set->flags[size_t(p)];
+      }
+      a.n = n;
+      a.me = g;
+      a.words = int(set->shards[0]->hist_words);
+    }
+  }
+  {
+    const int rc = shard_self_test(set);
+    if (rc) return bail(rc);
+  }
+  for (int g = 1; g < n; g++) set->workers.emplace_back(shard_worker, set, g);
+  nidreg_handle* lead = set->shards[0];
+  lead->set = set;
+  int64_t total = 0;
+  for (int g = 0; g < n; g++) total += set->shards[size_t(g)]->num_points;
+  (void)total;
+  *out = lead;
   return NIDREG_OK;
 }
 
@@ -757,7 +1075,10 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
 
 extern "C" {
 
-int nidreg_create(const nidreg_desc* d, nidreg_handle** out) { return create_impl(d, nullptr, nullptr, 0.0, 0, out); }
+int nidreg_create(const nidreg_desc* d, nidreg_handle** out) {
+  if (d && d->struct_size == int32_t(sizeof(nidreg_desc)) && wants_shards(d)) return create_sharded(d, out);
+  return create_impl(d, nullptr, nullptr, 0.0, 0, CreateOpts(), out);
+}
 
 int nidreg_cloud_create(int device_id, const double* points, int64_t point_stride, const double* intensities, int64_t num_points, nidreg_cloud** out) {
   if (!out || num_points < 0 || num_points > int64_t(INT_MAX) || (num_points > 0 && (!points || !intensities))) return fail(NIDREG_ERR_INVALID, "nidreg_cloud_create: bad argument");
@@ -801,20 +1122,35 @@ void nidreg_cloud_destroy(nidreg_cloud* c) {
 
 int nidreg_create_from_cloud(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T_camera_lidar, double min_z, int enable_depth_buffer_culling, nidreg_handle** out) {
   if (!cloud) return fail(NIDREG_ERR_INVALID, "nidreg_create_from_cloud: null cloud");
-  return create_impl(d, cloud, T_camera_lidar, min_z, enable_depth_buffer_culling, out);
+  return create_impl(d, cloud, T_camera_lidar, min_z, enable_depth_buffer_culling, CreateOpts(), out);
 }
 
 void nidreg_destroy(nidreg_handle* h) { free_handle(h); }
 
 int nidreg_eval(nidreg_handle* h, const double* se3, double* cost, double* grad7) {
   if (!h || !se3) return fail(NIDREG_ERR_INVALID, "nidreg_eval: null argument");
+  if (h->set) return set_eval(h->set, NIDREG_MODE_SPLINE, se3, cost, grad7);
   const int rc = eval_launch(h, se3, grad7 != nullptr);
   if (rc) return rc;
   return eval_finish(h, cost, grad7);
 }
 
+int nidreg_eval_batch(nidreg_handle* h, const double* se3s, int n, double* costs, double* grads7) {
+  if (!h || !se3s || n < 0) return fail(NIDREG_ERR_INVALID, "nidreg_eval_batch: bad argument");
+  int worst = NIDREG_OK;
+  for (int i = 0; i < n; i++) {
+    double c = 0.0;
+    const int rc = nidreg_eval(h, se3s + 7 * size_t(i), &c, grads7 ? grads7 + 7 * size_t(i) : nullptr);
+    if (rc < 0) return rc;
+    if (rc != NIDREG_OK) worst = rc;
+    if (costs) costs[i] = c;
+  }
+  return worst;
+}
+
 int nidreg_eval_iso(nidreg_handle* h, const double* T, double* cost) {
   if (!h || !T) return fail(NIDREG_ERR_INVALID, "nidreg_eval_iso: null argument");
+  if (h->set) return set_eval(h->set, NIDREG_MODE_NEAREST, T, cost, nullptr) < 0 ? NIDREG_ERR_HIP : NIDREG_OK;
   const int rc = iso_launch(h, T);
   if (rc) return rc;
   return eval_finish(h, cost, nullptr) < 0 ? NIDREG_ERR_HIP : NIDREG_OK;  // CostCalculatorNID has no finite check
@@ -824,6 +1160,8 @@ int nidreg_eval_multi(nidreg_handle* const* handles, int n, const double* init_s
   if (!handles || n <= 0 || !se3) return fail(NIDREG_ERR_INVALID, "nidreg_eval_multi: bad argument");
   if (init_se3 && !trust_gate_ok(init_se3, se3)) return NIDREG_FALSE;
   for (int i = 0; i < n; i++) {
+    if (!handles[i]) return fail(NIDREG_ERR_INVALID, "nidreg_eval_multi: null handle");
+    if (handles[i]->set) continue;  // a pair sharded over several GPUs: evaluated through its set below
     const int rc = eval_launch(handles[i], se3, grad7 != nullptr);
     if (rc) return rc;
   }
@@ -831,7 +1169,7 @@ int nidreg_eval_multi(nidreg_handle* const* handles, int n, const double* init_s
   bool all_ok = true;
   for (int i = 0; i < n; i++) {
     double c = 0.0, g[7];
-    const int rc = eval_finish(handles[i], &c, grad7 ? g : nullptr);
+    const int rc = handles[i]->set ? set_eval(handles[i]->set, NIDREG_MODE_SPLINE, se3, &c, grad7 ? g : nullptr) : eval_finish(handles[i], &c, grad7 ? g : nullptr);
     if (rc < 0) return rc;
     if (rc == NIDREG_FALSE) all_ok = false;
     csum += c;
@@ -847,13 +1185,15 @@ int nidreg_eval_multi(nidreg_handle* const* handles, int n, const double* init_s
 int nidreg_eval_iso_multi(nidreg_handle* const* handles, int n, const double* T, double* cost) {
   if (!handles || n <= 0 || !T) return fail(NIDREG_ERR_INVALID, "nidreg_eval_iso_multi: bad argument");
   for (int i = 0; i < n; i++) {
+    if (!handles[i]) return fail(NIDREG_ERR_INVALID, "nidreg_eval_iso_multi: null handle");
+    if (handles[i]->set) continue;
     const int rc = iso_launch(handles[i], T);
     if (rc) return rc;
   }
   double csum = 0.0;
   for (int i = 0; i < n; i++) {
     double c = 0.0;
-    const int rc = eval_finish(handles[i], &c, nullptr);
+    const int rc = handles[i]->set ? set_eval(handles[i]->set, NIDREG_MODE_NEAREST, T, &c, nullptr) : eval_finish(handles[i], &c, nullptr);
     if (rc < 0) return rc;
     csum += c;
   }
@@ -867,7 +1207,7 @@ int nidreg_get_hist_fixed(nidreg_handle* h, int64_t* joint, int64_t* inliers, in
   HIP_TRY(hipStreamSynchronize(h->stream));
   const int B = h->bins;
   std::vector<u64> tmp(size_t(h->hist_words));
-  HIP_TRY(hipMemcpy(tmp.data(), h->d_hist, tmp.size() * sizeof(u64), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(tmp.data(), hist_source(h), tmp.size() * sizeof(u64), hipMemcpyDeviceToHost));
   if (joint) {
     // device layout [bin_points][bin_image] -> [bin_image][bin_points]
     for (int c = 0; c < B; c++)
@@ -885,7 +1225,7 @@ int nidreg_get_hist(nidreg_handle* h, double* joint, double* hist_image, double*
     std::vector<int64_t> fx(size_t(B) * B);
     const int rc = nidreg_get_hist_fixed(h, fx.data(), nullptr, nullptr);
     if (rc) return rc;
-    const double inv_unit = std::ldexp(1.0, -h->frac_bits);
+    const double inv_unit = 1.0 / fixed_unit(h);
     for (size_t k = 0; k < fx.size(); k++) joint[k] = double(fx[k]) * inv_unit;
   }
   HIP_TRY(hipSetDevice(h->device));
@@ -937,9 +1277,10 @@ int64_t nidreg_view_culling(int model_id, const double* intrinsics, const double
   if (num_points == 0) return 0;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(NIDREG_ERR_NO_DEVICE, "nidreg_view_culling: no HIP device");
+  if (device_id < 0 || device_id >= ndev) return fail(NIDREG_ERR_INVALID, "nidreg_view_culling: device_id out of range");
   HIP_TRY(hipSetDevice(device_id));
   const int64_t stride = point_stride > 0 ? point_stride : 32;
-  if (stride % 8 != 0) return fail(NIDREG_ERR_INVALID, "nidreg_view_culling: point_stride must be a multiple of 8");
+  if (stride % 8 != 0 || stride < 32) return fail(NIDREG_ERR_INVALID, "nidreg_view_culling: point_stride must be a multiple of 8 and >= 32 ((x y z 1) doubles)");
   double* d_pts = nullptr;
   int* d_pix = nullptr;
   unsigned int* d_zbuf = nullptr;
@@ -970,6 +1311,7 @@ int64_t nidreg_view_culling(int model_id, const double* intrinsics, const double
 int nidreg_shard_hist(nidreg_handle* h, const double* se3) {
   if (!h || !se3) return fail(NIDREG_ERR_INVALID, "nidreg_shard_hist: null argument");
   if (h->mode != NIDREG_MODE_SPLINE) return fail(NIDREG_ERR_INVALID, "nidreg_shard_hist: SPLINE handles only");
+  if (h->set || h->is_shard) return fail(NIDREG_ERR_INVALID, "nidreg_shard_hist: the handle is already sharded inside the library (desc.device_ids / NIDREG_DEVICES)");
   HIP_TRY(hipSetDevice(h->device));
   return launch_hist_spline(h, se3);
 }
@@ -1013,6 +1355,36 @@ int nidreg_get_timing(nidreg_handle* h, float* ms6) {
   return NIDREG_OK;
 }
 
+int nidreg_num_shards(nidreg_handle* h) {
+  if (!h) return 0;
+  return h->set ? int(h->set->shards.size()) : 1;
+}
+
+int nidreg_shard_devices(nidreg_handle* h, int* device_ids, int capacity) {
+  if (!h || !device_ids) return fail(NIDREG_ERR_INVALID, "nidreg_shard_devices: null argument");
+  if (!h->set) {
+    if (capacity > 0) device_ids[0] = h->device;
+    return 1;
+  }
+  const int n = int(h->set->shards.size());
+  for (int g = 0; g < n && g < capacity; g++) device_ids[g] = h->set->shards[size_t(g)]->device;
+  return n;
+}
+
+void nidreg_trim(void) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess) return;
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  for (int dev = 0; dev < ndev && dev < 64; dev++) {
+    ScratchArena& a = ScratchArena::of(dev);
+    std::lock_guard<ScratchArena> guard(a);
+    (void)hipSetDevice(dev);
+    a.release();
+  }
+  (void)hipSetDevice(cur);
+}
+
 int nidreg_get_info(nidreg_handle* h, int64_t* info8) {
   if (!h || !info8) return fail(NIDREG_ERR_INVALID, "nidreg_get_info: null argument");
   info8[0] = h->rec64 ? int64_t(sizeof(Rec64)) : int64_t(sizeof(Rec32));
@@ -1022,6 +1394,10 @@ int nidreg_get_info(nidreg_handle* h, int64_t* info8) {
   info8[4] = int64_t(h->lds_hist);
   info8[5] = h->pitch;
   info8[6] = h->num_points;
+  if (h->set) {
+    info8[6] = 0;
+    for (nidreg_handle* sh : h->set->shards) info8[6] += sh->num_points;
+  }
   info8[7] = (h->rec64 ? 0 : 1) | (int64_t(1 << h->cshift) << 8);
   return NIDREG_OK;
 }

@@ -124,7 +124,7 @@ class Cloud:
 class _Handle:
     """RAII owner of one ``nidreg_handle`` (device residency of one LiDAR-camera pair)."""
 
-    def __init__(self, proj, image, points, intensities, bins, mode, precision, device, max_fov=0.0, columns_per_group=0, target_blocks=0, scale_points=0, flags=0, lds_copies=0, ext_stream=None, ext_hist=None, ext_out=None, cloud=None, cull=None):
+    def __init__(self, proj, image, points, intensities, bins, mode, precision, device, max_fov=0.0, columns_per_group=0, target_blocks=0, scale_points=0, flags=0, lds_copies=0, ext_stream=None, ext_hist=None, ext_out=None, cloud=None, cull=None, devices=None):
         if proj is None:
             raise ValueError("camera is None (create_camera failed)")
         lib = _lib.load()
@@ -173,6 +173,16 @@ class _Handle:
         d.ext_stream = ext_stream
         d.ext_hist = ext_hist
         d.ext_out = ext_out
+        if devices is not None:
+            # one pair sharded over several GPUs inside the library (single process, direct GPU-to-GPU histogram exchange)
+            devices = [int(v) for v in devices]
+            if len(devices) > 16:
+                raise ValueError("at most 16 devices")
+            d.num_devices = len(devices)
+            for i, v in enumerate(devices):
+                d.device_ids[i] = v
+            if devices:
+                d.device_id = devices[0]
         h = ctypes.c_void_p()
         if cloud is None:
             _lib.check(lib.nidreg_create(ctypes.byref(d), ctypes.byref(h)), "nidreg_create")
@@ -196,6 +206,14 @@ class _Handle:
             self.close()
         except Exception:
             pass
+
+    def num_shards(self):
+        return int(self._lib.nidreg_num_shards(self.h))
+
+    def shard_devices(self):
+        ids = (ctypes.c_int * 16)()
+        n = self._lib.nidreg_shard_devices(self.h, ids, 16)
+        return [int(ids[i]) for i in range(min(n, 16))]
 
     # ---- diagnostics shared by both cost classes
     def histograms(self):
@@ -261,6 +279,15 @@ class NIDCost(_Handle):
         grad = np.empty(7) if want_grad else None
         rc = _lib.check(self._lib.nidreg_eval(self.h, _dp(x), ctypes.byref(cost), _dp(grad)), "nidreg_eval")
         return rc == _lib.NIDREG_OK, cost.value, grad
+
+    def eval_batch(self, poses, want_grad=True):
+        """``n`` synchronous evaluations back to back inside the library (an optimiser's inner loop without the
+        per-call Python / ctypes overhead).  Returns ``(all_ok, costs[n], grads[n,7] | None)``."""
+        x = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 7)
+        costs = np.empty(x.shape[0])
+        grads = np.empty((x.shape[0], 7)) if want_grad else None
+        rc = _lib.check(self._lib.nidreg_eval_batch(self.h, _dp(x), x.shape[0], _dp(costs), _dp(grads)), "nidreg_eval_batch")
+        return rc == _lib.NIDREG_OK, costs, grads
 
     # split-phase API for point-sharded multi-GPU evaluation (see parallel.ShardedNIDCost)
     def shard_hist(self, x):

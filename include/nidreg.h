@@ -22,8 +22,12 @@
  *   nidreg_generate_lidar_image  vlcal::generate_lidar_image   (src/vlcal/preprocess/generate_lidar_image.cpp:7-41)
  *   nidreg_equalize_intensities  the rank equalisation loop    (src/vlcal/preprocess/preprocess.cpp:464-473)
  *   nidreg_shard_*           (no reference counterpart) split-phase evaluation of one pair whose
- *                            points are sharded over several GPUs; the caller all-reduces the
- *                            fixed-point histogram (RCCL) between the phases.
+ *                            points are sharded over several GPUs, ONE PROCESS PER GPU; the caller
+ *                            all-reduces the fixed-point histogram (RCCL) between the phases.
+ *   desc.num_devices /       (no reference counterpart) the same sharding inside ONE process: nidreg_create
+ *   NIDREG_DEVICES           splits the cloud over the listed GPUs and nidreg_eval* exchange the histogram
+ *                            GPU to GPU themselves (the reference's calibrate is a single process,
+ *                            src/calibrate.cpp:117-120)
  *   nidreg_destroy           ~NIDCost / ~CostCalculatorNID
  *
  * Conventions
@@ -75,6 +79,7 @@ extern "C" {
 #define NIDREG_IMAGE_U8 1   /* CV_8UC1 (what CostCalculatorNID receives) */
 
 #define NIDREG_MAX_BINS 256
+#define NIDREG_MAX_DEVICES 16
 
 /* nidreg_desc.flags */
 #define NIDREG_FLAG_EXT_STREAM 2  /* launch on desc.ext_stream even when it is NULL (= the legacy default
@@ -115,6 +120,14 @@ typedef struct nidreg_desc {
   void* ext_stream;         /* hipStream_t the handle launches on */
   void* ext_hist;           /* device buffer of nidreg_hist_words(bins) 64-bit words */
   void* ext_out;            /* device buffer of NIDREG_OUT_DOUBLES doubles */
+  /* one pair sharded over several GPUs inside the library (single process): num_devices > 1 splits the cloud into
+     contiguous point slices, one per device_ids[k], and nidreg_eval* then run every slice on its GPU with a direct
+     GPU-to-GPU all-reduce of the fixed-point histogram (results are bit-identical to the unsharded handle's cost;
+     the gradient differs by summation order only).  0 = device_id alone, unless the environment variable
+     NIDREG_DEVICES="0,1,..." is set -- which shards every handle built from host arrays, so a caller that knows
+     nothing about GPUs (the reference's `new NIDCost(proj, image, points, bins)`) uses the whole node. */
+  int32_t num_devices;
+  int32_t device_ids[NIDREG_MAX_DEVICES];
 } nidreg_desc;
 
 #define NIDREG_OUT_DOUBLES 16  /* [0]=cost [1..7]=grad7 [8]=status [9]=inliers [10..15] reserved */
@@ -139,6 +152,11 @@ int nidreg_create_from_cloud(const nidreg_desc* desc, const nidreg_cloud* cloud,
 
 /* NIDCost::operator(): cost (+ gradient when grad7 != NULL) at se3 = [qx qy qz qw tx ty tz] */
 int nidreg_eval(nidreg_handle* h, const double* se3, double* cost, double* grad7);
+
+/* n synchronous nidreg_eval calls back to back, as an optimiser's inner loop issues them (each evaluation completes --
+ * host sync included -- before the next starts): se3s n x 7, costs n (nullable), grads7 n x 7 (NULL = cost only).
+ * Returns < 0 on the first error, else NIDREG_FALSE if any evaluation was rejected, else NIDREG_OK. */
+int nidreg_eval_batch(nidreg_handle* h, const double* se3s, int n, double* costs, double* grads7);
 
 /* CostCalculatorNID::calculate at a row-major 4x4 T_camera_lidar */
 int nidreg_eval_iso(nidreg_handle* h, const double* T_camera_lidar, double* cost);
@@ -219,6 +237,13 @@ int nidreg_shard_hist(nidreg_handle* h, const double* se3);
 int nidreg_shard_entropy(nidreg_handle* h);
 int nidreg_shard_grad(nidreg_handle* h);
 int nidreg_shard_finish(nidreg_handle* h, double* cost, double* grad7);
+
+/* number of GPUs a handle is sharded over (1 = plain handle) and their device ordinals */
+int nidreg_num_shards(nidreg_handle* h);
+int nidreg_shard_devices(nidreg_handle* h, int* device_ids, int capacity);
+
+/* release the per-device scratch arenas that handle construction keeps between calls (upload staging, sort keys) */
+void nidreg_trim(void);
 
 /* device-side timing of the most recent nidreg_eval / nidreg_eval_iso in milliseconds (HIP events
  * recorded on the handle's stream, i.e. the stream the kernels run on):

@@ -5,8 +5,11 @@
 // reference computes in the constructor (cost_calculator_nid.cpp:13-17); here it is passed in or
 // estimated by the caller-supplied functor so this header stays free of the optimiser dependency.
 #pragma once
+#include <iostream>
+#include <limits>
 #include <memory>
 #include <stdexcept>
+#include <string>
 
 #include "camera.hpp"
 #ifdef NIDREG_WITH_REFERENCE_DEPS
@@ -73,7 +76,12 @@ public:
     for (int r = 0; r < 4; r++)
       for (int c = 0; c < 4; c++) T[r * 4 + c] = r < 3 ? T_camera_lidar(r, c) : (c == 3 ? 1.0 : 0.0);  // (r,c) access works for Eigen's column-major storage too
     double cost = 0.0;
-    if (nidreg_eval_iso(handle.get(), T, &cost) < 0) throw std::runtime_error(std::string("vlcal::CostCalculatorNID: ") + nidreg_last_error());
+    if (nidreg_eval_iso(handle.get(), T, &cost) < 0) {
+      // called inside `#pragma omp parallel for` (visual_camera_calibration.cpp:107), where an escaping exception is
+      // std::terminate: report, and hand the simplex a value it will never accept
+      std::cerr << "vlcal::CostCalculatorNID: " << nidreg_last_error() << std::endl;
+      return std::numeric_limits<double>::max();
+    }
     return cost;
   }
 

@@ -9,7 +9,9 @@
 #include <iostream>
 #include <memory>
 #include <stdexcept>
+#include <string>
 #include <type_traits>
+#include <vector>
 
 #include "camera.hpp"
 #ifdef NIDREG_WITH_REFERENCE_DEPS
@@ -43,10 +45,15 @@ private:
 
 class NIDCost {
 public:
+  // device_ids (optional extension): more than one entry shards the pair's points over those GPUs inside the library
+  // (single process; the histogram is all-reduced GPU to GPU).  Without it the environment variable NIDREG_DEVICES
+  // does the same for a caller that cannot be changed (visual_camera_calibration.cpp:206).
   NIDCost(const camera::GenericCameraBase::ConstPtr& proj, const cv::Mat& normalized_image, const Frame::ConstPtr& points, const int bins = 16, const int device_id = 0,
-          const int precision = NIDREG_PREC_FP64)
+          const int precision = NIDREG_PREC_FP64, const std::vector<int>& device_ids = std::vector<int>())
   {
     nidreg_desc d{};
+    d.num_devices = static_cast<int32_t>(device_ids.size() > NIDREG_MAX_DEVICES ? NIDREG_MAX_DEVICES : device_ids.size());
+    for (int i = 0; i < d.num_devices; i++) d.device_ids[i] = device_ids[static_cast<size_t>(i)];
     d.struct_size = sizeof(nidreg_desc);
     d.device_id = device_id;
     d.model_id = proj->nidreg_model_id();
@@ -99,14 +106,12 @@ public:
     double cost = 0.0;
     if constexpr (std::is_same<T, double>::value) {
       const int rc = nidreg_eval(handle.get(), se3, &cost, nullptr);
-      if (rc < 0) throw std::runtime_error(std::string("vlcal::NIDCost: ") + nidreg_last_error());
-      if (rc == NIDREG_FALSE) return false;  // non-finite NID (nid_cost.hpp:98-102)
+      if (rc != NIDREG_OK) return reject(rc);  // non-finite NID (nid_cost.hpp:98-102), or an engine error
       residual[0] = cost;
     } else {
       double grad[7];
       const int rc = nidreg_eval(handle.get(), se3, &cost, grad);
-      if (rc < 0) throw std::runtime_error(std::string("vlcal::NIDCost: ") + nidreg_last_error());
-      if (rc == NIDREG_FALSE) return false;
+      if (rc != NIDREG_OK) return reject(rc);
       // chain rule through whatever partials the caller seeded: residual.v = sum_k grad[k] * params[k].v
       T r = T_camera_lidar_params[0];
       r.a = cost;
@@ -122,6 +127,21 @@ public:
   }
 
   nidreg_handle* native_handle() const { return handle.get(); }
+  // text of the last engine error this functor swallowed (empty = none)
+  const std::string& last_error() const { return *error; }
+
+private:
+  // The functor contract is `return false` (an invalid step for Ceres' line search): the reference calls it inside
+  // `#pragma omp parallel for` (visual_camera_calibration.cpp:161), where an escaping exception is std::terminate.
+  // An engine error (rc < 0) is therefore reported on stderr, kept in last_error(), and rejected like a non-finite NID.
+  bool reject(const int rc) const {
+    if (rc < 0) {
+      *error = nidreg_last_error();
+      std::cerr << "vlcal::NIDCost: " << *error << std::endl;
+    }
+    return false;
+  }
+  std::shared_ptr<std::string> error = std::make_shared<std::string>();
 
 private:
   std::shared_ptr<nidreg_handle> handle;

@@ -39,7 +39,8 @@ static int run(const CamParams<double>& cam, int W, int H, int B, const std::vec
   int nbits = 1;
   while ((int64_t(1) << nbits) <= N) nbits++;
   const int frac = std::min(40, 62 - nbits);
-  const double dn = std::ldexp(1.0, frac - 1074), inv_unit = std::ldexp(1.0, -frac);
+  const double unit = 6.0 * std::rint(std::ldexp(1.0, frac) / 6.0), inv_unit = 1.0 / unit;  // nidreg.hip fixed_unit
+  const BsplineScale KS = bspline_scale(std::ldexp(unit / 6.0, -1074));
 
   // ---- pass A (k_spline_hist body): fixed-point joint histogram [bin_points][bin_image], inlier count
   std::vector<u64> hist(size_t(B) * B, 0);
@@ -55,14 +56,13 @@ static int run(const CamParams<double>& cam, int W, int H, int B, const std::vec
     const bool in = (u >= 0.0) && (u < fW) && (v >= 0.0) && (v < fH);
     if (!in) continue;
     inliers++;
-    const double fu = std::floor(u), fv = std::floor(v);
-    double bx[4], by[4];
-    bspline<double>(u - fu, bx);
-    bspline<double>(v - fv, by);
+    double bxs[4], by[4];
+    bspline_scaled(std::fabs(m_fract(u)), KS, bxs);  // x-weights straight in fixed-point units (k_spline_hist's taps)
+    bspline<double>(std::fabs(m_fract(v)), by);
     uint32_t cols[4];
-    load_patch(img.data(), pitch, int(fu), int(fv), cols);
+    load_patch(img.data(), pitch, int(u), int(v), cols);
     for (int b = 0; b < 4; b++)
-      for (int a = 0; a < 4; a++) hist[size_t(bin_pts[size_t(i)]) * B + ((cols[a] >> (8 * b)) & 0xffu)] += to_fixed_dn(bx[a] * dn, by[b]);
+      for (int a = 0; a < 4; a++) hist[size_t(bin_pts[size_t(i)]) * B + ((cols[a] >> (8 * b)) & 0xffu)] += to_fixed_dn(bxs[a], by[b]);
   }
 
   // ---- entropy tail (k_entropy + entropy_final_body): hist_image = row sums, hist_points = column sums / unit
@@ -102,19 +102,20 @@ static int run(const CamParams<double>& cam, int W, int H, int B, const std::vec
   double acc[12] = {0};
   for (int64_t i = 0; i < N; i++) {
     const double x = double(float(pts[4 * i])), y = double(float(pts[4 * i + 1])), z = double(float(pts[4 * i + 2]));
-    double cx, cy, cz, uu, vv, du[3], dv[3];
+    double cx, cy, cz, uu, vv;
+    ProjCtx<double> ctx;
     transform_fma<double>(pose, x, y, z, cx, cy, cz);
-    project_jac<MODEL, double>(cam, cx, cy, cz, uu, vv, du, dv);
+    project_fwd<MODEL, double>(cam, cx, cy, cz, uu, vv, ctx);  // k_spline_grad's two halves around the tap loop
     const bool in = (uu >= 0.0) && (uu < fW) && (vv >= 0.0) && (vv < fH);
     if (!in) continue;
-    const double fu = std::floor(uu), fv = std::floor(vv);
+    const double sx = std::fabs(m_fract(uu)), sy = std::fabs(m_fract(vv));
     double bx[4], by[4], dbx[4], dby[4];
-    bspline<double>(uu - fu, bx);
-    bspline<double>(vv - fv, by);
-    bspline_deriv<double>(uu - fu, dbx);
-    bspline_deriv<double>(vv - fv, dby);
+    bspline<double>(sx, bx);
+    bspline<double>(sy, by);
+    bspline_deriv<double>(sx, dbx);
+    bspline_deriv<double>(sy, dby);
     uint32_t cols[4];
-    load_patch(img.data(), pitch, int(fu), int(fv), cols);
+    load_patch(img.data(), pitch, int(uu), int(vv), cols);
     const double* gcol = G.data() + size_t(bin_pts[size_t(i)]) * B;
     double gx = 0, gy = 0;
     for (int b = 0; b < 4; b++) {
@@ -127,7 +128,8 @@ static int run(const CamParams<double>& cam, int W, int H, int B, const std::vec
       gx = fma(sa, by[b], gx);
       gy = fma(sb, dby[b], gy);
     }
-    const double gp[3] = {fma(gx, du[0], gy * dv[0]), fma(gx, du[1], gy * dv[1]), fma(gx, du[2], gy * dv[2])};
+    double gp[3];
+    project_bwd<MODEL, double>(cam, ctx, gx, gy, gp);
     const double p[3] = {x, y, z};
     for (int r = 0; r < 3; r++) {
       for (int c = 0; c < 3; c++) acc[3 * r + c] = fma(gp[r], p[c], acc[3 * r + c]);

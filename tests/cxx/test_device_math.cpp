@@ -167,20 +167,33 @@ int main() {
     if (et > 2e-14) bad++;
   }
   // fixed point in one multiply (to_fixed_dn): x-weights pre-scaled by 2^(frac - 1074), so that bits(bx' * by) is
-  // the integer round(bx' * by * 2^frac); error <= 0.5 max(by) + 0.5 = 0.834 units of 2^-frac, exact zeros, sign bit never set
+  // the integer round(bx' * by * 2^frac); the x-weights come out of bspline_scaled already in fixed-point units; exact zeros, sign bit never set
   {
     std::mt19937_64 rng(11);
     std::uniform_real_distribution<double> U(0.0, 1.0);
     double worst = 0, worst_sum = 0;
     for (int frac = 34; frac <= 40; frac += 2) {
-      const double dn = std::ldexp(1.0, frac - 1074), unit = std::ldexp(1.0, frac);
+      // the fixed-point unit is U = 6 round(2^frac / 6) grid steps (nidreg.hip fixed_unit), so that U/6, U/2, 4U/6, U are integers
+      const double unit = 6.0 * std::rint(std::ldexp(1.0, frac) / 6.0), dn = std::ldexp(unit, -1074);
+      const BsplineScale KS = bspline_scale(std::ldexp(unit / 6.0, -1074));
+      if (KS.k46 != std::ldexp(4.0 * unit / 6.0, -1074) || KS.k05 != std::ldexp(unit / 2.0, -1074) || KS.k1 != dn) bad++;  // exact constants
+      const BsplineScale KZ = {0.0, 0.0, 0.0, 0.0};  // an outlier / padding slot: zeroed constants
+      {
+        double z4[4];
+        bspline_scaled(0.37, KZ, z4);
+        for (int a = 0; a < 4; a++)
+          if (to_fixed_dn(z4[a], 0.6) != 0) bad++;  // adds exact zeros, sign bit clear
+      }
       for (int i = 0; i < 200000; i++) {
-        double bx[4], by[4];
-        bspline<double>(i == 0 ? 0.0 : (i == 1 ? std::nextafter(1.0, 0.0) : U(rng)), bx);
+        double bx[4], by[4], bxs4[4];
+        const double sxv = i == 0 ? 0.0 : (i == 1 ? std::nextafter(1.0, 0.0) : U(rng));
+        bspline<double>(sxv, bx);
+        bspline_scaled(sxv, KS, bxs4);  // the polynomial evaluated with constants pre-multiplied by dn (subnormal arithmetic)
         bspline<double>(i == 2 ? 0.0 : U(rng), by);
         double sum = 0;
         for (int a = 0; a < 4; a++) {
-          const double bxs = bx[a] * dn;
+          const double bxs = bxs4[a];
+          if (std::signbit(bxs)) bad++;
           for (int b = 0; b < 4; b++) {
             const u64 bits = to_fixed_dn(bxs, by[b]);
             if (bits >> 63) bad++;
@@ -193,7 +206,9 @@ int main() {
       if (to_fixed_dn(0.0 * dn, 0.7) != 0 || to_fixed_dn(0.3 * dn, 0.0) != 0 || to_fixed_dn(0.5 * 0.0, 0.25) != 0) bad++;  // outliers add exact zeros
     }
     std::printf("to_fixed_dn: max |fixed - exact| %.3f units, max |sum of 16 taps - 1| %.1f units\n", worst, worst_sum);
-    if (worst > 0.8334 || worst_sum > 12.0) bad++;
+    // each pre-scaled x-weight carries <= ~1.6 units of rounding (constants rounded to the grid + two roundings of the
+    // polynomial), times by <= 2/3, plus half a unit for the product
+    if (worst > 1.75 || worst_sum > 14.0) bad++;
   }
   // strip-tiled padded bin image: padded pixel (x, y) at (y >> 2) * 4 * pitch + 4 x + (y & 3); load_patch returns, for
   // knot (kx, ky), byte b of cols[a] = padded pixel (kx + a, ky + b) = source pixel (clamp(kx + a - 1), clamp(ky + b - 1))

@@ -1,0 +1,52 @@
+"""bench.py's multi-GPU launch path.  CPU: `python bench.py --gpus 2` (no launcher, no WORLD_SIZE) re-launches itself as
+two torch.distributed.run ranks, each of which then fails loudly for want of a GPU (the NID core has no CPU path).
+GPU (one device): the same command with the test hooks (both ranks on GPU 0, gloo instead of RCCL) produces ONE JSON
+line with n_gpus = 2, the weak-scaling value, and every multi_gpu case -- configs[3] pairs, configs[2] / [4] sharded
+over the ranks with the all-reduce of the fixed-point histogram, and the single-process route of the C ABI."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env(**extra):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra)
+    return env
+
+
+def test_plain_python_launch_spawns_one_rank_per_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("covered by the GPU test")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--points", "1000"], capture_output=True, text=True, env=_env(), timeout=600)
+    assert r.returncode != 0
+    # both ranks were started by the elastic launcher and each one refused to run without a GPU
+    assert r.stderr.count("bench.py needs an MI355X") >= 2, r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_produce_the_full_line():
+    r = subprocess.run(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--blocks", "3", "--points", "300000", "--extra-points-scale", "0.02", "--no-cpu-baseline"],
+        capture_output=True, text=True, env=_env(NIDREG_BENCH_ONE_GPU="1", NIDREG_BENCH_BACKEND="gloo"), timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["ranks_seen"] == 2
+    mg = d["multi_gpu"]
+    assert mg["ranks_seen"] == 2
+    for key in ("pairs_configs3", "shard_configs2", "shard_configs4"):
+        assert "error" not in mg[key], mg[key]
+        assert mg[key]["value"] > 0 and mg[key]["ranks_seen"] == 2
+    sp = mg["single_process_sharded"]
+    assert "error" not in sp, sp
+    assert sp["configs2"]["devices"] == [0, 0] and sp["configs2"]["value"] > 0 and sp["configs4"]["value"] > 0

@@ -145,10 +145,7 @@ def test_reference_cameras_feed_the_gpu_cost(tmp_path):
 def test_reference_calibrate_drives_the_gpu_engine(tmp_path):
     """The reference's own VisualCameraCalibration::calibrate (Nelder-Mead route) running on the GPU engine through the
     drop-in headers ends where the reference's CPU build ends (fixture).  The binary is built where the reference tree
-    is mounted and travels with the snapshot.  Not yet run on a GPU (the round's GPU budget was spent when it was
-    written): opt in with NIDREG_RUN_UNVALIDATED=1."""
-    if not os.environ.get("NIDREG_RUN_UNVALIDATED"):
-        pytest.skip("not yet validated on a GPU; set NIDREG_RUN_UNVALIDATED=1 to run")
+    is mounted and travels with the snapshot."""
     if not os.path.exists(EXE_CAL):
         pytest.skip("tests/cxx/test_integration_calibrate.bin was not built (needs the reference tree)")
     from direct_visual_lidar_calibration_amd import se3

@@ -21,12 +21,22 @@ for line in open(f"{src}/summary.txt"):
     if cur is None:
         continue
     f = line.split()
-    if f[0] in ("FETCH_SIZE", "WRITE_SIZE"):
+    if f[0] in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"):
         kernels.setdefault(cur, {})[f[0]] = float(f[2])
 out = {}
 for k, v in kernels.items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         out[k] = {"fetch_kib": v["FETCH_SIZE"], "write_kib": v["WRITE_SIZE"], "hbm_bytes_raw": int((v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024),
                   "hbm_bytes_corrected": int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)}
-json.dump({"source": src, "workload": dict(points=points, width=width, height=height, bins=bins, precision=precision), "kernels": out}, open(dst, "w"), indent=1)
+        # wave-instruction counts per launch (the VALU-issue roof bench.py reports next to the HBM one)
+        for name, key in (("SQ_INSTS_VALU", "valu_insts"), ("SQ_INSTS_LDS", "lds_insts"), ("SQ_INSTS_SALU", "salu_insts"), ("SQ_INSTS_VMEM_RD", "vmem_rd_insts"),
+                          ("SQ_ACTIVE_INST_VALU", "valu_active_quad_cycles"), ("GRBM_GUI_ACTIVE", "gui_active_cycles_all_xcd"), ("SQ_LDS_BANK_CONFLICT", "lds_bank_conflict_cycles"),
+                          ("SQ_LDS_IDX_ACTIVE", "lds_idx_active_cycles")):
+            if name in v:
+                out[k][key] = v[name]
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+from direct_visual_lidar_calibration_amd import _lib  # noqa: E402
+
+json.dump({"source": src, "kernel_build": _lib.kernel_source_hash(), "workload": dict(points=points, width=width, height=height, bins=bins, precision=precision), "kernels": out},
+          open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1))
