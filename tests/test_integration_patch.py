@@ -153,7 +153,10 @@ def test_reference_calibrate_drives_the_gpu_engine(tmp_path):
 
     c = CASES[0]
     path = _scene_file(tmp_path)
-    vals = [float(v) for v in subprocess.check_output([EXE_CAL, str(path), str(int(c["nm_bins"]))]).decode().split()]
+    # the reference prints "cost:<value>" on every improvement (visual_camera_calibration.cpp:115); the result is the last line
+    out = subprocess.check_output([EXE_CAL, str(path), str(int(c["nm_bins"]))]).decode().strip().splitlines()
+    vals = [float(v) for v in out[-1].split()]
+    assert len(vals) == 17 and vals[16] >= 1, out[-1]  # 16 matrix entries + the number of callback invocations
     T = np.array(vals[:16]).reshape(4, 4)
     dt, dr = se3.delta_trans_rot(se3.from_matrix(c["ref_nm_T_camera_lidar"]), se3.from_matrix(T))
     assert dt <= 1e-3 and dr <= 1e-3, (dt, dr)
