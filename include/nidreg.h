@@ -187,7 +187,9 @@ int nidreg_project_model(int model_id, const double* intrinsics, const double* d
 /* ViewCulling::cull (src/vlcal/calib/view_culling.cpp:21-92) on the device: FoV gate against
  * min_z = cos(estimate_camera_fov), in-image test, per-pixel depth buffer (float distance) and the
  * +0.1 m keep threshold.  points: host, (x y z 1) doubles with the given byte stride; T: row-major 4x4
- * T_camera_lidar.  Writes the surviving indices (ascending, identical to the reference's) into
+ * T_camera_lidar.  Writes the surviving indices (ascending; identical to the in-repo oracle's and to the reference's
+ * source compiled against the stand-in Eigen of oracle/shim -- a build against real Eigen, whose fixed-size reductions
+ * and 4x4 products may associate differently, can differ by 1 ulp in a borderline FoV / pixel / depth decision) into
  * indices_out (capacity num_points) and returns their number, or a negative error code. */
 int64_t nidreg_view_culling(int model_id, const double* intrinsics, const double* distortion, int device_id, int width, int height, double min_z, int enable_depth_buffer_culling,
                             const double* points, int64_t point_stride, int64_t num_points, const double* T_camera_lidar, int32_t* indices_out);
@@ -214,7 +216,8 @@ void nidreg_colorizer_destroy(nidreg_colorizer* c);
  * with the smallest squared camera-frame distance wins; on exact ties the largest index (the sequential
  * reference overwrites on `!(stored < sq_dist)`, :31).  intensity_image: height x width doubles (0 where
  * nothing landed), index_image: height x width int32 (-1 where nothing landed); either may be NULL.
- * Output is identical to the CPU loop's for any thread order. */
+ * Output is independent of the thread order and identical to the in-repo oracle's sequential loop (same 1-ulp caveat
+ * about real Eigen's association order as nidreg_view_culling). */
 int nidreg_generate_lidar_image(int model_id, const double* intrinsics, const double* distortion, int device_id, int width, int height, double min_nz, const double* points,
                                 int64_t point_stride, const double* intensities, int64_t num_points, const double* T_camera_lidar, double* intensity_image, int32_t* index_image);
 
