@@ -9,15 +9,31 @@
 
 #include "../nidreg.h"
 
+// What a GPU cost function needs from a camera: which model it is (NIDREG_MODEL_*) and its parameters, zero padded to
+// 5 intrinsics / 8 distortion coefficients.  The reference hides both inside GenericCamera<Projection>
+// (generic_camera.hpp:35-37); a camera can expose them in two ways, and nidreg_camera_params() accepts either:
+//   * as this side interface, which the cameras made by integration/src/create_camera.cpp (linked INSTEAD of the
+//     reference's src/camera/create_camera.cpp; no reference header is touched) implement next to GenericCamera<P>;
+//   * as three virtuals on GenericCameraBase itself (integration/reference_camera.patch, which defines
+//     NIDREG_CAMERA_PATCHED; the stand-in GenericCameraBase below has them too).
+namespace camera {
+class NidregCameraInfo {
+public:
+  virtual ~NidregCameraInfo() {}
+  virtual int nidreg_model_id() const = 0;
+  virtual const double* nidreg_intrinsics() const = 0;  // 5 doubles, zero padded
+  virtual const double* nidreg_distortion() const = 0;  // 8 doubles, zero padded
+};
+}  // namespace camera
+
 #ifdef NIDREG_WITH_REFERENCE_DEPS
-// inside a reference checkout: the reference's own camera classes, with the three accessors of
-// integration/reference_camera.patch applied (camera::GenericCameraBase::nidreg_model_id() / _intrinsics() /
-// _distortion()); CPU project() stays the reference's, camera::create_camera stays src/camera/create_camera.cpp
+// inside a reference checkout: the reference's own camera classes; CPU project() stays the reference's
 #include <Eigen/Core>
 #include <ceres/jet.h>
 #include <camera/create_camera.hpp>
 #include <camera/generic_camera_base.hpp>
 #else
+#define NIDREG_CAMERA_PATCHED 1
 #include "standins.hpp"
 
 namespace camera {
@@ -79,3 +95,25 @@ inline GenericCameraBase::ConstPtr create_camera(const std::string& camera_model
 
 }  // namespace camera
 #endif  // NIDREG_WITH_REFERENCE_DEPS
+
+#include <stdexcept>
+
+namespace camera {
+struct NidregCameraParams {
+  int model_id;
+  const double* intrinsics;  // 5
+  const double* distortion;  // 8
+};
+inline NidregCameraParams nidreg_camera_params(const GenericCameraBase& cam) {
+#ifdef NIDREG_CAMERA_PATCHED
+  return NidregCameraParams{cam.nidreg_model_id(), cam.nidreg_intrinsics(), cam.nidreg_distortion()};
+#else
+  const NidregCameraInfo* info = dynamic_cast<const NidregCameraInfo*>(&cam);
+  if (!info)
+    throw std::runtime_error(
+      "nidreg: this camera does not expose its model and parameters -- link integration/src/create_camera.cpp instead of the reference's "
+      "src/camera/create_camera.cpp, or apply integration/reference_camera.patch");
+  return NidregCameraParams{info->nidreg_model_id(), info->nidreg_intrinsics(), info->nidreg_distortion()};
+#endif
+}
+}  // namespace camera

@@ -49,12 +49,13 @@ public:
     nidreg_desc d{};
     d.struct_size = sizeof(nidreg_desc);
     d.device_id = device_id;
-    d.model_id = proj->nidreg_model_id();
+    const camera::NidregCameraParams cp = camera::nidreg_camera_params(*proj);
+    d.model_id = cp.model_id;
     d.mode = NIDREG_MODE_NEAREST;
     d.precision = precision;
     d.bins = params.bins;
-    for (int i = 0; i < 5; i++) d.intrinsics[i] = proj->nidreg_intrinsics()[i];
-    for (int i = 0; i < 8; i++) d.distortion[i] = proj->nidreg_distortion()[i];
+    for (int i = 0; i < 5; i++) d.intrinsics[i] = cp.intrinsics[i];
+    for (int i = 0; i < 8; i++) d.distortion[i] = cp.distortion[i];
     d.width = data->image.cols;
     d.height = data->image.rows;
     d.image_dtype = NIDREG_IMAGE_U8;

@@ -22,7 +22,8 @@ inline void generate_lidar_image(const camera::GenericCameraBase::ConstPtr& proj
   double T[16];
   for (int r = 0; r < 4; r++)
     for (int c = 0; c < 4; c++) T[r * 4 + c] = r < 3 ? T_camera_lidar(r, c) : (c == 3 ? 1.0 : 0.0);
-  const int rc = nidreg_generate_lidar_image(proj->nidreg_model_id(), proj->nidreg_intrinsics(), proj->nidreg_distortion(), device_id, width, height, min_z,
+  const camera::NidregCameraParams cp = camera::nidreg_camera_params(*proj);
+  const int rc = nidreg_generate_lidar_image(cp.model_id, cp.intrinsics, cp.distortion, device_id, width, height, min_z,
                                              reinterpret_cast<const double*>(points->points), sizeof(points->points[0]), points->intensities, static_cast<int64_t>(points->size()), T,
                                              intensity_image, index_image);
   if (rc != NIDREG_OK) throw std::runtime_error(std::string("vlcal::generate_lidar_image: ") + nidreg_last_error());

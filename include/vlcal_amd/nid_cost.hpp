@@ -56,12 +56,13 @@ public:
     for (int i = 0; i < d.num_devices; i++) d.device_ids[i] = device_ids[static_cast<size_t>(i)];
     d.struct_size = sizeof(nidreg_desc);
     d.device_id = device_id;
-    d.model_id = proj->nidreg_model_id();
+    const camera::NidregCameraParams cp = camera::nidreg_camera_params(*proj);
+    d.model_id = cp.model_id;
     d.mode = NIDREG_MODE_SPLINE;
     d.precision = precision;
     d.bins = bins;
-    for (int i = 0; i < 5; i++) d.intrinsics[i] = proj->nidreg_intrinsics()[i];
-    for (int i = 0; i < 8; i++) d.distortion[i] = proj->nidreg_distortion()[i];
+    for (int i = 0; i < 5; i++) d.intrinsics[i] = cp.intrinsics[i];
+    for (int i = 0; i < 8; i++) d.distortion[i] = cp.distortion[i];
     d.width = normalized_image.cols;
     d.height = normalized_image.rows;
     d.image_dtype = NIDREG_IMAGE_F64;  // CV_64FC1, made by convertTo(..., 1/255) (visual_camera_calibration.cpp:204)
@@ -82,12 +83,13 @@ public:
     nidreg_desc d{};
     d.struct_size = sizeof(nidreg_desc);
     d.device_id = device_id;
-    d.model_id = proj->nidreg_model_id();
+    const camera::NidregCameraParams cp = camera::nidreg_camera_params(*proj);
+    d.model_id = cp.model_id;
     d.mode = NIDREG_MODE_SPLINE;
     d.precision = precision;
     d.bins = bins;
-    for (int i = 0; i < 5; i++) d.intrinsics[i] = proj->nidreg_intrinsics()[i];
-    for (int i = 0; i < 8; i++) d.distortion[i] = proj->nidreg_distortion()[i];
+    for (int i = 0; i < 5; i++) d.intrinsics[i] = cp.intrinsics[i];
+    for (int i = 0; i < 8; i++) d.distortion[i] = cp.distortion[i];
     d.width = normalized_image.cols;
     d.height = normalized_image.rows;
     d.image_dtype = NIDREG_IMAGE_F64;

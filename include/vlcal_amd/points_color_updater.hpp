@@ -29,7 +29,8 @@ public:
                      const double min_nz, const int device_id = 0)
   : proj(proj), min_nz(min_nz), image(image), points(points) {
     nidreg_colorizer* c = nullptr;
-    const int rc = nidreg_colorizer_create(device_id, proj->nidreg_model_id(), proj->nidreg_intrinsics(), proj->nidreg_distortion(), image.cols, image.rows, image.data,
+    const camera::NidregCameraParams cp = camera::nidreg_camera_params(*proj);
+    const int rc = nidreg_colorizer_create(device_id, cp.model_id, cp.intrinsics, cp.distortion, image.cols, image.rows, image.data,
                                            static_cast<int64_t>(image.step), static_cast<int64_t>(points->size()), reinterpret_cast<const double*>(points->points),
                                            sizeof(points->points[0]), intensity_colors, min_nz, &c);
     if (rc != NIDREG_OK) throw std::runtime_error(std::string("vlcal::PointsColorUpdater: ") + nidreg_last_error());

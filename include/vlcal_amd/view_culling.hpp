@@ -49,7 +49,8 @@ public:
     for (int r = 0; r < 4; r++)
       for (int c = 0; c < 4; c++) T[r * 4 + c] = r < 3 ? T_camera_lidar(r, c) : (c == 3 ? 1.0 : 0.0);
     std::vector<int32_t> idx(points->size());
-    const int64_t n = nidreg_view_culling(proj->nidreg_model_id(), proj->nidreg_intrinsics(), proj->nidreg_distortion(), device_id, width, height, min_z,
+    const camera::NidregCameraParams cp = camera::nidreg_camera_params(*proj);
+    const int64_t n = nidreg_view_culling(cp.model_id, cp.intrinsics, cp.distortion, device_id, width, height, min_z,
                                           params.enable_depth_buffer_culling ? 1 : 0, reinterpret_cast<const double*>(points->points), sizeof(points->points[0]),
                                           static_cast<int64_t>(points->size()), T, idx.data());
     if (n < 0) throw std::runtime_error(std::string("vlcal::ViewCulling: ") + nidreg_last_error());

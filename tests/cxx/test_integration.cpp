@@ -27,9 +27,10 @@ static int describe() {
   for (const auto& c : cases) {
     auto proj = camera::create_camera(c.name, c.intr, c.dist);  // the reference's factory
     if (!proj) return 1;
-    std::printf("%s %d", c.name, proj->nidreg_model_id());
-    for (int i = 0; i < 5; i++) std::printf(" %.17g", proj->nidreg_intrinsics()[i]);
-    for (int i = 0; i < 8; i++) std::printf(" %.17g", proj->nidreg_distortion()[i]);
+    const camera::NidregCameraParams cp = camera::nidreg_camera_params(*proj);
+    std::printf("%s %d", c.name, cp.model_id);
+    for (int i = 0; i < 5; i++) std::printf(" %.17g", cp.intrinsics[i]);
+    for (int i = 0; i < 8; i++) std::printf(" %.17g", cp.distortion[i]);
     const Eigen::Vector2d uv = proj->project(Eigen::Vector3d(0.3, -0.2, 2.0));  // the reference's CPU projection still works
     std::printf(" %.17g %.17g\n", uv[0], uv[1]);
   }

@@ -52,6 +52,36 @@ def build_calibrate(scratch):
     return EXE_CAL
 
 
+EXE_CAL_NP = os.path.join(ROOT, "tests", "cxx", "test_integration_calibrate_nopatch.bin")
+
+
+def build_calibrate_nopatch():
+    """The second integration route: NO reference header is patched; integration/src/create_camera.cpp is compiled instead
+    of the reference's src/camera/create_camera.cpp (its cameras are the reference's GenericCamera<P> objects that also
+    implement camera::NidregCameraInfo), everything else as in build_calibrate."""
+    if not os.path.exists(os.path.join(CSRC, "libnidreg.so")):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    cmd = ["g++", "-std=c++17", "-O1", "-DNIDREG_WITH_REFERENCE_DEPS", "-Wno-sign-compare", "-Wl,--allow-multiple-definition",
+           "-I", os.path.join(ROOT, "integration", "include"), "-I", os.path.join(ROOT, "oracle", "shim"),
+           "-I", os.path.join(REF, "include"), "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "cxx", "test_integration_calibrate.cpp"), os.path.join(REF, "src", "vlcal", "calib", "visual_camera_calibration.cpp"),
+           os.path.join(ROOT, "integration", "src", "create_camera.cpp"), os.path.join(REF, "src", "vlcal", "common", "estimate_fov.cpp"),
+           "-L", CSRC, "-lnidreg", f"-Wl,-rpath,{CSRC}", "-o", EXE_CAL_NP]
+    subprocess.check_call(cmd)
+    return EXE_CAL_NP
+
+
+def test_unpatched_reference_headers_with_the_replacement_camera_factory():
+    """visual_camera_calibration.cpp, estimate_fov.cpp and EVERY reference header unmodified; only create_camera.cpp is
+    swapped for integration/src/create_camera.cpp: compiles, links, starts."""
+    if not os.path.isdir(os.path.join(REF, "include", "camera")):
+        pytest.skip("reference tree not present")
+    exe = build_calibrate_nopatch()
+    assert subprocess.run([exe]).returncode == 2
+
+
 def test_reference_calibration_driver_compiles_against_the_dropin_headers(tmp_path):
     """visual_camera_calibration.cpp, unmodified, with <vlcal/costs/nid_cost.hpp>, <vlcal/calib/cost_calculator_nid.hpp>
     and <vlcal/calib/view_culling.hpp> forwarded to include/vlcal_amd/: the reference's constructor calls and functor
@@ -139,6 +169,23 @@ def test_reference_cameras_feed_the_gpu_cost(tmp_path):
         ref = oracle_lib.nid_cost(s.model, s.intrinsics, s.distortion, s.image_f64, s.points, s.intensities, bins, x)
         assert abs(vals[0] - ref["cost"]) <= 1e-10 and abs(vals[8] - ref["cost"]) <= 1e-10
         assert np.allclose(vals[1:8], ref["grad"], rtol=1e-7, atol=1e-10)
+
+
+@pytest.mark.gpu
+def test_reference_calibrate_drives_the_gpu_engine_without_any_header_patch(tmp_path):
+    """Same as below through the patch-free route (replacement create_camera.cpp, all reference headers untouched)."""
+    if not os.path.exists(EXE_CAL_NP):
+        pytest.skip("tests/cxx/test_integration_calibrate_nopatch.bin was not built (needs the reference tree)")
+    from direct_visual_lidar_calibration_amd import se3
+    from test_reference_golden import CASES
+
+    c = CASES[0]
+    path = _scene_file(tmp_path)
+    out = subprocess.check_output([EXE_CAL_NP, str(path), str(int(c["nm_bins"]))]).decode().strip().splitlines()
+    vals = [float(v) for v in out[-1].split()]
+    T = np.array(vals[:16]).reshape(4, 4)
+    dt, dr = se3.delta_trans_rot(se3.from_matrix(c["ref_nm_T_camera_lidar"]), se3.from_matrix(T))
+    assert dt <= 1e-3 and dr <= 1e-3, (dt, dr)
 
 
 @pytest.mark.gpu
