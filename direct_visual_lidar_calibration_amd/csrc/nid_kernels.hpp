@@ -457,49 +457,67 @@ __device__ __forceinline__ void entropy_final_body(
   }
 }
 
+// 16 columns per workgroup, 1024 threads: thread (r = tid & 255, q = tid >> 8) takes row r of columns 4q .. 4q+3, so a
+// thread does 4 loads and 4 logs instead of 16 (with one 256-thread workgroup per CU the 16 dependent log chains of a
+// wave ran at single-wave latency: 13.8 -> see DESIGN.md section 6) and four waves per SIMD overlap them; the four
+// quarter-row partials meet in LDS.
 constexpr int kEntropyColsMax = 16;
-__global__ __launch_bounds__(kThreads) void k_entropy(
+constexpr int kEntropyThreads = 1024;
+constexpr int kEntropyWaves = kEntropyThreads / 64;
+__global__ __launch_bounds__(kEntropyThreads) void k_entropy(
   const u64* __restrict__ hist, int B, int CB, double inv_unit, double* part_hj, u64* row_part, double* phi_q, double* hist_image_out, double* hist_points_out,
   EntropyScalars* scal, double* out, double* out_host, double tag, unsigned int* counter, u64* __restrict__ zero_buf, long long zero_words) {
-  __shared__ double s_red[3 * kWaves];
+  __shared__ double s_red[3 * kEntropyWaves];
+  __shared__ u64 s_row[3][256];
   __shared__ int s_flag;
   const int tid = threadIdx.x;
   const int j = blockIdx.x;
   // double-buffered histogram: clear the buffer the NEXT evaluation accumulates into (nidreg.hip,
   // begin_histogram) -- ~0.5 MB of stores that replace a memset launch per evaluation
   if (zero_buf)
-    for (long long k = (long long)j * kThreads + tid; k < zero_words; k += (long long)gridDim.x * kThreads) zero_buf[k] = 0;
+    for (long long k = (long long)j * kEntropyThreads + tid; k < zero_words; k += (long long)gridDim.x * kEntropyThreads) zero_buf[k] = 0;
+  const int r = tid & 255, q = tid >> 8;
   const int c0 = j * CB;
   const int ncols = min(CB, B - c0);
-  u64 v[kEntropyColsMax];
+  constexpr int kPer = kEntropyColsMax / (kEntropyThreads / 256);  // columns per thread
+  u64 v[kPer];
 #pragma unroll
-  for (int c = 0; c < kEntropyColsMax; c++) v[c] = (tid < B && c < ncols) ? hist[size_t(c0 + c) * size_t(B) + tid] : 0;  // independent loads
+  for (int c = 0; c < kPer; c++) {
+    const int col = q * kPer + c;
+    v[c] = (r < B && col < ncols) ? hist[size_t(c0 + col) * size_t(B) + r] : 0;  // independent loads
+  }
   const double S = double(hist[size_t(B) * size_t(B) + kTailInliers]);
   const double scale = inv_unit / S;  // fixed-point word -> probability
   double acc = 0.0;
   u64 row = 0;
 #pragma unroll
-  for (int c = 0; c < kEntropyColsMax; c++) {
+  for (int c = 0; c < kPer; c++) {
     if (v[c]) {
       const double p = double(v[c]) * scale;
       acc += p * log(p + 1e-6);
     }
     row += v[c];
   }
-  if (tid < B) row_part[size_t(j) * size_t(B) + tid] = row;
+  if (q > 0) s_row[q - 1][r] = row;
   acc = wave_sum(acc);
   if ((tid & 63) == 0) s_red[tid >> 6] = acc;
   __syncthreads();
+  if (q == 0 && r < B) row_part[size_t(j) * size_t(B) + r] = row + s_row[0][r] + s_row[1][r] + s_row[2][r];
   if (tid == 0) {
     double t = 0.0;
-    for (int w = 0; w < kWaves; w++) t += s_red[w];
+    for (int w = 0; w < kEntropyWaves; w++) t += s_red[w];
     part_hj[j] = t;
   }
   const u64* col_sum = hist + size_t(B) * size_t(B) + kTailWords;  // accumulated by the histogram kernels' flush
+  // the tail's loops stride by kThreads = 256 over B <= 256 items: threads beyond 255 find nothing to do but take part
+  // in its barriers and (with zeros) in its wave reductions -- s_red holds 3 slots for each of the 16 waves
   if (last_workgroup_arrives<false>(counter, gridDim.x, &s_flag))
     entropy_final_body(hist, B, int(gridDim.x), inv_unit, part_hj, row_part, col_sum, phi_q, hist_image_out, hist_points_out, scal, out, out_host, tag, s_red);
 }
 
+#endif  // NID_COMMON_KERNELS
+
+#ifdef NID_COMMON_KERNELS
 // ------------------------------------------------------------------------------------------
 // One pair whose points are sharded over several GPUs: NID is nonlinear in the histogram,
 // so the per-shard fixed-point partial histograms are summed (exactly: they are integers) before the

@@ -302,7 +302,7 @@ int launch_hist_nearest(nidreg_handle* h, const double* T) {
 int launch_entropy(nidreg_handle* h, double tag) {
   const double inv_unit = 1.0 / fixed_unit(h);
   hipLaunchKernelGGL(
-    k_entropy, dim3(h->NEB), dim3(kThreads), 0, h->stream, hist_source(h), h->bins, kEntropyCols, inv_unit, h->d_part_hj, h->d_row_part, h->d_phi_q, h->d_hist_image,
+    k_entropy, dim3(h->NEB), dim3(kEntropyThreads), 0, h->stream, hist_source(h), h->bins, kEntropyCols, inv_unit, h->d_part_hj, h->d_row_part, h->d_phi_q, h->d_hist_image,
     h->d_hist_points, h->d_scal, h->d_out, h->d_out_host, tag, h->d_counters, h->own_hist ? h->d_hist_buf[h->hist_cur ^ 1] : nullptr, h->hist_words);
   HIP_TRY(hipGetLastError());
   if (h->own_hist) h->hist_zeroed[h->hist_cur ^ 1] = true;  // zeroed by this k_entropy for the next evaluation
