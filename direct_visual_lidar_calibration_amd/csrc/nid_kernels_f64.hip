@@ -1,5 +1,6 @@
-// double-precision SPLINE (NIDCost) kernels + projection utility.  Contraction allowed: parity here is a
-// tolerance (NID 1e-10), and fused multiply-adds cut the fp64 VALU work that bounds both passes.
+// double-precision SPLINE (NIDCost) kernels + projection utility.  Built with -ffp-contract=off like every other
+// translation unit (csrc/Makefile): the fusions wanted are explicit fma calls, so a point gets the same arithmetic
+// whichever unrolled slot / chunk / GPU processes it.
 #include "nid_launch_impl.hpp"
 
 namespace nidreg {
@@ -12,6 +13,8 @@ template <> hipError_t launch_spline_grad<double>(const PassArgs& a) {
   if (a.nchunks == 0) return hipSuccess;
   return a.rec64 ? launch_spline_grad_rec<double, Rec64>(a) : launch_spline_grad_rec<double, Rec32>(a);
 }
+template <> int occupancy_spline_hist<double>(const PassArgs& a) { return a.rec64 ? occupancy_spline_hist_rec<double, Rec64>(a) : occupancy_spline_hist_rec<double, Rec32>(a); }
+template <> int occupancy_spline_grad<double>(const PassArgs& a) { return a.rec64 ? occupancy_spline_grad_rec<double, Rec64>(a) : occupancy_spline_grad_rec<double, Rec32>(a); }
 template <> hipError_t launch_project<double>(int model, const double* intr, const double* dist, const double* p3, long long n, double* uv, double* jac, hipStream_t stream) {
   if (n == 0) return hipSuccess;
   struct { int model; } a{model};

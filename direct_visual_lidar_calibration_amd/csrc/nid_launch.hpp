@@ -46,6 +46,10 @@ struct PassArgs {
 template <typename real> hipError_t launch_spline_hist(const PassArgs& a);
 template <typename real> hipError_t launch_spline_grad(const PassArgs& a);
 template <typename real> hipError_t launch_nearest_hist(const PassArgs& a);
+// workgroups of the selected kernel instantiation (model, record type, tiling) that fit on one CU at once
+// (hipOccupancyMaxActiveBlocksPerMultiprocessor; 0 on error): a pass gets exactly one round of co-resident workgroups
+template <typename real> int occupancy_spline_hist(const PassArgs& a);
+template <typename real> int occupancy_spline_grad(const PassArgs& a);
 template <typename real> hipError_t launch_project(int model, const double* intr, const double* dist, const double* p3, long long n, double* uv, double* jac, hipStream_t stream);
 
 // ViewCulling::cull (nid_cull_kernels.hpp); all pointers are device memory

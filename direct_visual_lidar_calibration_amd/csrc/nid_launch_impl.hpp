@@ -111,6 +111,82 @@ static hipError_t launch_spline_grad_rec(const PassArgs& a) {
 }
 
 template <typename real, typename Rec>
+static int occupancy_spline_hist_rec(const PassArgs& a) {
+  int n = 0;
+#define NID_OCC_W(M, WIDE, THREADS)                                                                                                   \
+  {                                                                                                                                   \
+    auto k = k_spline_hist<M, Rec, real, WIDE>;                                                                                       \
+    if (ensure_lds(k, a.lds_hist) != hipSuccess) return 0;                                                                            \
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(k), THREADS, a.lds_hist) != hipSuccess) n = 0; \
+  }
+  if (a.wide) {
+#define NID_LAUNCH(M) NID_OCC_W(M, true, kWideThreads)
+    switch (a.model) {
+      case MODEL_PLUMB_BOB: NID_LAUNCH(MODEL_PLUMB_BOB); break;
+      case MODEL_FISHEYE: NID_LAUNCH(MODEL_FISHEYE); break;
+      case MODEL_OMNIDIR: NID_LAUNCH(MODEL_OMNIDIR); break;
+      case MODEL_EQUIRECT: NID_LAUNCH(MODEL_EQUIRECT); break;
+      case MODEL_ATAN: NID_LAUNCH(MODEL_ATAN); break;
+      case MODEL_RATIONAL: NID_LAUNCH(MODEL_RATIONAL); break;
+      default: return 0;
+    }
+#undef NID_LAUNCH
+  } else {
+#define NID_LAUNCH(M) NID_OCC_W(M, false, kThreads)
+    switch (a.model) {
+      case MODEL_PLUMB_BOB: NID_LAUNCH(MODEL_PLUMB_BOB); break;
+      case MODEL_FISHEYE: NID_LAUNCH(MODEL_FISHEYE); break;
+      case MODEL_OMNIDIR: NID_LAUNCH(MODEL_OMNIDIR); break;
+      case MODEL_EQUIRECT: NID_LAUNCH(MODEL_EQUIRECT); break;
+      case MODEL_ATAN: NID_LAUNCH(MODEL_ATAN); break;
+      case MODEL_RATIONAL: NID_LAUNCH(MODEL_RATIONAL); break;
+      default: return 0;
+    }
+#undef NID_LAUNCH
+  }
+#undef NID_OCC_W
+  return n;
+}
+
+template <typename real, typename Rec>
+static int occupancy_spline_grad_rec(const PassArgs& a) {
+  int n = 0;
+#define NID_OCC_G(M, GW1)                                                                                                             \
+  {                                                                                                                                   \
+    auto k = k_spline_grad<M, Rec, real, GW1>;                                                                                        \
+    if (ensure_lds(k, a.lds_grad) != hipSuccess) return 0;                                                                            \
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(k), kThreads, a.lds_grad) != hipSuccess) n = 0; \
+  }
+  if (a.GW == 1) {
+#define NID_LAUNCH(M) NID_OCC_G(M, true)
+    switch (a.model) {
+      case MODEL_PLUMB_BOB: NID_LAUNCH(MODEL_PLUMB_BOB); break;
+      case MODEL_FISHEYE: NID_LAUNCH(MODEL_FISHEYE); break;
+      case MODEL_OMNIDIR: NID_LAUNCH(MODEL_OMNIDIR); break;
+      case MODEL_EQUIRECT: NID_LAUNCH(MODEL_EQUIRECT); break;
+      case MODEL_ATAN: NID_LAUNCH(MODEL_ATAN); break;
+      case MODEL_RATIONAL: NID_LAUNCH(MODEL_RATIONAL); break;
+      default: return 0;
+    }
+#undef NID_LAUNCH
+  } else {
+#define NID_LAUNCH(M) NID_OCC_G(M, false)
+    switch (a.model) {
+      case MODEL_PLUMB_BOB: NID_LAUNCH(MODEL_PLUMB_BOB); break;
+      case MODEL_FISHEYE: NID_LAUNCH(MODEL_FISHEYE); break;
+      case MODEL_OMNIDIR: NID_LAUNCH(MODEL_OMNIDIR); break;
+      case MODEL_EQUIRECT: NID_LAUNCH(MODEL_EQUIRECT); break;
+      case MODEL_ATAN: NID_LAUNCH(MODEL_ATAN); break;
+      case MODEL_RATIONAL: NID_LAUNCH(MODEL_RATIONAL); break;
+      default: return 0;
+    }
+#undef NID_LAUNCH
+  }
+#undef NID_OCC_G
+  return n;
+}
+
+template <typename real, typename Rec>
 static hipError_t launch_nearest_hist_rec(const PassArgs& a) {
   const IsoParams<real> iso = make_iso<real>(a);
   const CamParams<real> cam = make_cam<real>(a.intr, a.dist);

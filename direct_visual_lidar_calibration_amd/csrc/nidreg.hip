@@ -359,28 +359,39 @@ int eval_finish(nidreg_handle* h, double* cost, double* grad7) {
     // the finalising workgroup wrote the results and then this evaluation's tag into host-mapped memory:
     // poll the tag (a few us cheaper than hipStreamSynchronize); look at the stream now and then so that a
     // faulted kernel cannot hang the caller, and so the runtime can retire finished commands
-    // (acquire load of the tag, then plain loads of the payload; the spin backs off so that N in-flight
-    // handles -- one OpenMP thread per pair in the reference -- do not burn N cores at full speed)
+    // acquire load of the tag, then plain loads of the payload.  Back-off by elapsed TIME, not by spin count (a count
+    // means a different wait on every host CPU: with naps starting too early, their ~60 us granularity added 40-50 us
+    // to every 100-200 us evaluation): `pause` spinning for the first 2 ms -- every evaluation up to ~100M points --,
+    // then 50 us naps, so that N in-flight handles (one OpenMP thread per pair in the reference) do not burn N cores
+    // through a long wait; the stream is looked at once per millisecond so that a faulted kernel cannot hang the caller.
     const double* flag = h->h_out + 15;
-    unsigned long long spins = 0;
-    while (__atomic_load_n(reinterpret_cast<const uint64_t*>(flag), __ATOMIC_ACQUIRE) != h->seq_bits) {
-      ++spins;
-      if (spins < 64) {
-        __builtin_ia32_pause();
-      } else if (spins < 512) {  // ~0.3 ms of paused spinning covers a 10M-point evaluation
-        for (int k = 0; k < 16; k++) __builtin_ia32_pause();
-      } else {
-        struct timespec ts = {0, 20000};  // 20 us naps once the wait is long (>~100 us): the kernels are still running
-        nanosleep(&ts, nullptr);
-      }
-      if ((spins & 0xffull) == 0) {
-        const hipError_t q = hipStreamQuery(h->stream);
-        if (q == hipSuccess) {
-          if (__atomic_load_n(reinterpret_cast<const uint64_t*>(flag), __ATOMIC_ACQUIRE) != h->seq_bits) HIP_TRY(hipStreamSynchronize(h->stream));
-          if (__atomic_load_n(reinterpret_cast<const uint64_t*>(flag), __ATOMIC_ACQUIRE) != h->seq_bits) return fail(NIDREG_ERR_HIP, "nidreg_eval: stream drained but the completion tag is missing");
-          break;
+    auto tag_seen = [&]() { return __atomic_load_n(reinterpret_cast<const uint64_t*>(flag), __ATOMIC_ACQUIRE) == h->seq_bits; };
+    if (!tag_seen()) {
+      struct timespec t0;
+      clock_gettime(CLOCK_MONOTONIC, &t0);
+      double next_query_us = 1000.0;
+      unsigned spins = 0;
+      for (;;) {
+        for (int k = 0; k < 32 && !tag_seen(); k++) __builtin_ia32_pause();
+        if (tag_seen()) break;
+        if ((++spins & 7u) != 0) continue;  // look at the clock every ~256 pauses
+        struct timespec t1;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        const double us = (t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3;
+        if (us >= next_query_us) {
+          next_query_us = us + 1000.0;
+          const hipError_t q = hipStreamQuery(h->stream);
+          if (q == hipSuccess) {
+            if (!tag_seen()) HIP_TRY(hipStreamSynchronize(h->stream));
+            if (!tag_seen()) return fail(NIDREG_ERR_HIP, "nidreg_eval: stream drained but the completion tag is missing");
+            break;
+          }
+          if (q != hipErrorNotReady) return fail(NIDREG_ERR_HIP, std::string("nidreg_eval: ") + hipGetErrorString(q));
         }
-        if (q != hipErrorNotReady) return fail(NIDREG_ERR_HIP, std::string("nidreg_eval: ") + hipGetErrorString(q));
+        if (us > 2000.0) {
+          struct timespec ts = {0, 50000};
+          nanosleep(&ts, nullptr);
+        }
       }
     }
     if (++h->evals_since_reap >= 256) {
@@ -669,14 +680,25 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
         }
       }
     };
+    // workgroups per CU that are really co-resident for THIS kernel instantiation: 4 for the pinhole family, 3 for the
+    // fisheye / equirectangular gradient kernels (154-161 VGPRs) -- 1024 chunks there meant 1.33 rounds
+    int per_cu_grad = 4, per_cu_hist = h->wide ? 2 : 4;
+    if (d->mode == NIDREG_MODE_SPLINE) {
+      PassArgs oa;
+      fill_pass_args(h, oa);
+      const int og = h->precision == NIDREG_PREC_FP32 ? occupancy_spline_grad<float>(oa) : occupancy_spline_grad<double>(oa);
+      const int oh = h->precision == NIDREG_PREC_FP32 ? occupancy_spline_hist<float>(oa) : occupancy_spline_hist<double>(oa);
+      if (og > 0) per_cu_grad = std::min(og, 8);
+      if (oh > 0) per_cu_hist = std::min(oh, 8);
+    }
     std::vector<Chunk> chunks;
-    build_chunks(d->target_blocks > 0 ? d->target_blocks : 4 * num_cus, kThreads, chunks);
+    build_chunks(d->target_blocks > 0 ? d->target_blocks : (h->wide ? per_cu_grad : std::min(per_cu_grad, per_cu_hist)) * num_cus, kThreads, chunks);
     h->nchunks = int(chunks.size());
     CREATE_TRY(hipMalloc(&h->d_chunks, std::max<size_t>(chunks.size(), 1) * sizeof(Chunk)));
     if (!chunks.empty()) CREATE_TRY(hipMemcpy(h->d_chunks, chunks.data(), chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice));
     if (h->wide) {
       std::vector<Chunk> wide_chunks;
-      build_chunks(d->target_blocks > 0 ? d->target_blocks : 2 * num_cus, kWideThreads, wide_chunks);
+      build_chunks(d->target_blocks > 0 ? d->target_blocks : per_cu_hist * num_cus, kWideThreads, wide_chunks);
       h->nchunks_hist = int(wide_chunks.size());
       CREATE_TRY(hipMalloc(&h->d_chunks_hist, std::max<size_t>(wide_chunks.size(), 1) * sizeof(Chunk)));
       if (!wide_chunks.empty()) CREATE_TRY(hipMemcpy(h->d_chunks_hist, wide_chunks.data(), wide_chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice));
@@ -874,13 +896,21 @@ int set_eval(ShardSet* set, int mode, const double* pose, double* cost, double* 
     set->cv.notify_all();
   }
   set->rc[0] = run_shard(set, 0);
-  unsigned spins = 0;
-  while (set->pending.load(std::memory_order_acquire) > 0) {
-    if (++spins < 4096) {
+  {
+    // the other shards finish within microseconds of this one: pause-spin (2 ms by the clock), then nap
+    struct timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    unsigned spins = 0;
+    while (set->pending.load(std::memory_order_acquire) > 0) {
       __builtin_ia32_pause();
-    } else {
-      struct timespec ts = {0, 20000};
-      nanosleep(&ts, nullptr);
+      if ((++spins & 0xffu) == 0) {
+        struct timespec t1;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if ((t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3 > 2000.0) {
+          struct timespec ts = {0, 50000};
+          nanosleep(&ts, nullptr);
+        }
+      }
     }
   }
   bool all_ok = true;
