@@ -623,8 +623,11 @@ __global__ void k_shard_pattern(u64* part, int words, u64 shard, u64 round) {
 // broadcast, unlike atomics -- no lane-private copies either: the tap's LDS byte address is just
 // bin_image << 3, ONE v_lshlrev_b32_sdwa instead of extract + shift + add (gtile sits at LDS
 // address 0: no static LDS in this kernel).  Measured on cfg 2: 103.4 -> 99.5 us.
+#ifndef NID_GRAD_MIN_WAVES
+#define NID_GRAD_MIN_WAVES 1
+#endif
 template <int MODEL, typename Rec, typename real, bool GW1>
-__global__ __launch_bounds__(kThreads) void k_spline_grad(
+__global__ __launch_bounds__(kThreads, NID_GRAD_MIN_WAVES) void k_spline_grad(
   const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint8_t* __restrict__ img, int pitch, int W, int H, PoseParams<real> pose, CamParams<real> cam, int B,
   int GW, int cshift, double inv_unit, const u64* __restrict__ hist, const double* __restrict__ phi_q, const EntropyScalars* __restrict__ scal, double* partials, double qx,
   double qy, double qz, double qw, double* out, double* out_host, double tag, unsigned int* counter) {
