@@ -1,4 +1,8 @@
-"""Host-side calibration driver with the structure of the reference's ``VisualCameraCalibration``
+"""RESTATEMENT OF AN OUT-OF-SCOPE CALLER (src/vlcal/calib/visual_camera_calibration.cpp), kept so that GPU runs can be driven probe for probe like the
+reference's host code in tests and in the Python `calibrate` command; it is not a component of the hot path and claims
+no coverage of SURVEY section 8.
+
+Host-side calibration driver with the structure of the reference's ``VisualCameraCalibration``
 (src/vlcal/calib/visual_camera_calibration.cpp:35-68 outer loop, :70-139 Nelder-Mead inner solve,
 :190-238 BFGS inner solve).  This is the *caller* of the hot path; the reference keeps it on the
 host (Ceres / dfo) and so do we.  Ceres itself is not available offline, so the BFGS + Wolfe line

@@ -1,4 +1,8 @@
-"""Host-side derivative-free optimiser with the semantics of the reference's ``dfo::NelderMead<N>``
+"""RESTATEMENT OF AN OUT-OF-SCOPE CALLER (include/dfo/nelder_mead.hpp), kept so that GPU runs can be driven probe for probe like the
+reference's host code in tests and in the Python `calibrate` command; it is not a component of the hot path and claims
+no coverage of SURVEY section 8.
+
+Host-side derivative-free optimiser with the semantics of the reference's ``dfo::NelderMead<N>``
 (include/dfo/nelder_mead.hpp:11-113): simplex from ``x0 + init_step * e_i``, sort, variance-based
 convergence test on the coordinates only, centroid is *evaluated* every iteration, reflection /
 expansion / outside contraction / shrink with (alpha, gamma, rho) = (1, 2, 0.5).
