@@ -1009,6 +1009,11 @@ int create_sharded(const nidreg_desc* d, nidreg_handle** out) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(NIDREG_ERR_NO_DEVICE, "nidreg_create: no HIP device (the NID core has no CPU path)");
   for (int id : ids)
     if (id < 0 || id >= ndev) return fail(NIDREG_ERR_INVALID, "nidreg_create: device id " + std::to_string(id) + " out of range (NIDREG_DEVICES / desc.device_ids)");
+  // The same device may be listed more than once (a 1-GPU box exercising the protocol), but the exchange kernels of
+  // co-located shards wait for each other while holding a hardware queue each: beyond three per device two of them
+  // share a queue (ROCm maps streams onto 4) and the wait could only end by its timeout.
+  for (int id : ids)
+    if (std::count(ids.begin(), ids.end(), id) > 3) return fail(NIDREG_ERR_INVALID, "nidreg_create: at most 3 shards of one pair may share a device (device " + std::to_string(id) + " is listed more often)");
   // peer mappings, both directions, before any buffer is allocated
   for (int i = 0; i < n; i++) {
     for (int j = 0; j < n; j++) {

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Protocol cost of the in-library sharded evaluation on ONE GPU (the same device listed n times): with a cloud so small
+"""Protocol cost of the in-library sharded evaluation on ONE GPU (the same device listed n times; at most 3: co-located exchange kernels each hold a hardware queue): with a cloud so small
 that the kernels' work is negligible, the time per evaluation beyond the plain handle's is the exchange (two flag round
 trips + slice reduce + delivery), the extra launch and the host-thread hand-off.  Also the 10M-point case for the record
 (there the shards' kernels share the one GPU, so nothing is gained -- it only shows the protocol at full size).
@@ -23,7 +23,7 @@ for label, n_points in (("tiny", 4096), ("10M", 10_000_000)):
     rng = np.random.default_rng(3)
     poses = np.ascontiguousarray([synth.random_pose_near(s.T_camera_lidar_true, rng) for _ in range(40)])
     row = {}
-    for n in (1, 2, 4):
+    for n in (1, 2, 3):
         c = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, bins, devices=None if n == 1 else [0] * n)
         c.eval_batch(poses[:5])
         ts = []
