@@ -129,13 +129,14 @@ def load():
 
 
 def kernel_source_hash():
-    """sha256 (16 hex digits) over the sources libnidreg.so is built from: stamps PMC summaries so that bench.py never
-    reports counter traffic measured on a different kernel build."""
-    import glob
+    """sha256 (16 hex digits) over the sources of the evaluation kernels (device code, launch wrappers, build flags --
+    not the host side of the ABI): stamps PMC summaries so that bench.py never reports counter traffic measured on a
+    different kernel build."""
     import hashlib
 
     h = hashlib.sha256()
-    for path in sorted(glob.glob(os.path.join(CSRC_DIR, "*.hip")) + glob.glob(os.path.join(CSRC_DIR, "*.hpp")) + [os.path.join(CSRC_DIR, "Makefile")]):
+    names = ["nid_device.hpp", "nid_kernels.hpp", "nid_launch_impl.hpp", "nid_kernels_f64.hip", "nid_kernels_f32.hip", "nid_kernels_f64_exact.hip", "Makefile"]
+    for path in [os.path.join(CSRC_DIR, n) for n in names]:
         h.update(os.path.basename(path).encode())
         with open(path, "rb") as f:
             h.update(f.read())
