@@ -329,16 +329,21 @@ int launch_grad(nidreg_handle* h) {
   return NIDREG_OK;
 }
 
-// asynchronous part of nidreg_eval
-int eval_launch(nidreg_handle* h, const double* se3, bool want_grad) {
+// asynchronous part of nidreg_eval, in two steps so that a multi-handle caller can put every GPU to work before it
+// queues the rest: eval_launch_first = the histogram pass, eval_launch_rest = entropy (+ gradient)
+int eval_launch_first(nidreg_handle* h, const double* se3) {
   if (h->mode != NIDREG_MODE_SPLINE) return fail(NIDREG_ERR_INVALID, "nidreg_eval: handle was created in NEAREST mode");
   HIP_TRY(hipSetDevice(h->device));
   bump_seq(h);
   if (h->timing) HIP_TRY(hipEventRecord(h->ev[0], h->stream));
-  int rc = launch_hist_spline(h, se3);
+  const int rc = launch_hist_spline(h, se3);
   if (rc) return rc;
   if (h->timing) HIP_TRY(hipEventRecord(h->ev[2], h->stream));
-  rc = launch_entropy(h, want_grad ? 0.0 : h->seq);
+  return NIDREG_OK;
+}
+int eval_launch_rest(nidreg_handle* h, bool want_grad) {
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = launch_entropy(h, want_grad ? 0.0 : h->seq);
   if (rc) return rc;
   if (h->timing) HIP_TRY(hipEventRecord(h->ev[3], h->stream));
   h->ev_grad = want_grad;
@@ -351,6 +356,11 @@ int eval_launch(nidreg_handle* h, const double* se3, bool want_grad) {
   if (h->timing) HIP_TRY(hipEventRecord(h->ev[5], h->stream));
   if (!h->d_out_host) HIP_TRY(hipMemcpyAsync(h->h_out, h->d_out, NIDREG_OUT_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   return NIDREG_OK;
+}
+int eval_launch(nidreg_handle* h, const double* se3, bool want_grad) {
+  const int rc = eval_launch_first(h, se3);
+  if (rc) return rc;
+  return eval_launch_rest(h, want_grad);
 }
 
 int eval_finish(nidreg_handle* h, double* cost, double* grad7) {
@@ -1197,7 +1207,12 @@ int nidreg_eval_multi(nidreg_handle* const* handles, int n, const double* init_s
   for (int i = 0; i < n; i++) {
     if (!handles[i]) return fail(NIDREG_ERR_INVALID, "nidreg_eval_multi: null handle");
     if (handles[i]->set) continue;  // a pair sharded over several GPUs: evaluated through its set below
-    const int rc = eval_launch(handles[i], se3, grad7 != nullptr);
+    const int rc = eval_launch_first(handles[i], se3);  // every pair's (every GPU's) histogram pass is running ...
+    if (rc) return rc;
+  }
+  for (int i = 0; i < n; i++) {
+    if (handles[i]->set) continue;
+    const int rc = eval_launch_rest(handles[i], grad7 != nullptr);  // ... while the rest is queued behind it
     if (rc) return rc;
   }
   double csum = 0.0, gsum[7] = {0, 0, 0, 0, 0, 0, 0};

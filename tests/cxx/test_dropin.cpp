@@ -75,6 +75,16 @@ int main(int argc, char** argv) {
   vlcal::NIDCost from_cloud(proj, img64, cloud, nullptr, 0.0, false, bins);
   double c3 = 0.0;
   if (!from_cloud(se3, &c3) || c3 != c2) return 9;
+  // the pair sharded over "two GPUs" inside the library (the device list extension of the constructor; the same device
+  // twice is what a 1-GPU box offers): bit-identical cost, gradient equal to summation order
+  {
+    vlcal::NIDCost sharded(proj, img64, frame, bins, 0, NIDREG_PREC_FP64, std::vector<int>{0, 0});
+    if (nidreg_num_shards(sharded.native_handle()) != 2) return 10;
+    J res_s;
+    if (!sharded(params, &res_s) || res_s.a != res.a) return 11;
+    for (int k = 0; k < 7; k++)
+      if (std::fabs(res_s.v[k] - res.v[k]) > 1e-12 * (1.0 + std::fabs(res.v[k]))) return 12;
+  }
 
   auto data = std::make_shared<vlcal::VisualLiDARData>(img8, frame);
   vlcal::NIDCostParams np;
