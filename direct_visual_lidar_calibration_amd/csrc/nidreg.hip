@@ -1022,6 +1022,14 @@ int create_sharded(const nidreg_desc* d, nidreg_handle** out) {
   // The same device may be listed more than once (a 1-GPU box exercising the protocol), but the exchange kernels of
   // co-located shards wait for each other while holding a hardware queue each: beyond three per device two of them
   // share a queue (ROCm maps streams onto 4) and the wait could only end by its timeout.
+  {
+    bool colocated = false;
+    for (int id : ids) colocated = colocated || std::count(ids.begin(), ids.end(), id) > 1;
+    static std::atomic<bool> warned{false};
+    if (colocated && !warned.exchange(true))
+      std::fprintf(stderr, "nidreg: several shards of one pair share a device -- a test configuration: their streams must not share a hardware queue "
+                           "(set GPU_MAX_HW_QUEUES >= the number of streams in the process before HIP initialises)\n");
+  }
   for (int id : ids)
     if (std::count(ids.begin(), ids.end(), id) > 3) return fail(NIDREG_ERR_INVALID, "nidreg_create: at most 3 shards of one pair may share a device (device " + std::to_string(id) + " is listed more often)");
   // peer mappings, both directions, before any buffer is allocated

@@ -658,3 +658,52 @@ def test_input_order_flag_and_strided_points():
     assert np.allclose(ra[2], rb[2], rtol=1e-12, atol=1e-15)
     for h in (a, b):
         h.close()
+
+
+@pytest.mark.parametrize("bins", [16, 256])
+def test_outliers_and_padding_do_not_change_the_bits(bins):
+    """The histogram kernels pick, per wave and per four points, between tap code with uniform constants (every lane an
+    inlier) and with per-lane constants zeroed for outliers / padding slots.  Both must give a point the same bits:
+    interleaving outliers (outside the image, behind the camera, NaN) with the cloud -- in the caller's order, so that
+    they share waves with inliers -- changes neither the fixed-point histogram nor the cost, and only adds zeros to the
+    gradient sums."""
+    from direct_visual_lidar_calibration_amd import _lib
+
+    s = scene_for("plumb_bob", n=24000)
+    proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
+    x = s.T_camera_lidar_true
+    base = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, bins, flags=_lib.FLAG_INPUT_ORDER)
+    ok, c, g = base(x)
+    fx, inl, frac = base.histogram_fixed()
+    assert ok and inl > 0.9 * s.points.shape[0]
+    T = se3.to_matrix(x)
+    Tinv = np.linalg.inv(T)
+    rng = np.random.default_rng(12)
+    n_out = 5000
+    cam = np.stack([rng.uniform(-1, 1, n_out) * 50.0, rng.uniform(-1, 1, n_out) * 50.0, rng.uniform(0.2, 1.0, n_out)], -1)  # far outside the image
+    cam[::3, 2] *= -1.0  # behind the camera (mirrored projection: still outside or inside? keep only those that fall outside below)
+    outl = np.concatenate([cam @ Tinv[:3, :3].T + Tinv[:3, 3], np.ones((n_out, 1))], -1)
+    outl[:, :3] = outl[:, :3].astype(np.float32).astype(np.float64)  # PLY-representable like the cloud: float32 records either way
+    outl[::7, :3] = np.nan
+    uv = oracle_lib.project(s.model, s.intrinsics, s.distortion, outl[:, :3] @ T[:3, :3].T + T[:3, 3])
+    outside = ~((uv[:, 0] >= 0) & (uv[:, 0] < s.width) & (uv[:, 1] >= 0) & (uv[:, 1] < s.height))  # NaN compares false -> outside
+    outl = outl[outside]
+    assert outl.shape[0] > 2000
+    # interleave: every 5th record of the mixed cloud is an outlier, intensities drawn from the cloud's own levels
+    n = s.points.shape[0]
+    k = min(outl.shape[0], n // 4)
+    pts = np.empty((n + k, 4))
+    ints = np.empty(n + k)
+    mask = np.zeros(n + k, dtype=bool)
+    mask[np.arange(k) * 5 + 2] = True
+    pts[mask], pts[~mask] = outl[:k], s.points
+    ints[mask], ints[~mask] = s.intensities[rng.integers(0, n, k)], s.intensities
+    for flags in (_lib.FLAG_INPUT_ORDER, 0):
+        mixed = nid.NIDCost(proj, s.image_f64, pts, ints, bins, flags=flags)
+        ok2, c2, g2 = mixed(x)
+        fx2, inl2, frac2 = mixed.histogram_fixed()
+        assert ok2 and inl2 == inl and frac2 == frac
+        assert np.array_equal(fx2, fx) and c2 == c
+        assert np.allclose(g2, g, rtol=1e-12, atol=1e-15)
+        mixed.close()
+    base.close()

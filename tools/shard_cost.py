@@ -11,6 +11,8 @@ import time
 
 import numpy as np
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # co-located shards must not share an in-order hardware queue
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from direct_visual_lidar_calibration_amd import nid, synth  # noqa: E402
