@@ -15,6 +15,7 @@
 // All kernels: 256 threads (4 waves of 64); dynamic LDS only, base 16-B aligned.
 #pragma once
 #include "nid_device.hpp"
+#include "nid_multi.hpp"
 
 namespace nidreg {
 
@@ -163,7 +164,7 @@ constexpr int kWideShift = 5;
 template <int MODEL, typename Rec, typename real, bool WIDE>
 __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_spline_hist(
   const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint8_t* __restrict__ img, int pitch, int W, int H, PoseParams<real> pose, CamParams<real> cam, int B,
-  int GW, int cshift, double dn_scale, u64* __restrict__ hist) {
+  int GW, int cshift, double dn_scale, u64* __restrict__ hist, const MultiEntry* __restrict__ multi, MultiDyn dyn) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u64* tile = reinterpret_cast<u64*>(smem);
   if (WIDE) {  // the specialisation's tiling is fixed: compile-time constants instead of three SGPRs
@@ -184,6 +185,13 @@ __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_spline_hist(
   constexpr int kT = WIDE ? kWideThreads : kThreads;
   const int tid = threadIdx.x;
   const Chunk ch = chunks[blockIdx.x];
+  if (multi) {  // one grid over several pairs: this chunk's pair brings its own records, bin image, histogram and unit
+    const MultiEntry& e = multi[ch.pad];
+    pts = static_cast<const Rec*>(e.pts);
+    img = e.img;
+    hist = e.hist_buf[dyn.cur[ch.pad]];
+    dn_scale = e.k16;
+  }
   stamp_begin();
   for (int k = tid; k < tile_w; k += kT) tile[k] = 0;
   if (tid == 0) *s_inl = 0;
@@ -466,16 +474,38 @@ constexpr int kEntropyThreads = 1024;
 constexpr int kEntropyWaves = kEntropyThreads / 64;
 __global__ __launch_bounds__(kEntropyThreads) void k_entropy(
   const u64* __restrict__ hist, int B, int CB, double inv_unit, double* part_hj, u64* row_part, double* phi_q, double* hist_image_out, double* hist_points_out,
-  EntropyScalars* scal, double* out, double* out_host, double tag, unsigned int* counter, u64* __restrict__ zero_buf, long long zero_words) {
+  EntropyScalars* scal, double* out, double* out_host, double tag, unsigned int* counter, u64* __restrict__ zero_buf, long long zero_words, const MultiEntry* __restrict__ multi,
+  MultiDyn dyn) {
   __shared__ double s_red[3 * kEntropyWaves];
   __shared__ u64 s_row[3][256];
   __shared__ int s_flag;
   const int tid = threadIdx.x;
-  const int j = blockIdx.x;
+  int j = blockIdx.x;
+  int nblocks = int(gridDim.x);
+  if (multi) {  // dyn.neb workgroups per pair, pair after pair
+    const int pair = int(blockIdx.x) / dyn.neb;
+    j = int(blockIdx.x) % dyn.neb;
+    nblocks = dyn.neb;
+    const MultiEntry& e = multi[pair];
+    hist = e.hist_buf[dyn.cur[pair]];
+    zero_buf = e.hist_buf[dyn.cur[pair] ^ 1];
+    zero_words = e.zero_words;
+    inv_unit = e.inv_unit;
+    part_hj = e.part_hj;
+    row_part = e.row_part;
+    phi_q = e.phi_q;
+    hist_image_out = e.hist_image;
+    hist_points_out = e.hist_points;
+    scal = e.scal;
+    out = e.out;
+    out_host = e.out_host;
+    counter = e.counters;
+    tag = dyn.want_grad ? 0.0 : dyn.tag[pair];
+  }
   // double-buffered histogram: clear the buffer the NEXT evaluation accumulates into (nidreg.hip,
   // begin_histogram) -- ~0.5 MB of stores that replace a memset launch per evaluation
   if (zero_buf)
-    for (long long k = (long long)j * kEntropyThreads + tid; k < zero_words; k += (long long)gridDim.x * kEntropyThreads) zero_buf[k] = 0;
+    for (long long k = (long long)j * kEntropyThreads + tid; k < zero_words; k += (long long)nblocks * kEntropyThreads) zero_buf[k] = 0;
   const int r = tid & 255, q = tid >> 8;
   const int c0 = j * CB;
   const int ncols = min(CB, B - c0);
@@ -511,8 +541,8 @@ __global__ __launch_bounds__(kEntropyThreads) void k_entropy(
   const u64* col_sum = hist + size_t(B) * size_t(B) + kTailWords;  // accumulated by the histogram kernels' flush
   // the tail's loops stride by kThreads = 256 over B <= 256 items: threads beyond 255 find nothing to do but take part
   // in its barriers and (with zeros) in its wave reductions -- s_red holds 3 slots for each of the 16 waves
-  if (last_workgroup_arrives<false>(counter, gridDim.x, &s_flag))
-    entropy_final_body(hist, B, int(gridDim.x), inv_unit, part_hj, row_part, col_sum, phi_q, hist_image_out, hist_points_out, scal, out, out_host, tag, s_red);
+  if (last_workgroup_arrives<false>(counter, unsigned(nblocks), &s_flag))
+    entropy_final_body(hist, B, nblocks, inv_unit, part_hj, row_part, col_sum, phi_q, hist_image_out, hist_points_out, scal, out, out_host, tag, s_red);
 }
 
 #endif  // NID_COMMON_KERNELS
@@ -630,7 +660,7 @@ template <int MODEL, typename Rec, typename real, bool GW1>
 __global__ __launch_bounds__(kThreads, NID_GRAD_MIN_WAVES) void k_spline_grad(
   const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint8_t* __restrict__ img, int pitch, int W, int H, PoseParams<real> pose, CamParams<real> cam, int B,
   int GW, int cshift, double inv_unit, const u64* __restrict__ hist, const double* __restrict__ phi_q, const EntropyScalars* __restrict__ scal, double* partials, double qx,
-  double qy, double qz, double qw, double* out, double* out_host, double tag, unsigned int* counter) {
+  double qy, double qz, double qw, double* out, double* out_host, double tag, unsigned int* counter, const MultiEntry* __restrict__ multi, MultiDyn dyn) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* gtile = reinterpret_cast<double*>(smem);
   const int tile_n = GW * B;
@@ -641,6 +671,23 @@ __global__ __launch_bounds__(kThreads, NID_GRAD_MIN_WAVES) void k_spline_grad(
 
   const int tid = threadIdx.x;
   const Chunk ch = chunks[blockIdx.x];
+  unsigned int my_block = blockIdx.x, my_blocks = gridDim.x;  // this workgroup's slot among its pair's partials
+  if (multi) {
+    const MultiEntry& e = multi[ch.pad];
+    pts = static_cast<const Rec*>(e.pts);
+    img = e.img;
+    hist = e.hist_buf[dyn.cur[ch.pad]];
+    inv_unit = e.inv_unit;
+    phi_q = e.phi_q;
+    scal = e.scal;
+    partials = e.partials;
+    out = e.out;
+    out_host = e.out_host;
+    tag = dyn.tag[ch.pad];
+    counter = e.counters + 1;
+    my_block = blockIdx.x - unsigned(e.chunk_base);
+    my_blocks = unsigned(e.nchunks);
+  }
   {
     const double coefA = scal->coefA, coefB = scal->coefB;
     const double scale = inv_unit / scal->S;
@@ -738,9 +785,9 @@ __global__ __launch_bounds__(kThreads, NID_GRAD_MIN_WAVES) void k_spline_grad(
     double t = 0.0;
     for (int w = 0; w < kWaves; w++) t += s_red[w * 12 + tid];
     // [12][nchunks] (coalesced for the final reduction), stored write-through at agent scope
-    __hip_atomic_store(&partials[size_t(tid) * gridDim.x + blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&partials[size_t(tid) * my_blocks + my_block], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (last_workgroup_arrives<true>(counter, gridDim.x, s_flag)) grad_final_body(partials, int(gridDim.x), qx, qy, qz, qw, out, out_host, tag, s_red);
+  if (last_workgroup_arrives<true>(counter, my_blocks, s_flag)) grad_final_body(partials, int(my_blocks), qx, qy, qz, qw, out, out_host, tag, s_red);
 }
 
 #ifdef NID_COMMON_KERNELS

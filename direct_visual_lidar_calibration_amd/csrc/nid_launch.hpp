@@ -10,6 +10,8 @@
 #include <mutex>
 #include <vector>
 
+#include "nid_multi.hpp"
+
 namespace nidreg {
 
 struct Chunk;
@@ -41,6 +43,8 @@ struct PassArgs {
   unsigned int* counter;  // last-workgroup ticket
   hipStream_t stream;
   size_t lds_hist, lds_grad;
+  const MultiEntry* multi;  // non-NULL: one grid over several pairs (chunks / nchunks are then the combined table)
+  MultiDyn dyn;
 };
 
 template <typename real> hipError_t launch_spline_hist(const PassArgs& a);

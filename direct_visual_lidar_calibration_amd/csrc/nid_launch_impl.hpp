@@ -70,7 +70,7 @@ static hipError_t launch_spline_hist_rec(const PassArgs& a) {
     hipError_t e = ensure_lds(k, a.lds_hist);                                                                                                          \
     if (e != hipSuccess) return e;                                                                                                                     \
     hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(THREADS), a.lds_hist, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, pose, cam, \
-                       a.B, a.GW, a.cshift, a.magic, a.hist);                                                                                                   \
+                       a.B, a.GW, a.cshift, a.magic, a.hist, a.multi, a.dyn);                                                                                                   \
   }
   if (a.wide) {  // B = 256, GW = 1, 32 copies, 512 threads (see k_spline_hist)
 #define NID_LAUNCH(M) NID_LAUNCH_W(M, true, kWideThreads)
@@ -95,7 +95,7 @@ static hipError_t launch_spline_grad_rec(const PassArgs& a) {
     hipError_t e = ensure_lds(k, a.lds_grad);                                                                                                          \
     if (e != hipSuccess) return e;                                                                                                                     \
     hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(kThreads), a.lds_grad, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, pose, cam, \
-                       a.B, a.GW, a.cshift, a.inv_unit, a.hist, a.phi_q, a.scal, a.partials, a.q[0], a.q[1], a.q[2], a.q[3], a.out, a.out_host, a.tag, a.counter); \
+                       a.B, a.GW, a.cshift, a.inv_unit, a.hist, a.phi_q, a.scal, a.partials, a.q[0], a.q[1], a.q[2], a.q[3], a.out, a.out_host, a.tag, a.counter, a.multi, a.dyn); \
   }
   if (a.GW == 1) {
 #define NID_LAUNCH(M) NID_LAUNCH_G(M, true)

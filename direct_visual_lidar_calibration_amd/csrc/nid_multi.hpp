@@ -1,0 +1,43 @@
+// nid_multi.hpp -- per-pair table of the single-grid multi-pair evaluation (shared by the kernels and the host side).
+#pragma once
+#include <stdint.h>
+
+namespace nidreg {
+
+typedef unsigned long long u64;
+struct EntropyScalars;
+
+// MultiNIDCost on one GPU (visual_camera_calibration.cpp:141-178: the same pose for every pair): ONE grid per pass over
+// the chunks of ALL pairs instead of three launches per pair.  Chunk::pad carries the pair's index into this table (device
+// memory, built once per set of handles); what changes per evaluation -- which of the two histogram buffers is current,
+// the completion tag -- travels by value (MultiDyn).  multi == nullptr: the single-pair launch, unchanged.
+constexpr int kMaxMulti = 16;
+struct MultiEntry {
+  const void* pts;
+  const uint8_t* img;
+  u64* hist_buf[2];
+  double k16;       // U/6 as a subnormal double (bspline_scale)
+  double inv_unit;  // 1 / U
+  double* part_hj;
+  u64* row_part;
+  double* phi_q;
+  double* hist_image;
+  double* hist_points;
+  EntropyScalars* scal;
+  double* partials;
+  double* out;
+  double* out_host;
+  unsigned int* counters;  // [0] entropy ticket, [1] gradient ticket
+  long long zero_words;
+  int chunk_base;  // first chunk of this pair in the combined gradient-pass table
+  int nchunks;
+};
+struct MultiDyn {
+  double tag[kMaxMulti];
+  unsigned char cur[kMaxMulti];  // index of the histogram buffer this evaluation accumulates into
+  int want_grad;
+  int neb;  // entropy workgroups per pair
+};
+
+
+}  // namespace nidreg

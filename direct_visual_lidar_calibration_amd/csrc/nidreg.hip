@@ -112,6 +112,8 @@ struct nidreg_handle {
 
   size_t lds_hist = 0, lds_grad = 0, lds_entropy = 0;
   int64_t hist_words = 0;
+  std::vector<int64_t> gcount;  // record offsets of the column groups (host copy: multi-pair groups build their chunk tables from it)
+  int num_cus = 256, per_cu_grad = 4, per_cu_hist = 2;
 
   bool timing = false;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -152,6 +154,7 @@ struct ShardSet {
 namespace {
 
 void free_shard_set(ShardSet* set);
+void drop_groups_of(const nidreg_handle* h);
 
 void free_handle(nidreg_handle* h) {
   if (!h) return;
@@ -159,6 +162,7 @@ void free_handle(nidreg_handle* h) {
     free_shard_set(h->set);  // stops the workers and frees the other shards
     h->set = nullptr;
   }
+  drop_groups_of(h);
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->d_pts) (void)hipFree(h->d_pts);
@@ -248,19 +252,20 @@ void pose_from_se3(const double* se3, double* R, double* t) {
 // buffers the previous evaluation's k_entropy has already zeroed it; a caller-provided buffer
 // (ext_hist: the sharded protocol all-reduces it in place) or a buffer left dirty by a failed launch
 // is cleared with a memset.
-hipError_t begin_histogram(nidreg_handle* h) {
+hipError_t begin_histogram(nidreg_handle* h, hipStream_t stream) {
   if (h->own_hist) {
     h->hist_cur ^= 1;
     h->d_hist = h->d_hist_buf[h->hist_cur];
     if (!h->hist_zeroed[h->hist_cur]) {
-      hipError_t e = hipMemsetAsync(h->d_hist, 0, size_t(h->hist_words) * sizeof(u64), h->stream);
+      hipError_t e = hipMemsetAsync(h->d_hist, 0, size_t(h->hist_words) * sizeof(u64), stream);
       if (e != hipSuccess) return e;
     }
     h->hist_zeroed[h->hist_cur] = false;  // about to be written
     return hipSuccess;
   }
-  return hipMemsetAsync(h->d_hist, 0, size_t(h->hist_words) * sizeof(u64), h->stream);
+  return hipMemsetAsync(h->d_hist, 0, size_t(h->hist_words) * sizeof(u64), stream);
 }
+hipError_t begin_histogram(nidreg_handle* h) { return begin_histogram(h, h->stream); }
 
 int launch_hist_spline(nidreg_handle* h, const double* se3) {
   PassArgs a;
@@ -303,7 +308,8 @@ int launch_entropy(nidreg_handle* h, double tag) {
   const double inv_unit = 1.0 / fixed_unit(h);
   hipLaunchKernelGGL(
     k_entropy, dim3(h->NEB), dim3(kEntropyThreads), 0, h->stream, hist_source(h), h->bins, kEntropyCols, inv_unit, h->d_part_hj, h->d_row_part, h->d_phi_q, h->d_hist_image,
-    h->d_hist_points, h->d_scal, h->d_out, h->d_out_host, tag, h->d_counters, h->own_hist ? h->d_hist_buf[h->hist_cur ^ 1] : nullptr, h->hist_words);
+    h->d_hist_points, h->d_scal, h->d_out, h->d_out_host, tag, h->d_counters, h->own_hist ? h->d_hist_buf[h->hist_cur ^ 1] : nullptr, h->hist_words, static_cast<const MultiEntry*>(nullptr),
+    MultiDyn());
   HIP_TRY(hipGetLastError());
   if (h->own_hist) h->hist_zeroed[h->hist_cur ^ 1] = true;  // zeroed by this k_entropy for the next evaluation
   return NIDREG_OK;
@@ -363,7 +369,10 @@ int eval_launch(nidreg_handle* h, const double* se3, bool want_grad) {
   return eval_launch_rest(h, want_grad);
 }
 
-int eval_finish(nidreg_handle* h, double* cost, double* grad7) {
+int eval_finish_on(nidreg_handle* h, hipStream_t stream, double* cost, double* grad7);
+int eval_finish(nidreg_handle* h, double* cost, double* grad7) { return eval_finish_on(h, h->stream, cost, grad7); }
+// `stream` = the stream the evaluation's kernels were queued on (the handle's own, or a multi-pair group's)
+int eval_finish_on(nidreg_handle* h, hipStream_t stream, double* cost, double* grad7) {
   HIP_TRY(hipSetDevice(h->device));
   if (h->d_out_host) {
     // the finalising workgroup wrote the results and then this evaluation's tag into host-mapped memory:
@@ -390,9 +399,9 @@ int eval_finish(nidreg_handle* h, double* cost, double* grad7) {
         const double us = (t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3;
         if (us >= next_query_us) {
           next_query_us = us + 1000.0;
-          const hipError_t q = hipStreamQuery(h->stream);
+          const hipError_t q = hipStreamQuery(stream);
           if (q == hipSuccess) {
-            if (!tag_seen()) HIP_TRY(hipStreamSynchronize(h->stream));
+            if (!tag_seen()) HIP_TRY(hipStreamSynchronize(stream));
             if (!tag_seen()) return fail(NIDREG_ERR_HIP, "nidreg_eval: stream drained but the completion tag is missing");
             break;
           }
@@ -406,10 +415,10 @@ int eval_finish(nidreg_handle* h, double* cost, double* grad7) {
     }
     if (++h->evals_since_reap >= 256) {
       h->evals_since_reap = 0;
-      (void)hipStreamQuery(h->stream);
+      (void)hipStreamQuery(stream);
     }
   } else {
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipStreamSynchronize(stream));
   }
   if (cost) *cost = h->h_out[0];
   if (grad7)
@@ -701,6 +710,10 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
       if (og > 0) per_cu_grad = std::min(og, 8);
       if (oh > 0) per_cu_hist = std::min(oh, 8);
     }
+    h->gcount = gcount;
+    h->num_cus = num_cus;
+    h->per_cu_grad = h->wide ? per_cu_grad : std::min(per_cu_grad, per_cu_hist);
+    h->per_cu_hist = per_cu_hist;
     std::vector<Chunk> chunks;
     build_chunks(d->target_blocks > 0 ? d->target_blocks : (h->wide ? per_cu_grad : std::min(per_cu_grad, per_cu_hist)) * num_cus, kThreads, chunks);
     h->nchunks = int(chunks.size());
@@ -793,6 +806,205 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
   for (int i = 0; i < 6; i++) CREATE_TRY(hipEventCreate(&h->ev[i]));
 #undef CREATE_TRY
   *out = h;
+  return NIDREG_OK;
+}
+
+// ---- several pairs on one GPU: one grid per pass over all pairs' chunks -----------------------------------------
+// MultiNIDCost evaluates every pair at the same pose (visual_camera_calibration.cpp:147-173).  Launching three kernels
+// per pair makes k small pairs on one GPU launch- and prologue-bound (8 x 1.25M points: 337 us against 160 us for one
+// 10M-point pair); a group launches THREE kernels in all, whose combined chunk tables give every pair a share of the
+// one round of co-resident workgroups in proportion to its points.  Results are bit-identical to evaluating the handles
+// one by one (each pair keeps its own histogram buffers, fixed-point unit, scratch and result block).
+struct MultiGroup {
+  std::vector<nidreg_handle*> hs;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  MultiEntry* d_table = nullptr;
+  Chunk* d_chunks = nullptr;       // gradient pass / generic histogram kernels
+  Chunk* d_chunks_hist = nullptr;  // WIDE histogram kernel
+  int nchunks = 0, nchunks_hist = 0;
+};
+std::mutex g_groups_mu;
+std::vector<MultiGroup*> g_groups;
+
+void free_group(MultiGroup* g) {
+  (void)hipSetDevice(g->device);
+  if (g->stream) (void)hipStreamSynchronize(g->stream);
+  if (g->d_table) (void)hipFree(g->d_table);
+  if (g->d_chunks) (void)hipFree(g->d_chunks);
+  if (g->d_chunks_hist) (void)hipFree(g->d_chunks_hist);
+  if (g->stream) (void)hipStreamDestroy(g->stream);
+  delete g;
+}
+// called by free_handle: a group dies with any of its members
+void drop_groups_of(const nidreg_handle* h) {
+  std::lock_guard<std::mutex> lk(g_groups_mu);
+  for (size_t i = 0; i < g_groups.size();) {
+    if (std::find(g_groups[i]->hs.begin(), g_groups[i]->hs.end(), h) != g_groups[i]->hs.end()) {
+      free_group(g_groups[i]);
+      g_groups.erase(g_groups.begin() + long(i));
+    } else {
+      i++;
+    }
+  }
+}
+
+bool groupable(const nidreg_handle* a, const nidreg_handle* b) {
+  return a->device == b->device && a->model == b->model && a->mode == NIDREG_MODE_SPLINE && b->mode == NIDREG_MODE_SPLINE && a->precision == b->precision && a->bins == b->bins &&
+         a->W == b->W && a->H == b->H && a->pitch == b->pitch && a->GW == b->GW && a->cshift == b->cshift && a->wide == b->wide && a->rec64 == b->rec64 &&
+         std::memcmp(a->intr, b->intr, sizeof(a->intr)) == 0 && std::memcmp(a->dist, b->dist, sizeof(a->dist)) == 0 && a->own_hist && b->own_hist && a->d_out_host && b->d_out_host &&
+         !a->set && !b->set && !a->is_shard && !b->is_shard && !a->timing && !b->timing;
+}
+
+// chunks of one pair for a share `target` of the round (same rule as create_impl: a column group is split evenly)
+void pair_chunks(const nidreg_handle* h, int pair, int64_t target, int threads, std::vector<Chunk>& chunks) {
+  const int64_t N = h->num_points;
+  int64_t CH = (N + target - 1) / std::max<int64_t>(target, 1);
+  CH = std::max<int64_t>(threads, ((CH + threads - 1) / threads) * threads);
+  for (int g = 0; g < h->NG; g++) {
+    const int64_t lo = h->gcount[size_t(g)], hi = h->gcount[size_t(g) + 1];
+    if (hi <= lo) continue;
+    const int64_t parts = (hi - lo + CH - 1) / CH;
+    const int64_t size = (((hi - lo + parts - 1) / parts + 63) / 64) * 64;
+    for (int64_t st = lo; st < hi; st += size) {
+      Chunk c;
+      c.start = uint32_t(st);
+      c.count = uint32_t(std::min<int64_t>(size, hi - st));
+      c.group = uint32_t(g);
+      c.pad = uint32_t(pair);
+      chunks.push_back(c);
+    }
+  }
+}
+
+MultiGroup* find_or_make_group(nidreg_handle* const* handles, int n) {
+  std::lock_guard<std::mutex> lk(g_groups_mu);
+  for (MultiGroup* g : g_groups)
+    if (int(g->hs.size()) == n && std::equal(g->hs.begin(), g->hs.end(), handles)) return g;
+  MultiGroup* g = new MultiGroup();
+  g->hs.assign(handles, handles + n);
+  g->device = handles[0]->device;
+  int64_t total = 0;
+  for (int i = 0; i < n; i++) total += std::max<int64_t>(handles[i]->num_points, 1);
+  std::vector<Chunk> chunks, wide_chunks;
+  std::vector<MultiEntry> table(static_cast<size_t>(n));
+  const nidreg_handle* h0 = handles[0];
+  for (int i = 0; i < n; i++) {
+    nidreg_handle* h = handles[i];
+    const int64_t share_grad = std::max<int64_t>(1, int64_t(h0->per_cu_grad) * h0->num_cus * std::max<int64_t>(h->num_points, 1) / total);
+    const int base = int(chunks.size());
+    pair_chunks(h, i, share_grad, kThreads, chunks);
+    if (h0->wide) {
+      const int64_t share_hist = std::max<int64_t>(1, int64_t(h0->per_cu_hist) * h0->num_cus * std::max<int64_t>(h->num_points, 1) / total);
+      pair_chunks(h, i, share_hist, kWideThreads, wide_chunks);
+    }
+    MultiEntry& e = table[size_t(i)];
+    e.pts = h->d_pts;
+    e.img = h->d_img;
+    e.hist_buf[0] = h->d_hist_buf[0];
+    e.hist_buf[1] = h->d_hist_buf[1];
+    e.k16 = std::ldexp(fixed_unit(h) / 6.0, -1074);
+    e.inv_unit = 1.0 / fixed_unit(h);
+    e.part_hj = h->d_part_hj;
+    e.row_part = h->d_row_part;
+    e.phi_q = h->d_phi_q;
+    e.hist_image = h->d_hist_image;
+    e.hist_points = h->d_hist_points;
+    e.scal = h->d_scal;
+    e.partials = h->d_partials;
+    e.out = h->d_out;
+    e.out_host = h->d_out_host;
+    e.counters = h->d_counters;
+    e.zero_words = h->hist_words;
+    e.chunk_base = base;
+    e.nchunks = int(chunks.size()) - base;
+    if (e.nchunks > std::max(h->nchunks, 1)) {  // the pair's partial buffer holds 12 doubles per chunk of ITS OWN table
+      delete g;
+      return nullptr;
+    }
+  }
+  hipError_t err = hipSetDevice(g->device);
+  if (err == hipSuccess) err = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
+  if (err == hipSuccess) err = hipMalloc(&g->d_table, table.size() * sizeof(MultiEntry));
+  if (err == hipSuccess) err = hipMemcpy(g->d_table, table.data(), table.size() * sizeof(MultiEntry), hipMemcpyHostToDevice);
+  if (err == hipSuccess) err = hipMalloc(&g->d_chunks, std::max<size_t>(chunks.size(), 1) * sizeof(Chunk));
+  if (err == hipSuccess && !chunks.empty()) err = hipMemcpy(g->d_chunks, chunks.data(), chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice);
+  if (err == hipSuccess && h0->wide) {
+    err = hipMalloc(&g->d_chunks_hist, std::max<size_t>(wide_chunks.size(), 1) * sizeof(Chunk));
+    if (err == hipSuccess && !wide_chunks.empty()) err = hipMemcpy(g->d_chunks_hist, wide_chunks.data(), wide_chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice);
+  }
+  if (err != hipSuccess) {
+    free_group(g);
+    return nullptr;
+  }
+  g->nchunks = int(chunks.size());
+  g->nchunks_hist = int(wide_chunks.size());
+  g_groups.push_back(g);
+  return g;
+}
+
+// one evaluation of a group: three launches for all pairs, then every pair's completion tag
+int group_eval(MultiGroup* g, const double* se3, bool want_grad, double* costs, double* grads /* n x 7 or null */, bool* all_ok) {
+  const int n = int(g->hs.size());
+  nidreg_handle* h0 = g->hs[0];
+  HIP_TRY(hipSetDevice(g->device));
+  PassArgs a;
+  fill_pass_args(h0, a);
+  a.stream = g->stream;
+  a.multi = g->d_table;
+  a.dyn.want_grad = want_grad ? 1 : 0;
+  a.dyn.neb = h0->NEB;
+  pose_from_se3(se3, a.R, a.t);
+  for (int k = 0; k < 4; k++) a.q[k] = se3[k];
+  for (int i = 0; i < n; i++) {
+    nidreg_handle* h = g->hs[size_t(i)];
+    bump_seq(h);
+    HIP_TRY(begin_histogram(h, g->stream));
+    a.dyn.cur[i] = static_cast<unsigned char>(h->hist_cur);
+    a.dyn.tag[i] = h->seq;
+    for (int k = 0; k < 4; k++) h->last_q[k] = se3[k];
+    std::memcpy(h->last_R, a.R, sizeof(a.R));
+    std::memcpy(h->last_t, a.t, sizeof(a.t));
+    h->ev_grad = want_grad;
+  }
+  // pass A
+  a.chunks = h0->wide ? g->d_chunks_hist : g->d_chunks;
+  a.nchunks = h0->wide ? g->nchunks_hist : g->nchunks;
+  if (h0->precision == NIDREG_PREC_FP32) {
+    HIP_TRY(launch_spline_hist<float>(a));
+  } else {
+    HIP_TRY(launch_spline_hist<double>(a));
+  }
+  // entropy: NEB workgroups per pair
+  hipLaunchKernelGGL(
+    k_entropy, dim3(h0->NEB * n), dim3(kEntropyThreads), 0, g->stream, static_cast<const u64*>(nullptr), h0->bins, kEntropyCols, 0.0, static_cast<double*>(nullptr),
+    static_cast<u64*>(nullptr), static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<EntropyScalars*>(nullptr), static_cast<double*>(nullptr),
+    static_cast<double*>(nullptr), 0.0, static_cast<unsigned int*>(nullptr), static_cast<u64*>(nullptr), 0ll, static_cast<const MultiEntry*>(g->d_table), a.dyn);
+  HIP_TRY(hipGetLastError());
+  for (int i = 0; i < n; i++) g->hs[size_t(i)]->hist_zeroed[g->hs[size_t(i)]->hist_cur ^ 1] = true;
+  // pass B
+  if (want_grad) {
+    a.chunks = g->d_chunks;
+    a.nchunks = g->nchunks;
+    if (h0->precision == NIDREG_PREC_FP32) {
+      HIP_TRY(launch_spline_grad<float>(a));
+    } else {
+      HIP_TRY(launch_spline_grad<double>(a));
+    }
+    for (int i = 0; i < n; i++) {
+      nidreg_handle* h = g->hs[size_t(i)];
+      if (h->nchunks == 0 || h->num_points == 0) {  // an empty pair has no gradient workgroups: finalise (zeros) stand-alone
+        hipLaunchKernelGGL(k_grad_final, dim3(1), dim3(kThreads), 0, g->stream, h->d_partials, 0, se3[0], se3[1], se3[2], se3[3], h->d_out, h->d_out_host, h->seq);
+        HIP_TRY(hipGetLastError());
+      }
+    }
+  }
+  *all_ok = true;
+  for (int i = 0; i < n; i++) {
+    const int rc = eval_finish_on(g->hs[size_t(i)], g->stream, costs + i, grads ? grads + 7 * i : nullptr);
+    if (rc < 0) return rc;
+    if (rc == NIDREG_FALSE) *all_ok = false;
+  }
   return NIDREG_OK;
 }
 
@@ -1212,8 +1424,35 @@ int nidreg_eval_iso(nidreg_handle* h, const double* T, double* cost) {
 int nidreg_eval_multi(nidreg_handle* const* handles, int n, const double* init_se3, const double* se3, double* cost, double* grad7) {
   if (!handles || n <= 0 || !se3) return fail(NIDREG_ERR_INVALID, "nidreg_eval_multi: bad argument");
   if (init_se3 && !trust_gate_ok(init_se3, se3)) return NIDREG_FALSE;
-  for (int i = 0; i < n; i++) {
+  for (int i = 0; i < n; i++)
     if (!handles[i]) return fail(NIDREG_ERR_INVALID, "nidreg_eval_multi: null handle");
+  // several compatible pairs on ONE GPU: a single grid per pass over all pairs (group_eval)
+  if (n >= 2 && n <= kMaxMulti && !std::getenv("NIDREG_NO_MULTI_GRID")) {
+    bool same = true;
+    for (int i = 1; i < n && same; i++) same = groupable(handles[0], handles[i]) && handles[i] != handles[0];
+    for (int i = 0; i < n && same; i++)
+      for (int j = i + 1; j < n && same; j++) same = handles[i] != handles[j];
+    if (same && groupable(handles[0], handles[0])) {
+      MultiGroup* g = find_or_make_group(handles, n);
+      if (g) {
+        double costs[kMaxMulti], grads[kMaxMulti * 7];
+        bool all_ok = true;
+        const int rc = group_eval(g, se3, grad7 != nullptr, costs, grad7 ? grads : nullptr, &all_ok);
+        if (rc < 0) return rc;
+        double csum = 0.0, gsum[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < n; i++) {
+          csum += costs[i];
+          if (grad7)
+            for (int k = 0; k < 7; k++) gsum[k] += grads[7 * i + k];
+        }
+        if (cost) *cost = csum;
+        if (grad7)
+          for (int k = 0; k < 7; k++) grad7[k] = gsum[k];
+        return all_ok ? NIDREG_OK : NIDREG_FALSE;
+      }
+    }
+  }
+  for (int i = 0; i < n; i++) {
     if (handles[i]->set) continue;  // a pair sharded over several GPUs: evaluated through its set below
     const int rc = eval_launch_first(handles[i], se3);  // every pair's (every GPU's) histogram pass is running ...
     if (rc) return rc;

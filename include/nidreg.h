@@ -161,9 +161,13 @@ int nidreg_eval_batch(nidreg_handle* h, const double* se3s, int n, double* costs
 /* CostCalculatorNID::calculate at a row-major 4x4 T_camera_lidar */
 int nidreg_eval_iso(nidreg_handle* h, const double* T_camera_lidar, double* cost);
 
-/* MultiNIDCost::operator(): trust gate against init_se3 (NULL = no gate), all handles launched
- * concurrently (one per pair, possibly on different GPUs), plain sum of costs / gradients,
- * NIDREG_FALSE if the gate rejects or any pair is non-finite. */
+/* MultiNIDCost::operator(): trust gate against init_se3 (NULL = no gate), all pairs in flight at once, plain sum
+ * of costs / gradients, NIDREG_FALSE if the gate rejects or any pair is non-finite.  Handles on different GPUs run
+ * concurrently (every GPU's histogram pass is queued before the rest).  2..16 compatible SPLINE handles on ONE GPU
+ * (same camera, image size, bins, precision) are evaluated by ONE grid per pass over the chunks of all pairs -- three
+ * launches in all instead of three per pair; each pair keeps its own histogram, fixed-point unit and result block, so
+ * the result is bit-identical to evaluating the handles one by one (NIDREG_NO_MULTI_GRID=1 in the environment forces
+ * the per-pair launches). */
 int nidreg_eval_multi(nidreg_handle* const* handles, int n, const double* init_se3, const double* se3, double* cost, double* grad7);
 
 /* sum_i CostCalculatorNID_i::calculate(T) */

@@ -707,3 +707,58 @@ def test_outliers_and_padding_do_not_change_the_bits(bins):
         assert np.allclose(g2, g, rtol=1e-12, atol=1e-15)
         mixed.close()
     base.close()
+
+
+@pytest.mark.parametrize("bins", [16, 256])
+def test_multi_pair_single_grid_matches_individual_evaluations(bins, monkeypatch):
+    """nidreg_eval_multi over several compatible pairs on one GPU runs ONE grid per pass over all pairs' chunks (three
+    launches in all).  Every pair keeps its own histogram, unit and scratch, so the result must be exactly the sum of
+    the individual evaluations -- cost bit for bit, member histograms bit for bit -- for pairs of very different sizes,
+    over repeated calls (both histogram buffers), cost-only calls, and with the single-grid path switched off."""
+    sizes = [26000, 9000, 700, 15000]
+    scenes = [scene_for("plumb_bob", n=n, seed=70 + k) for k, n in enumerate(sizes)]
+    proj = nid.create_camera(scenes[0].model, scenes[0].intrinsics, scenes[0].distortion)
+    costs = [nid.NIDCost(proj, s.image_f64, s.points, s.intensities, bins) for s in scenes]
+    solo = [nid.NIDCost(proj, s.image_f64, s.points, s.intensities, bins) for s in scenes]
+    rng = np.random.default_rng(21)
+    poses = [scenes[0].T_camera_lidar_init] + [synth.random_pose_near(scenes[0].T_camera_lidar_true, rng) for _ in range(4)]
+    multi = nid.MultiNIDCost(None)
+    for c in costs:
+        multi.add(c)
+    for x in poses:
+        ok, c, g = multi(x)
+        parts = [s_(x) for s_ in solo]
+        assert ok and all(p[0] for p in parts)
+        csum = 0.0
+        for p in parts:
+            csum += p[1]
+        assert c == csum
+        assert np.allclose(g, sum(p[2] for p in parts), rtol=1e-12, atol=1e-15)
+        for a, b in zip(costs, solo):
+            assert np.array_equal(a.histogram_fixed()[0], b.histogram_fixed()[0]) and a.histogram_fixed()[1] == b.histogram_fixed()[1]
+        ok2, c2, g2 = multi(x, want_grad=False)
+        assert ok2 and c2 == csum and g2 is None
+    # a member evaluated on its own afterwards (its own stream, its own chunk table) still agrees
+    x = poses[2]
+    assert costs[1](x)[1] == solo[1](x)[1]
+    # the same through the per-pair launches
+    monkeypatch.setenv("NIDREG_NO_MULTI_GRID", "1")
+    ok3, c3, g3 = multi(poses[1])
+    monkeypatch.delenv("NIDREG_NO_MULTI_GRID")
+    ok4, c4, g4 = multi(poses[1])
+    assert ok3 and ok4 and c3 == c4 and np.allclose(g3, g4, rtol=1e-12, atol=1e-15)
+    # the trust gate still applies (visual_camera_calibration.cpp:152-156)
+    gated = nid.MultiNIDCost(poses[0])
+    for c in costs:
+        gated.add(c)
+    far = se3.plus(poses[0], np.array([0.3, 0.0, 0.0, 0.0, 0.0, 0.0]))
+    assert gated(far)[0] is False
+    # a group dies with any of its members; the rest keep working
+    costs[2].close()
+    rest = nid.MultiNIDCost(None)
+    for k in (0, 1, 3):
+        rest.add(costs[k])
+    okr, cr, gr = rest(poses[3])
+    assert okr and cr == solo[0](poses[3])[1] + solo[1](poses[3])[1] + solo[3](poses[3])[1]
+    for c in costs + solo:
+        c.close()
