@@ -316,7 +316,7 @@ __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_spline_hist(
 template <int MODEL, typename Rec, typename real>
 __global__ __launch_bounds__(kThreads) void k_nearest_hist(
   const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint8_t* __restrict__ img, int pitch, int W, int H, IsoParams<real> iso, CamParams<real> cam, int B,
-  int GW, int cshift, real cos_fov, u64* __restrict__ hist) {
+  int GW, int cshift, real cos_fov, u64* __restrict__ hist, const MultiEntry* __restrict__ multi, MultiDyn dyn) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u64* tile = reinterpret_cast<u64*>(smem);
   const int tile_n = GW * B;
@@ -327,6 +327,12 @@ __global__ __launch_bounds__(kThreads) void k_nearest_hist(
 
   const int tid = threadIdx.x;
   const Chunk ch = chunks[blockIdx.x];
+  if (multi) {  // one grid over several pairs (see k_spline_hist)
+    const MultiEntry& e = multi[ch.pad];
+    pts = static_cast<const Rec*>(e.pts);
+    img = e.img;
+    hist = e.hist_buf[dyn.cur[ch.pad]];
+  }
   for (int k = tid; k < tile_w; k += kThreads) tile[k] = 0;
   if (tid == 0) *s_inl = 0;
   if (tid < GW) s_colsum[tid] = 0;

@@ -196,7 +196,7 @@ static hipError_t launch_nearest_hist_rec(const PassArgs& a) {
     hipError_t e = ensure_lds(k, a.lds_hist);                                                                                                          \
     if (e != hipSuccess) return e;                                                                                                                     \
     hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(kThreads), a.lds_hist, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, iso, cam,  \
-                       a.B, a.GW, a.cshift, real(a.cos_fov), a.hist);                                                                                            \
+                       a.B, a.GW, a.cshift, real(a.cos_fov), a.hist, a.multi, a.dyn);                                                                                            \
   }
   NID_MODEL_SWITCH(NID_LAUNCH)
 #undef NID_LAUNCH

@@ -850,7 +850,7 @@ void drop_groups_of(const nidreg_handle* h) {
 }
 
 bool groupable(const nidreg_handle* a, const nidreg_handle* b) {
-  return a->device == b->device && a->model == b->model && a->mode == NIDREG_MODE_SPLINE && b->mode == NIDREG_MODE_SPLINE && a->precision == b->precision && a->bins == b->bins &&
+  return a->device == b->device && a->model == b->model && a->mode == b->mode && a->max_fov == b->max_fov && a->precision == b->precision && a->bins == b->bins &&
          a->W == b->W && a->H == b->H && a->pitch == b->pitch && a->GW == b->GW && a->cshift == b->cshift && a->wide == b->wide && a->rec64 == b->rec64 &&
          std::memcmp(a->intr, b->intr, sizeof(a->intr)) == 0 && std::memcmp(a->dist, b->dist, sizeof(a->dist)) == 0 && a->own_hist && b->own_hist && a->d_out_host && b->d_out_host &&
          !a->set && !b->set && !a->is_shard && !b->is_shard && !a->timing && !b->timing;
@@ -1006,6 +1006,58 @@ int group_eval(MultiGroup* g, const double* se3, bool want_grad, double* costs, 
     if (rc == NIDREG_FALSE) *all_ok = false;
   }
   return NIDREG_OK;
+}
+
+// the Nelder-Mead objective's sum over pairs (visual_camera_calibration.cpp:103-119) the same way: two launches in all
+int group_eval_iso(MultiGroup* g, const double* T, double* costs) {
+  const int n = int(g->hs.size());
+  nidreg_handle* h0 = g->hs[0];
+  HIP_TRY(hipSetDevice(g->device));
+  PassArgs a;
+  fill_pass_args(h0, a);
+  a.stream = g->stream;
+  a.multi = g->d_table;
+  a.dyn.want_grad = 0;
+  a.dyn.neb = h0->NEB;
+  for (int k = 0; k < 12; k++) a.iso[k] = T[k];
+  for (int i = 0; i < n; i++) {
+    nidreg_handle* h = g->hs[size_t(i)];
+    bump_seq(h);
+    HIP_TRY(begin_histogram(h, g->stream));
+    a.dyn.cur[i] = static_cast<unsigned char>(h->hist_cur);
+    a.dyn.tag[i] = h->seq;
+    h->ev_grad = false;
+  }
+  a.chunks = g->d_chunks;
+  a.nchunks = g->nchunks;
+  if (h0->precision == NIDREG_PREC_FP32) {
+    HIP_TRY(launch_nearest_hist<float>(a));
+  } else {
+    HIP_TRY(launch_nearest_hist<double>(a));
+  }
+  hipLaunchKernelGGL(
+    k_entropy, dim3(h0->NEB * n), dim3(kEntropyThreads), 0, g->stream, static_cast<const u64*>(nullptr), h0->bins, kEntropyCols, 0.0, static_cast<double*>(nullptr),
+    static_cast<u64*>(nullptr), static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<EntropyScalars*>(nullptr), static_cast<double*>(nullptr),
+    static_cast<double*>(nullptr), 0.0, static_cast<unsigned int*>(nullptr), static_cast<u64*>(nullptr), 0ll, static_cast<const MultiEntry*>(g->d_table), a.dyn);
+  HIP_TRY(hipGetLastError());
+  for (int i = 0; i < n; i++) g->hs[size_t(i)]->hist_zeroed[g->hs[size_t(i)]->hist_cur ^ 1] = true;
+  for (int i = 0; i < n; i++) {
+    const int rc = eval_finish_on(g->hs[size_t(i)], g->stream, costs + i, nullptr);
+    if (rc < 0) return rc;
+  }
+  return NIDREG_OK;
+}
+
+// handles[0..n) all distinct, compatible and on one device?
+bool can_group(nidreg_handle* const* handles, int n) {
+  if (n < 2 || n > kMaxMulti || std::getenv("NIDREG_NO_MULTI_GRID")) return false;
+  if (!groupable(handles[0], handles[0])) return false;
+  for (int i = 1; i < n; i++)
+    if (!groupable(handles[0], handles[i])) return false;
+  for (int i = 0; i < n; i++)
+    for (int j = i + 1; j < n; j++)
+      if (handles[i] == handles[j]) return false;
+  return true;
 }
 
 // ---- sharded pairs ----------------------------------------------------------------------------------------------
@@ -1427,12 +1479,8 @@ int nidreg_eval_multi(nidreg_handle* const* handles, int n, const double* init_s
   for (int i = 0; i < n; i++)
     if (!handles[i]) return fail(NIDREG_ERR_INVALID, "nidreg_eval_multi: null handle");
   // several compatible pairs on ONE GPU: a single grid per pass over all pairs (group_eval)
-  if (n >= 2 && n <= kMaxMulti && !std::getenv("NIDREG_NO_MULTI_GRID")) {
-    bool same = true;
-    for (int i = 1; i < n && same; i++) same = groupable(handles[0], handles[i]) && handles[i] != handles[0];
-    for (int i = 0; i < n && same; i++)
-      for (int j = i + 1; j < n && same; j++) same = handles[i] != handles[j];
-    if (same && groupable(handles[0], handles[0])) {
+  if (handles[0]->mode == NIDREG_MODE_SPLINE) {
+    if (can_group(handles, n)) {
       MultiGroup* g = find_or_make_group(handles, n);
       if (g) {
         double costs[kMaxMulti], grads[kMaxMulti * 7];
@@ -1481,6 +1529,20 @@ int nidreg_eval_multi(nidreg_handle* const* handles, int n, const double* init_s
 
 int nidreg_eval_iso_multi(nidreg_handle* const* handles, int n, const double* T, double* cost) {
   if (!handles || n <= 0 || !T) return fail(NIDREG_ERR_INVALID, "nidreg_eval_iso_multi: bad argument");
+  for (int i = 0; i < n; i++)
+    if (!handles[i]) return fail(NIDREG_ERR_INVALID, "nidreg_eval_iso_multi: null handle");
+  if (handles[0]->mode == NIDREG_MODE_NEAREST && can_group(handles, n)) {  // several pairs on one GPU: one grid per pass
+    MultiGroup* g = find_or_make_group(handles, n);
+    if (g) {
+      double costs[kMaxMulti];
+      const int rc = group_eval_iso(g, T, costs);
+      if (rc < 0) return rc;
+      double csum = 0.0;
+      for (int i = 0; i < n; i++) csum += costs[i];
+      if (cost) *cost = csum;
+      return NIDREG_OK;
+    }
+  }
   for (int i = 0; i < n; i++) {
     if (!handles[i]) return fail(NIDREG_ERR_INVALID, "nidreg_eval_iso_multi: null handle");
     if (handles[i]->set) continue;

@@ -170,7 +170,7 @@ int nidreg_eval_iso(nidreg_handle* h, const double* T_camera_lidar, double* cost
  * the per-pair launches). */
 int nidreg_eval_multi(nidreg_handle* const* handles, int n, const double* init_se3, const double* se3, double* cost, double* grad7);
 
-/* sum_i CostCalculatorNID_i::calculate(T) */
+/* sum_i CostCalculatorNID_i::calculate(T); compatible NEAREST handles on one GPU share one grid per pass like nidreg_eval_multi */
 int nidreg_eval_iso_multi(nidreg_handle* const* handles, int n, const double* T_camera_lidar, double* cost);
 
 /* raw histograms of the most recent evaluation (any pointer may be NULL).

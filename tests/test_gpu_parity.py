@@ -753,6 +753,20 @@ def test_multi_pair_single_grid_matches_individual_evaluations(bins, monkeypatch
         gated.add(c)
     far = se3.plus(poses[0], np.array([0.3, 0.0, 0.0, 0.0, 0.0, 0.0]))
     assert gated(far)[0] is False
+    # the Nelder-Mead objective's sum over pairs (nidreg_eval_iso_multi) through the same single-grid path
+    max_fov = oracle_lib.estimate_camera_fov(scenes[0].model, scenes[0].intrinsics, scenes[0].distortion, scenes[0].width, scenes[0].height)
+    calcs = [nid.CostCalculatorNID(proj, s.image_u8, s.points, s.intensities, nid.NIDCostParams(bins), max_fov=max_fov) for s in scenes]
+    solo_calcs = [nid.CostCalculatorNID(proj, s.image_u8, s.points, s.intensities, nid.NIDCostParams(bins), max_fov=max_fov) for s in scenes]
+    for x in poses[:3]:
+        T = se3.to_matrix(x)
+        tot = 0.0
+        for cc in solo_calcs:
+            tot += cc.calculate(T)
+        assert nid.sum_costs(calcs, T) == tot
+        for a, b in zip(calcs, solo_calcs):
+            assert np.array_equal(a.histogram_fixed()[0], b.histogram_fixed()[0])
+    for cc in calcs + solo_calcs:
+        cc.close()
     # a group dies with any of its members; the rest keep working
     costs[2].close()
     rest = nid.MultiNIDCost(None)
