@@ -161,10 +161,10 @@ __device__ __forceinline__ void grad_final_body(const double* partials, int nblo
 #endif
 constexpr int kWideThreads = NID_WIDE_THREADS;
 constexpr int kWideShift = 5;
-template <int MODEL, typename Rec, typename real, bool WIDE>
+template <int MODEL, typename Rec, typename real, bool WIDE, bool MULTI>
 __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_spline_hist(
   const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint8_t* __restrict__ img, int pitch, int W, int H, PoseParams<real> pose, CamParams<real> cam, int B,
-  int GW, int cshift, double dn_scale, u64* __restrict__ hist, const MultiEntry* __restrict__ multi, MultiDyn dyn) {
+  int GW, int cshift, double dn_scale, u64* __restrict__ hist, const MultiEntry* __restrict__ multi, typename multi_dyn_of<MULTI>::type dyn) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u64* tile = reinterpret_cast<u64*>(smem);
   if (WIDE) {  // the specialisation's tiling is fixed: compile-time constants instead of three SGPRs
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_spline_hist(
   constexpr int kT = WIDE ? kWideThreads : kThreads;
   const int tid = threadIdx.x;
   const Chunk ch = chunks[blockIdx.x];
-  if (multi) {  // one grid over several pairs: this chunk's pair brings its own records, bin image, histogram and unit
+  if constexpr (MULTI) {  // one grid over several pairs: this chunk's pair brings its own records, bin image, histogram and unit
     const MultiEntry& e = multi[ch.pad];
     pts = static_cast<const Rec*>(e.pts);
     img = e.img;
@@ -313,10 +313,10 @@ __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_spline_hist(
 // point, truncating int cast, one count per inlier.  The arithmetic order matches the reference
 // expression tree so that, compiled with -ffp-contract=off, +,-,*,/,sqrt results are bit-identical
 // to the CPU's and the integer histogram is exactly reproducible.
-template <int MODEL, typename Rec, typename real>
+template <int MODEL, typename Rec, typename real, bool MULTI>
 __global__ __launch_bounds__(kThreads) void k_nearest_hist(
   const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint8_t* __restrict__ img, int pitch, int W, int H, IsoParams<real> iso, CamParams<real> cam, int B,
-  int GW, int cshift, real cos_fov, u64* __restrict__ hist, const MultiEntry* __restrict__ multi, MultiDyn dyn) {
+  int GW, int cshift, real cos_fov, u64* __restrict__ hist, const MultiEntry* __restrict__ multi, typename multi_dyn_of<MULTI>::type dyn) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u64* tile = reinterpret_cast<u64*>(smem);
   const int tile_n = GW * B;
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(kThreads) void k_nearest_hist(
 
   const int tid = threadIdx.x;
   const Chunk ch = chunks[blockIdx.x];
-  if (multi) {  // one grid over several pairs (see k_spline_hist)
+  if constexpr (MULTI) {  // one grid over several pairs (see k_spline_hist)
     const MultiEntry& e = multi[ch.pad];
     pts = static_cast<const Rec*>(e.pts);
     img = e.img;
@@ -478,17 +478,18 @@ __device__ __forceinline__ void entropy_final_body(
 constexpr int kEntropyColsMax = 16;
 constexpr int kEntropyThreads = 1024;
 constexpr int kEntropyWaves = kEntropyThreads / 64;
+template <bool MULTI>
 __global__ __launch_bounds__(kEntropyThreads) void k_entropy(
   const u64* __restrict__ hist, int B, int CB, double inv_unit, double* part_hj, u64* row_part, double* phi_q, double* hist_image_out, double* hist_points_out,
   EntropyScalars* scal, double* out, double* out_host, double tag, unsigned int* counter, u64* __restrict__ zero_buf, long long zero_words, const MultiEntry* __restrict__ multi,
-  MultiDyn dyn) {
+  typename multi_dyn_of<MULTI>::type dyn) {
   __shared__ double s_red[3 * kEntropyWaves];
   __shared__ u64 s_row[3][256];
   __shared__ int s_flag;
   const int tid = threadIdx.x;
   int j = blockIdx.x;
   int nblocks = int(gridDim.x);
-  if (multi) {  // dyn.neb workgroups per pair, pair after pair
+  if constexpr (MULTI) {  // dyn.neb workgroups per pair, pair after pair
     const int pair = int(blockIdx.x) / dyn.neb;
     j = int(blockIdx.x) % dyn.neb;
     nblocks = dyn.neb;
@@ -662,11 +663,11 @@ __global__ void k_shard_pattern(u64* part, int words, u64 shard, u64 round) {
 #ifndef NID_GRAD_MIN_WAVES
 #define NID_GRAD_MIN_WAVES 1
 #endif
-template <int MODEL, typename Rec, typename real, bool GW1>
+template <int MODEL, typename Rec, typename real, bool GW1, bool MULTI>
 __global__ __launch_bounds__(kThreads, NID_GRAD_MIN_WAVES) void k_spline_grad(
   const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint8_t* __restrict__ img, int pitch, int W, int H, PoseParams<real> pose, CamParams<real> cam, int B,
   int GW, int cshift, double inv_unit, const u64* __restrict__ hist, const double* __restrict__ phi_q, const EntropyScalars* __restrict__ scal, double* partials, double qx,
-  double qy, double qz, double qw, double* out, double* out_host, double tag, unsigned int* counter, const MultiEntry* __restrict__ multi, MultiDyn dyn) {
+  double qy, double qz, double qw, double* out, double* out_host, double tag, unsigned int* counter, const MultiEntry* __restrict__ multi, typename multi_dyn_of<MULTI>::type dyn) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* gtile = reinterpret_cast<double*>(smem);
   const int tile_n = GW * B;
@@ -678,7 +679,7 @@ __global__ __launch_bounds__(kThreads, NID_GRAD_MIN_WAVES) void k_spline_grad(
   const int tid = threadIdx.x;
   const Chunk ch = chunks[blockIdx.x];
   unsigned int my_block = blockIdx.x, my_blocks = gridDim.x;  // this workgroup's slot among its pair's partials
-  if (multi) {
+  if constexpr (MULTI) {
     const MultiEntry& e = multi[ch.pad];
     pts = static_cast<const Rec*>(e.pts);
     img = e.img;

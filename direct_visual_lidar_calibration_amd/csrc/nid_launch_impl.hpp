@@ -65,12 +65,18 @@ static hipError_t launch_spline_hist_rec(const PassArgs& a) {
   const PoseParams<real> pose = make_pose<real>(a);
   const CamParams<real> cam = make_cam<real>(a.intr, a.dist);
 #define NID_LAUNCH_W(M, WIDE, THREADS)                                                                                                                 \
-  {                                                                                                                                                    \
-    auto k = k_spline_hist<M, Rec, real, WIDE>;                                                                                                        \
+  if (a.multi) {                                                                                                                                       \
+    auto k = k_spline_hist<M, Rec, real, WIDE, true>;                                                                                                  \
     hipError_t e = ensure_lds(k, a.lds_hist);                                                                                                          \
     if (e != hipSuccess) return e;                                                                                                                     \
     hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(THREADS), a.lds_hist, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, pose, cam, \
-                       a.B, a.GW, a.cshift, a.magic, a.hist, a.multi, a.dyn);                                                                                                   \
+                       a.B, a.GW, a.cshift, a.magic, a.hist, a.multi, a.dyn);                                                                           \
+  } else {                                                                                                                                             \
+    auto k = k_spline_hist<M, Rec, real, WIDE, false>;                                                                                                 \
+    hipError_t e = ensure_lds(k, a.lds_hist);                                                                                                          \
+    if (e != hipSuccess) return e;                                                                                                                     \
+    hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(THREADS), a.lds_hist, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, pose, cam, \
+                       a.B, a.GW, a.cshift, a.magic, a.hist, a.multi, NoMultiDyn());                                                                    \
   }
   if (a.wide) {  // B = 256, GW = 1, 32 copies, 512 threads (see k_spline_hist)
 #define NID_LAUNCH(M) NID_LAUNCH_W(M, true, kWideThreads)
@@ -90,12 +96,19 @@ static hipError_t launch_spline_grad_rec(const PassArgs& a) {
   const PoseParams<real> pose = make_pose<real>(a);
   const CamParams<real> cam = make_cam<real>(a.intr, a.dist);
 #define NID_LAUNCH_G(M, GW1)                                                                                                                           \
-  {                                                                                                                                                    \
-    auto k = k_spline_grad<M, Rec, real, GW1>;                                                                                                         \
+  if (a.multi) {                                                                                                                                       \
+    auto k = k_spline_grad<M, Rec, real, GW1, true>;                                                                                                   \
     hipError_t e = ensure_lds(k, a.lds_grad);                                                                                                          \
     if (e != hipSuccess) return e;                                                                                                                     \
     hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(kThreads), a.lds_grad, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, pose, cam, \
                        a.B, a.GW, a.cshift, a.inv_unit, a.hist, a.phi_q, a.scal, a.partials, a.q[0], a.q[1], a.q[2], a.q[3], a.out, a.out_host, a.tag, a.counter, a.multi, a.dyn); \
+  } else {                                                                                                                                             \
+    auto k = k_spline_grad<M, Rec, real, GW1, false>;                                                                                                  \
+    hipError_t e = ensure_lds(k, a.lds_grad);                                                                                                          \
+    if (e != hipSuccess) return e;                                                                                                                     \
+    hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(kThreads), a.lds_grad, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, pose, cam, \
+                       a.B, a.GW, a.cshift, a.inv_unit, a.hist, a.phi_q, a.scal, a.partials, a.q[0], a.q[1], a.q[2], a.q[3], a.out, a.out_host, a.tag, a.counter, a.multi,        \
+                       NoMultiDyn());                                                                                                                  \
   }
   if (a.GW == 1) {
 #define NID_LAUNCH(M) NID_LAUNCH_G(M, true)
@@ -115,7 +128,7 @@ static int occupancy_spline_hist_rec(const PassArgs& a) {
   int n = 0;
 #define NID_OCC_W(M, WIDE, THREADS)                                                                                                   \
   {                                                                                                                                   \
-    auto k = k_spline_hist<M, Rec, real, WIDE>;                                                                                       \
+    auto k = k_spline_hist<M, Rec, real, WIDE, false>;                                                                                \
     if (ensure_lds(k, a.lds_hist) != hipSuccess) return 0;                                                                            \
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(k), THREADS, a.lds_hist) != hipSuccess) n = 0; \
   }
@@ -153,7 +166,7 @@ static int occupancy_spline_grad_rec(const PassArgs& a) {
   int n = 0;
 #define NID_OCC_G(M, GW1)                                                                                                             \
   {                                                                                                                                   \
-    auto k = k_spline_grad<M, Rec, real, GW1>;                                                                                        \
+    auto k = k_spline_grad<M, Rec, real, GW1, false>;                                                                                 \
     if (ensure_lds(k, a.lds_grad) != hipSuccess) return 0;                                                                            \
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(k), kThreads, a.lds_grad) != hipSuccess) n = 0; \
   }
@@ -191,12 +204,18 @@ static hipError_t launch_nearest_hist_rec(const PassArgs& a) {
   const IsoParams<real> iso = make_iso<real>(a);
   const CamParams<real> cam = make_cam<real>(a.intr, a.dist);
 #define NID_LAUNCH(M)                                                                                                                                  \
-  {                                                                                                                                                    \
-    auto k = k_nearest_hist<M, Rec, real>;                                                                                                             \
+  if (a.multi) {                                                                                                                                       \
+    auto k = k_nearest_hist<M, Rec, real, true>;                                                                                                       \
     hipError_t e = ensure_lds(k, a.lds_hist);                                                                                                          \
     if (e != hipSuccess) return e;                                                                                                                     \
     hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(kThreads), a.lds_hist, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, iso, cam,  \
-                       a.B, a.GW, a.cshift, real(a.cos_fov), a.hist, a.multi, a.dyn);                                                                                            \
+                       a.B, a.GW, a.cshift, real(a.cos_fov), a.hist, a.multi, a.dyn);                                                                   \
+  } else {                                                                                                                                             \
+    auto k = k_nearest_hist<M, Rec, real, false>;                                                                                                      \
+    hipError_t e = ensure_lds(k, a.lds_hist);                                                                                                          \
+    if (e != hipSuccess) return e;                                                                                                                     \
+    hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(kThreads), a.lds_hist, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, iso, cam,  \
+                       a.B, a.GW, a.cshift, real(a.cos_fov), a.hist, a.multi, NoMultiDyn());                                                            \
   }
   NID_MODEL_SWITCH(NID_LAUNCH)
 #undef NID_LAUNCH

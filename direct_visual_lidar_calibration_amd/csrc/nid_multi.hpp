@@ -2,6 +2,8 @@
 #pragma once
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace nidreg {
 
 typedef unsigned long long u64;
@@ -32,6 +34,7 @@ struct MultiEntry {
   int chunk_base;  // first chunk of this pair in the combined gradient-pass table
   int nchunks;
 };
+struct NoMultiDyn {};  // what the single-pair instantiations take in its place (no kernel-argument bytes, no branch)
 struct MultiDyn {
   double tag[kMaxMulti];
   unsigned char cur[kMaxMulti];  // index of the histogram buffer this evaluation accumulates into
@@ -39,5 +42,10 @@ struct MultiDyn {
   int neb;  // entropy workgroups per pair
 };
 
+
+template <bool MULTI>
+struct multi_dyn_of {
+  typedef typename std::conditional<MULTI, MultiDyn, NoMultiDyn>::type type;
+};
 
 }  // namespace nidreg

@@ -307,9 +307,9 @@ int launch_hist_nearest(nidreg_handle* h, const double* T) {
 int launch_entropy(nidreg_handle* h, double tag) {
   const double inv_unit = 1.0 / fixed_unit(h);
   hipLaunchKernelGGL(
-    k_entropy, dim3(h->NEB), dim3(kEntropyThreads), 0, h->stream, hist_source(h), h->bins, kEntropyCols, inv_unit, h->d_part_hj, h->d_row_part, h->d_phi_q, h->d_hist_image,
+    k_entropy<false>, dim3(h->NEB), dim3(kEntropyThreads), 0, h->stream, hist_source(h), h->bins, kEntropyCols, inv_unit, h->d_part_hj, h->d_row_part, h->d_phi_q, h->d_hist_image,
     h->d_hist_points, h->d_scal, h->d_out, h->d_out_host, tag, h->d_counters, h->own_hist ? h->d_hist_buf[h->hist_cur ^ 1] : nullptr, h->hist_words, static_cast<const MultiEntry*>(nullptr),
-    MultiDyn());
+    NoMultiDyn());
   HIP_TRY(hipGetLastError());
   if (h->own_hist) h->hist_zeroed[h->hist_cur ^ 1] = true;  // zeroed by this k_entropy for the next evaluation
   return NIDREG_OK;
@@ -977,7 +977,7 @@ int group_eval(MultiGroup* g, const double* se3, bool want_grad, double* costs, 
   }
   // entropy: NEB workgroups per pair
   hipLaunchKernelGGL(
-    k_entropy, dim3(h0->NEB * n), dim3(kEntropyThreads), 0, g->stream, static_cast<const u64*>(nullptr), h0->bins, kEntropyCols, 0.0, static_cast<double*>(nullptr),
+    k_entropy<true>, dim3(h0->NEB * n), dim3(kEntropyThreads), 0, g->stream, static_cast<const u64*>(nullptr), h0->bins, kEntropyCols, 0.0, static_cast<double*>(nullptr),
     static_cast<u64*>(nullptr), static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<EntropyScalars*>(nullptr), static_cast<double*>(nullptr),
     static_cast<double*>(nullptr), 0.0, static_cast<unsigned int*>(nullptr), static_cast<u64*>(nullptr), 0ll, static_cast<const MultiEntry*>(g->d_table), a.dyn);
   HIP_TRY(hipGetLastError());
@@ -1036,7 +1036,7 @@ int group_eval_iso(MultiGroup* g, const double* T, double* costs) {
     HIP_TRY(launch_nearest_hist<double>(a));
   }
   hipLaunchKernelGGL(
-    k_entropy, dim3(h0->NEB * n), dim3(kEntropyThreads), 0, g->stream, static_cast<const u64*>(nullptr), h0->bins, kEntropyCols, 0.0, static_cast<double*>(nullptr),
+    k_entropy<true>, dim3(h0->NEB * n), dim3(kEntropyThreads), 0, g->stream, static_cast<const u64*>(nullptr), h0->bins, kEntropyCols, 0.0, static_cast<double*>(nullptr),
     static_cast<u64*>(nullptr), static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<EntropyScalars*>(nullptr), static_cast<double*>(nullptr),
     static_cast<double*>(nullptr), 0.0, static_cast<unsigned int*>(nullptr), static_cast<u64*>(nullptr), 0ll, static_cast<const MultiEntry*>(g->d_table), a.dyn);
   HIP_TRY(hipGetLastError());

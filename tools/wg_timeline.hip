@@ -89,7 +89,7 @@ int main(int argc, char** argv) {
   cam.dist[0] = -0.04, cam.dist[1] = 0.08, cam.dist[2] = 1e-4, cam.dist[3] = -3e-4, cam.dist[4] = -0.04;
   const int frac = 38;
   const double dn = std::ldexp(1.0, frac - 1074);
-  auto k = k_spline_hist<MODEL_PLUMB_BOB, Rec32, double, true>;
+  auto k = k_spline_hist<MODEL_PLUMB_BOB, Rec32, double, true, false>;
   const size_t lds = (size_t(B) * 8 << kWideShift) + 8 + 16;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
   hipEvent_t e0, e1;
@@ -99,7 +99,7 @@ int main(int argc, char** argv) {
   for (int it = 0; it < 6; it++) {
     CK(hipMemset(d_hist, 0, hist_words * 8));
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL(k, dim3(unsigned(chunks.size())), dim3(kWideThreads), lds, 0, d_recs, d_chunks, d_img, pitch, W, H, pose, cam, B, 1, kWideShift, dn, d_hist);
+    hipLaunchKernelGGL(k, dim3(unsigned(chunks.size())), dim3(kWideThreads), lds, 0, d_recs, d_chunks, d_img, pitch, W, H, pose, cam, B, 1, kWideShift, dn, d_hist, static_cast<const MultiEntry*>(nullptr), NoMultiDyn());
     CK(hipEventRecord(e1));
     CK(hipDeviceSynchronize());
     CK(hipEventElapsedTime(&ms, e0, e1));
