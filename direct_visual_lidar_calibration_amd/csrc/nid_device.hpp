@@ -163,9 +163,16 @@ NID_HD auto mad(const A& a, const B& b, const C& c) -> decltype(a * b + c) {
   }
 }
 
-// 1/z by v_rcp_f64 + two Newton steps (5 instructions instead of the ~12 of the IEEE division
-// sequence); |z| is a camera-frame depth in metres, never denormal / inf in range of interest, and a
-// NaN / zero z still yields a NaN / inf projection, i.e. an outlier.
+// 1/z by v_rcp_f64 + Newton steps r += r (1 - z r) (instead of the ~12 instructions of the IEEE division
+// sequence).  The hardware seed is good to <= 2^29 ulp, i.e. 2^-23 relative (measured: tools/ubench_rcp.hip), and
+// every step squares the error: kNewtonSteps = 1 leaves <= 2^-46 = 1.4e-14 relative -- 3e-11 px on a 2000-px
+// coordinate, three orders below the histogram tolerance --, 2 gives the correctly rounded quotient to ~1 ulp.
+// |z| is a camera-frame depth in metres, never denormal / inf in range of interest, and a NaN / zero z still
+// yields a NaN / inf projection, i.e. an outlier.
+#ifndef NID_NEWTON_STEPS
+#define NID_NEWTON_STEPS 1
+#endif
+constexpr int kNewtonSteps = NID_NEWTON_STEPS;
 NID_HD double rcp_seed(double z) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return __builtin_amdgcn_rcp(z);
@@ -182,16 +189,16 @@ NID_HD double rsq_seed(double z) {
 }
 NID_HD double fast_rcp(double z) {
   double r = rcp_seed(z);
-  r = fma(fma(-z, r, 1.0), r, r);
-  r = fma(fma(-z, r, 1.0), r, r);
+#pragma unroll
+  for (int k = 0; k < kNewtonSteps; k++) r = fma(fma(-z, r, 1.0), r, r);
   return r;
 }
 NID_HD float fast_rcp(float z) { return 1.0f / z; }
-// 1/sqrt(z) by v_rsq_f64 + two Newton steps r += r (1 - z r^2) / 2.  z = 0 -> NaN (inf * 0), z < 0 -> NaN.
+// 1/sqrt(z) by v_rsq_f64 + the same number of Newton steps r += r (1 - z r^2) / 2.  z = 0 -> NaN (inf * 0), z < 0 -> NaN.
 NID_HD double fast_rsq(double z) {
   double r = rsq_seed(z);
-  r = fma(0.5 * r, fma(-z * r, r, 1.0), r);
-  r = fma(0.5 * r, fma(-z * r, r, 1.0), r);
+#pragma unroll
+  for (int k = 0; k < kNewtonSteps; k++) r = fma(0.5 * r, fma(-z * r, r, 1.0), r);
   return r;
 }
 NID_HD float fast_rsq(float z) { return 1.0f / sqrtf(z); }
@@ -258,6 +265,30 @@ NID_HD void persp(const Dual3<real>& x, const Dual3<real>& y, const Dual3<real>&
   py = y / z;
 }
 
+// Radial-tangential distortion of the SPLINE kernels (plumb_bob / rational_polynomial / omnidir), factored so that the
+// value and -- in the gradient pass -- its Jacobian share every product (rc = the radial factor):
+//   dx = px i0 + p2 py^2,   i0 = rc + 2 p1 py + 3 p2 px      ( = rc px + 2 p1 px py + p2 (r2 + 2 px^2), pinhole.hpp:33-47 )
+//   dy = py i1 + p1 px^2,   i1 = rc + 2 p2 px + 3 p1 py
+//   d(dx)/d(px) = i0 + 3 p2 px + px^2 rc2,   d(dy)/d(py) = i1 + 3 p1 py + py^2 rc2,   rc2 = 2 d(rc)/d(r2)
+//   d(dx)/d(py) = d(dy)/d(px) = px py rc2 + 2 p1 px + 2 p2 py
+// -- 8 fused operations for the value (10 in the reference's association) and 9 more for the Jacobian (20 before).
+// The two functions repeat i0 / i1 with identical expressions: after inlining they are computed once.
+template <typename real>
+NID_HD void radtan_value(real p1, real p2, real px, real py, real x2, real y2, real rc, real& dx, real& dy) {
+  const real i0 = fma(real(3) * p2, px, fma(real(2) * p1, py, rc));
+  const real i1 = fma(real(3) * p1, py, fma(real(2) * p2, px, rc));
+  dx = fma(px, i0, p2 * y2);
+  dy = fma(py, i1, p1 * x2);
+}
+template <typename real>
+NID_HD void radtan_partials(real p1, real p2, real px, real py, real x2, real y2, real rc, real rc2, real& a00, real& off, real& a11) {
+  const real i0 = fma(real(3) * p2, px, fma(real(2) * p1, py, rc));
+  const real i1 = fma(real(3) * p1, py, fma(real(2) * p2, px, rc));
+  a00 = fma(x2, rc2, fma(real(3) * p2, px, i0));
+  off = fma(px * py, rc2, fma(real(2) * p1, px, (real(2) * p2) * py));
+  a11 = fma(y2, rc2, fma(real(3) * p1, py, i1));
+}
+
 // projection models (reference: include/camera/{pinhole,fisheye,omnidir,equirectangular,atan,
 // rational_polynomial}.hpp), T = real or Dual3<real>.
 template <int MODEL, typename T, typename real, bool FAST = false>
@@ -271,11 +302,16 @@ NID_HD void project(const CamParams<real>& c, const T& x, const T& y, const T& z
     const T r4 = r2 * r2;
     const T r6 = r2 * r4;
     const T rc = mad<FAST>(k3, r6, mad<FAST>(k2, r4, mad<FAST>(k1, r2, real(1))));  // 1 + k1 r2 + k2 r4 + k3 r6
-    const T t1 = real(2) * px * py;
-    const T t2 = mad<FAST>(real(2), x2, r2);                              // r2 + 2 x2
-    const T t3 = mad<FAST>(real(2), y2, r2);
-    const T dx = mad<FAST>(p2, t2, mad<FAST>(p1, t1, rc * px));           // rc px + p1 t1 + p2 t2
-    const T dy = mad<FAST>(p2, t1, mad<FAST>(p1, t3, rc * py));           // rc py + p1 t3 + p2 t1
+    T dx, dy;
+    if constexpr (FAST && std::is_floating_point<T>::value) {
+      radtan_value<T>(p1, p2, px, py, x2, y2, rc, dx, dy);
+    } else {
+      const T t1 = real(2) * px * py;
+      const T t2 = mad<FAST>(real(2), x2, r2);                            // r2 + 2 x2
+      const T t3 = mad<FAST>(real(2), y2, r2);
+      dx = mad<FAST>(p2, t2, mad<FAST>(p1, t1, rc * px));                 // rc px + p1 t1 + p2 t2
+      dy = mad<FAST>(p2, t1, mad<FAST>(p1, t3, rc * py));                 // rc py + p1 t3 + p2 t1
+    }
     u = mad<FAST>(c.intr[0], dx, c.intr[2]);
     v = mad<FAST>(c.intr[1], dy, c.intr[3]);
   } else if (MODEL == MODEL_FISHEYE) {  // fisheye.hpp:14-36 (abs(z) at :16)
@@ -330,8 +366,13 @@ NID_HD void project(const CamParams<real>& c, const T& x, const T& y, const T& z
     const T r2 = mad<FAST>(ux, ux, y2);
     const T r4 = r2 * r2;
     const T dr = mad<FAST>(k2, r4, mad<FAST>(k1, r2, real(1)));
-    const T nx = mad<FAST>(p2, mad<FAST>(real(2), x2, r2), mad<FAST>(real(2) * p1, xy, ux * dr));
-    const T ny = mad<FAST>(real(2) * p2, xy, mad<FAST>(p1, mad<FAST>(real(2), y2, r2), uy * dr));
+    T nx, ny;
+    if constexpr (FAST && std::is_floating_point<T>::value) {
+      radtan_value<T>(p1, p2, ux, uy, x2, y2, dr, nx, ny);
+    } else {
+      nx = mad<FAST>(p2, mad<FAST>(real(2), x2, r2), mad<FAST>(real(2) * p1, xy, ux * dr));
+      ny = mad<FAST>(real(2) * p2, xy, mad<FAST>(p1, mad<FAST>(real(2), y2, r2), uy * dr));
+    }
     u = mad<FAST>(c.intr[0], nx, c.intr[2]);
     v = mad<FAST>(c.intr[1], ny, c.intr[3]);
   } else if (MODEL == MODEL_EQUIRECT) {  // equirectangular.hpp:14-28, intr = [W H]
@@ -386,35 +427,40 @@ NID_HD void project(const CamParams<real>& c, const T& x, const T& y, const T& z
     const T num = mad<FAST>(k3, r6, mad<FAST>(k2, r4, mad<FAST>(k1, r2, real(1))));
     const T den = mad<FAST>(k6, r6, mad<FAST>(k5, r4, mad<FAST>(k4, r2, real(1))));
     const T rc = den > real(1e-8) ? num / den : num;
-    const T t1 = real(2) * px * py;
-    const T t2 = mad<FAST>(real(2), x2, r2);
-    const T t3 = mad<FAST>(real(2), y2, r2);
-    const T dx = mad<FAST>(p2, t2, mad<FAST>(p1, t1, rc * px));
-    const T dy = mad<FAST>(p2, t1, mad<FAST>(p1, t3, rc * py));
+    T dx, dy;
+    if constexpr (FAST && std::is_floating_point<T>::value) {
+      radtan_value<T>(p1, p2, px, py, x2, y2, rc, dx, dy);
+    } else {
+      const T t1 = real(2) * px * py;
+      const T t2 = mad<FAST>(real(2), x2, r2);
+      const T t3 = mad<FAST>(real(2), y2, r2);
+      dx = mad<FAST>(p2, t2, mad<FAST>(p1, t1, rc * px));
+      dy = mad<FAST>(p2, t1, mad<FAST>(p1, t3, rc * py));
+    }
     u = mad<FAST>(c.intr[0], dx, c.intr[2]);
     v = mad<FAST>(c.intr[1], dy, c.intr[3]);
   }
 }
 
-// Jacobian of the radial-tangential distortion shared by plumb_bob / rational_polynomial / omnidir,
-//   dx = rc px + 2 p1 px py + p2 (r2 + 2 px^2),  dy = rc py + p1 (r2 + 2 py^2) + 2 p2 px py,
-// written out by hand (it is symmetric up to fx / fy): a = diag(fx, fy) d(dx, dy)/d(px, py).
+// Jacobian of the radial-tangential distortion shared by plumb_bob / rational_polynomial / omnidir (radtan_partials
+// above; it is symmetric up to fx / fy): a = diag(fx, fy) d(dx, dy)/d(px, py).  rc and the powers of r2 are the value
+// pass's own expressions (project<..., FAST>), so that after inlining they are computed once.
 template <int MODEL, typename real>
 NID_HD void radtan_jac(const CamParams<real>& c, real px, real py, real& a00, real& a01, real& a10, real& a11) {
-  const real x2 = px * px, y2 = py * py, xy = px * py;
+  const real x2 = px * px, y2 = py * py;
   const real r2 = fma(px, px, y2);
   const real r4 = r2 * r2;
   const real p1 = c.dist[2], p2 = c.dist[3];
-  real rc, rcp;  // radial factor and d(rc)/d(r2)
+  real rc, rc2;  // radial factor and 2 d(rc)/d(r2)
   if (MODEL == MODEL_PLUMB_BOB) {
     const real k1 = c.dist[0], k2 = c.dist[1], k3 = c.dist[4];
     const real r6 = r2 * r4;
     rc = fma(k3, r6, fma(k2, r4, fma(k1, r2, real(1))));
-    rcp = fma(real(3) * k3, r4, fma(real(2) * k2, r2, k1));
+    rc2 = fma(real(6) * k3, r4, fma(real(4) * k2, r2, real(2) * k1));
   } else if (MODEL == MODEL_OMNIDIR) {
     const real k1 = c.dist[0], k2 = c.dist[1];
     rc = fma(k2, r4, fma(k1, r2, real(1)));
-    rcp = fma(real(2) * k2, r2, k1);
+    rc2 = fma(real(4) * k2, r2, real(2) * k1);
   } else {
     const real k1 = c.dist[0], k2 = c.dist[1], k3 = c.dist[4], k4 = c.dist[5], k5 = c.dist[6], k6 = c.dist[7];
     const real r6 = r2 * r4;
@@ -424,18 +470,19 @@ NID_HD void radtan_jac(const CamParams<real>& c, real px, real py, real& a00, re
     const real denp = fma(real(3) * k6, r4, fma(real(2) * k5, r2, k4));
     if (den > real(1e-8)) {
       const real id = real(1) / den;
-      rc = num * id;
-      rcp = (nump - rc * denp) * id;
+      rc = num / den;  // the value pass's own quotient (project<MODEL_RATIONAL>)
+      rc2 = real(2) * ((nump - rc * denp) * id);
     } else {
       rc = num;
-      rcp = nump;
+      rc2 = real(2) * nump;
     }
   }
-  const real off = fma(real(2) * xy, rcp, real(2) * fma(p1, px, p2 * py));  // d(dx)/d(py) = d(dy)/d(px)
-  a00 = c.intr[0] * fma(real(2) * x2, rcp, rc + real(2) * fma(p1, py, real(3) * p2 * px));
+  real b00, off, b11;
+  radtan_partials<real>(p1, p2, px, py, x2, y2, rc, rc2, b00, off, b11);
+  a00 = c.intr[0] * b00;
   a01 = c.intr[0] * off;
   a10 = c.intr[1] * off;
-  a11 = c.intr[1] * fma(real(2) * y2, rcp, rc + real(2) * fma(real(3) * p1, py, p2 * px));
+  a11 = c.intr[1] * b11;
 }
 
 // projection value + 2x3 Jacobian d(u,v)/d(x,y,z) for the gradient pass.  The value is the same
@@ -625,43 +672,44 @@ struct Chunk {  // one workgroup's slice of the bucketed cloud
 };
 
 // uniform cubic B-spline basis, the reference's 4x4 coefficient matrix / 6 (nid_cost.hpp:29-33), written in the
-// two mirror variables s and t = 1 - s (b2(s) = b1(t), b3(s) = b0(t)):
-//   b0 = t^3 / 6,  b1 = 2/3 - s^2 + s^3 / 2,  b2 = 2/3 - t^2 + t^3 / 2,  b3 = s^3 / 6
-// -- 11 operations for the four weights, 6 more for the four derivatives, every one an explicit mul / fma: all
-// translation units are built with -ffp-contract=off so that a point gets the same arithmetic whichever unrolled
-// slot / chunk / GPU processes it (the histogram is bit-identical across tilings).
-// Every weight is >= +0 by construction (products of non-negative factors; b1, b2 >= 1/6): the subnormal
-// fixed-point trick (to_fixed_dn) needs sign bit 0 on every weight.
+// two mirror variables s and t = 1 - s (b2(s) = b1(t), b3(s) = b0(t)) and WITHOUT the 1/6 -- bspline6 returns 6 b:
+//   6 b0 = t^3,  6 b1 = 4 - 6 s^2 + 3 s^3,  6 b2 = 4 - 6 t^2 + 3 t^3,  6 b3 = s^3
+// -- 9 operations for the four weights; bspline_deriv2 returns 2 db/ds = (-t^2, s (3 s - 4), t (4 - 3 t), s^2), 4 more
+// (s^2, t^2 are shared; the sign of -t^2 folds into the consuming fma).  The consumers carry the constant factors once
+// per workgroup instead of once per point: the histogram pass in the fixed-point unit of the x-weights
+// (BsplineScale), the gradient pass in its G tile (1/12 = 1/6 * 1/2 for both gx and gy).
+// Every operation is an explicit mul / fma: all translation units are built with -ffp-contract=off so that a point
+// gets the same arithmetic whichever unrolled slot / chunk / GPU processes it (the histogram is bit-identical across
+// tilings).  Every weight is >= +0 by construction (products of non-negative factors; 6 b1, 6 b2 >= 1): the
+// subnormal fixed-point trick (to_fixed_dn) needs sign bit 0 on every weight.
 template <typename real>
-NID_HD void bspline(real s, real* b) {
-  const real k16 = real(1.0 / 6.0), k46 = real(4.0 / 6.0);
+NID_HD void bspline6(real s, real* b) {
   const real t = real(1) - s;
   const real s2 = s * s, t2 = t * t;
-  b[0] = t2 * (t * k16);
-  b[1] = fma(s2, fma(real(0.5), s, real(-1)), k46);
-  b[2] = fma(t2, fma(real(0.5), t, real(-1)), k46);
-  b[3] = s2 * (s * k16);
+  b[0] = t2 * t;
+  b[1] = fma(s2, fma(real(3), s, real(-6)), real(4));
+  b[2] = fma(t2, fma(real(3), t, real(-6)), real(4));
+  b[3] = s2 * s;
 }
-// d/ds of the above: -t^2/2,  s (3/2 s - 2),  t (2 - 3/2 t),  s^2/2
 template <typename real>
-NID_HD void bspline_deriv(real s, real* d) {
+NID_HD void bspline_deriv2(real s, real* d) {
   const real t = real(1) - s;
-  d[0] = real(-0.5) * (t * t);
-  d[1] = s * fma(real(1.5), s, real(-2));
-  d[2] = t * fma(real(-1.5), t, real(2));
-  d[3] = real(0.5) * (s * s);
+  d[0] = -(t * t);
+  d[1] = s * fma(real(3), s, real(-4));
+  d[2] = t * fma(real(-3), t, real(4));
+  d[3] = s * s;
 }
 
 // The x-weights of the histogram pass come out of the polynomial ALREADY in fixed-point units: its constants are
-// pre-multiplied by the unit (one set per kernel, uniform -- or zeroed per lane for an outlier / padding slot, which
-// then adds exact zeros), so b'[a] = b[a] * unit needs no multiply of its own and bits(b'[a] * by[b]) is the integer
-// weight (to_fixed_dn).  All of this arithmetic happens in the SUBNORMAL range, i.e. on the integer grid of 2^-1074:
-// the constants are k, 3k, 4k, 6k grid steps with k = round(2^frac / 6), so they are exact, the fixed-point unit is
-// U = 6k (within 3 of 2^frac; nidreg.hip fixed_unit) and no constant carries a rounding bias into the histogram;
-// each operation rounds to the grid (<= ~1.4 units per weight instead of 0.5, unbiased, deterministic, order
-// independent).
+// pre-multiplied by U/36 (one set per kernel, uniform -- or zeroed per lane for an outlier / padding slot, which
+// then adds exact zeros), so b'[a] = 6 bx[a] * U/36 needs no multiply of its own and bits(b'[a] * 6 by[b]) is the
+// integer weight bx by U (to_fixed_dn).  All of this arithmetic happens in the SUBNORMAL range, i.e. on the integer
+// grid of 2^-1074: the constants are k, 3k, 4k, 6k grid steps with k = round(2^frac / 36), so they are exact, the
+// fixed-point unit is U = 36k (within 18 of 2^frac; nidreg.hip fixed_unit) and no constant carries a rounding bias
+// into the histogram; each operation rounds to the grid (a few grid steps per weight after the multiplication by
+// 6 by <= 4 -- unbiased, deterministic, order independent; bound checked by tests/cxx/test_device_math.cpp).
 struct BsplineScale {
-  double k16, k46, k05, k1;  // U/6, 4U/6, U/2, U as subnormal doubles (k, 4k, 3k, 6k grid steps)
+  double k16, k46, k05, k1;  // k, 4k, 3k, 6k grid steps as subnormal doubles, k = U/36
 };
 NID_HD BsplineScale bspline_scale(double k16) {
   BsplineScale K;
@@ -688,11 +736,9 @@ NID_HD void transform_fma(const PoseParams<real>& pose, real x, real y, real z, 
   cz = fma(pose.R[8], z, fma(pose.R[7], y, fma(pose.R[6], x, pose.t[2])));
 }
 
-// weight -> unsigned fixed point with `frac` fractional bits in ONE instruction: the x-weights are
-// pre-multiplied by dn = 2^(frac - 1074), so the product bxs * by is a SUBNORMAL double whose bit
-// pattern (exponent field 0) IS the integer round-to-nearest(bx' * by * 2^frac) -- no magic add, no mask.
-// (bx' = bx rounded to 2^-frac by the pre-scaling: total quantisation <= 0.5 max(by) + 0.5 = 0.84 units of
-// 2^-frac instead of 0.5 -- checked on the host by tests/cxx/test_device_math.cpp; still deterministic and order independent.)  gfx950 handles fp64 denormals at full rate.
+// weight -> unsigned fixed point in ONE instruction: the x-weights are born in grid steps of 2^-1074 (bspline_scaled),
+// so the product bxs * by6 is a SUBNORMAL double whose bit pattern (exponent field 0) IS the integer
+// round-to-nearest(bx by U) -- no magic add, no mask.  gfx950 handles fp64 denormals at full rate.
 NID_HD u64 to_fixed_dn(double bx_scaled, double by) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return u64(__double_as_longlong(bx_scaled * by));
@@ -721,11 +767,21 @@ NID_HD uint32_t align_bytes(uint32_t hi, uint32_t lo, uint32_t sh) {
   return uint32_t(((uint64_t(hi) << 32) | lo) >> (8u * (sh & 3u)));
 #endif
 }
+// 24-bit multiply (v_mul_u32_u24, full rate; v_mul_lo_u32 is quarter rate): strip index < 2^24, strip bytes < 2^24
+NID_HD uint32_t mul24(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul24(a, b);
+#else
+  return a * b;
+#endif
+}
 NID_HD void load_patch(const uint8_t* __restrict__ img, int pitch, int kx, int ky, uint32_t* cols) {
   const uint32_t stride = uint32_t(pitch) * 4u;
-  const uint32_t base = (uint32_t(ky) >> 2) * stride + uint32_t(kx) * 4u;
+  const uint32_t base = mul24(uint32_t(ky) >> 2, stride) + uint32_t(kx) * 4u;
+  // both loads: uniform base (SGPR pair) + the same 32-bit lane offset -- no 64-bit address arithmetic per point
+  const uint8_t* __restrict__ img_next = img + stride;
   const StripQuad s0 = *reinterpret_cast<const StripQuad*>(img + base);
-  const StripQuad s1 = *reinterpret_cast<const StripQuad*>(img + base + stride);
+  const StripQuad s1 = *reinterpret_cast<const StripQuad*>(img_next + base);
   const uint32_t sh = uint32_t(ky) & 3u;
 #pragma unroll
   for (int a = 0; a < 4; a++) cols[a] = align_bytes(s1.c[a], s0.c[a], sh);

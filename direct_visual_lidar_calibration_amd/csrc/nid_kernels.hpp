@@ -218,7 +218,7 @@ __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_spline_hist(
     // |.|: a projected coordinate of exactly -0.0 passes `>= 0`, and a -0.0 fraction would put a sign bit into a
     // weight (to_fixed_dn reads bit patterns); the modifier folds into the consuming instructions
     bspline_scaled(double(m_abs(m_fract(uc))), K, bxs);
-    bspline<real>(m_abs(m_fract(vc)), by);
+    bspline6<real>(m_abs(m_fract(vc)), by);
     u64* col = tile + ((((bin - col0) * uint32_t(B)) << cshift) + lane_copy);
     // padded bin image: tap (a,b) of knot (kx,ky) is padded pixel (kx + a, ky + b) (edge-replicated,
     // which is the reference's clamp of knots_x / knots_y, nid_cost.hpp:70-73)
@@ -703,7 +703,8 @@ __global__ __launch_bounds__(kThreads, NID_GRAD_MIN_WAVES) void k_spline_grad(
     const int n = ncols * B;
     for (int k = tid; k < n; k += kThreads) {
       const double p = double(src[k]) * scale;
-      const double gval = coefA * (log(p + 1e-6) + p / (p + 1e-6)) + coefB * phi_q[k % B];
+      // times 1/12: the tap loop below works with 6 b and 2 db/ds (bspline6 / bspline_deriv2)
+      const double gval = (coefA * (log(p + 1e-6) + p / (p + 1e-6)) + coefB * phi_q[k % B]) * (1.0 / 12.0);
       for (uint32_t j = 0; j <= cmask; j++) gtile[(uint32_t(k) << cshift) + ((j + uint32_t(k)) & cmask)] = gval;
     }
   }
@@ -740,14 +741,28 @@ __global__ __launch_bounds__(kThreads, NID_GRAD_MIN_WAVES) void k_spline_grad(
         const int kx = int(uu), ky = int(vv);  // uu, vv >= 0 here: truncation is the floor knot
         const real sx = m_abs(m_fract(uu)), sy = m_abs(m_fract(vv));  // |.| as in the histogram pass: identical fractions
         real bx[4], by[4], dbx[4], dby[4];
-        bspline<real>(sx, bx);
-        bspline<real>(sy, by);
-        bspline_deriv<real>(sx, dbx);
-        bspline_deriv<real>(sy, dby);
+        bspline6<real>(sx, bx);
+        bspline6<real>(sy, by);
+        bspline_deriv2<real>(sx, dbx);
+        bspline_deriv2<real>(sy, dby);
         typedef __attribute__((address_space(3))) const double lds_f64_t;
         const double* gcol = gtile + ((((bins_[k] - col0) * uint32_t(B)) << cshift) + lane_copy);
         uint32_t cols[4];
+#ifdef NID_EXP_GRAD_NOGATHER
+        cols[0] = uint32_t(kx) * 0x01010101u, cols[1] = cols[0] + 0x01010101u, cols[2] = uint32_t(ky) * 0x01010101u, cols[3] = cols[2] + 0x01010101u;
+#else
         load_patch(img, pitch, kx, ky, cols);
+#endif
+#ifdef NID_EXP_GRAD_PAD
+        {  // experiment: NID_EXP_GRAD_PAD independent fp64 fmas per point (marginal cost of a VALU instruction)
+          double pa = double(sx), pb = double(sy), pc = double(uu), pd = double(vv);
+#pragma unroll
+          for (int q = 0; q < NID_EXP_GRAD_PAD / 4; q++) {
+            pa = fma(pa, 0.999, 0.25), pb = fma(pb, 0.999, 0.25), pc = fma(pc, 0.999, 0.25), pd = fma(pd, 0.999, 0.25);
+          }
+          acc[11] += (pa + pb + pc + pd) * 1e-300;
+        }
+#endif
         real gx = real(0), gy = real(0);
 #pragma unroll
         for (int b = 0; b < 4; b++) {

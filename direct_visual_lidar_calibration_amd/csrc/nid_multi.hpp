@@ -18,7 +18,7 @@ struct MultiEntry {
   const void* pts;
   const uint8_t* img;
   u64* hist_buf[2];
-  double k16;       // U/6 as a subnormal double (bspline_scale)
+  double k16;       // U/36 as a subnormal double (bspline_scale)
   double inv_unit;  // 1 / U
   double* part_hj;
   u64* row_part;

@@ -185,12 +185,15 @@ void free_handle(nidreg_handle* h) {
 
 inline u64* hist_source(const nidreg_handle* h) { return h->d_hist_full ? h->d_hist_full : h->d_hist; }
 
-// The fixed-point unit of the SPLINE histogram: U = 6 round(2^frac / 6) -- within 3 of 2^frac, and a multiple of 6
-// so that the B-spline constants U/6, U/2, 4U/6, U are integers (nid_device.hpp bspline_scale).  NEAREST counts: 1.
+// The fixed-point unit of the SPLINE histogram: U = 36 round(2^frac / 36) -- within 18 of 2^frac, and a multiple of 36
+// so that the constants U/36, 3U/36, 4U/36, 6U/36 of the x-weight polynomial are integers (nid_device.hpp
+// bspline_scale; both axes produce 6 b).  NEAREST counts: 1.
 inline double fixed_unit(const nidreg_handle* h) {
   if (h->mode == NIDREG_MODE_NEAREST || h->frac_bits == 0) return 1.0;
-  return 6.0 * std::rint(std::ldexp(1.0, h->frac_bits) / 6.0);
+  return 36.0 * std::rint(std::ldexp(1.0, h->frac_bits) / 36.0);
 }
+// U/36 grid steps of 2^-1074 as a subnormal double (the kernels' dn_scale / MultiEntry::k16)
+inline double fixed_unit_k(const nidreg_handle* h) { return std::ldexp(fixed_unit(h) / 36.0, -1074); }
 
 void fill_pass_args(const nidreg_handle* h, PassArgs& a) {
   std::memset(&a, 0, sizeof(a));
@@ -209,7 +212,7 @@ void fill_pass_args(const nidreg_handle* h, PassArgs& a) {
   a.wide = h->wide;
   std::memcpy(a.intr, h->intr, sizeof(a.intr));
   std::memcpy(a.dist, h->dist, sizeof(a.dist));
-  a.magic = std::ldexp(fixed_unit(h) / 6.0, -1074);  // U/6 grid steps as a subnormal double: the x-weight constants (bspline_scale)
+  a.magic = fixed_unit_k(h);  // the x-weight constants (bspline_scale)
   a.inv_unit = 1.0 / fixed_unit(h);
   a.cos_fov = std::cos(h->max_fov);
   a.hist = h->d_hist;
@@ -903,7 +906,7 @@ MultiGroup* find_or_make_group(nidreg_handle* const* handles, int n) {
     e.img = h->d_img;
     e.hist_buf[0] = h->d_hist_buf[0];
     e.hist_buf[1] = h->d_hist_buf[1];
-    e.k16 = std::ldexp(fixed_unit(h) / 6.0, -1074);
+    e.k16 = fixed_unit_k(h);
     e.inv_unit = 1.0 / fixed_unit(h);
     e.part_hj = h->d_part_hj;
     e.row_part = h->d_row_part;

@@ -1,6 +1,6 @@
 // Host emulation of the DEVICE ALGORITHM of one NIDCost evaluation (k_spline_hist -> k_entropy -> k_spline_grad in
 // csrc/nid_kernels.hpp), built from the very same scalar helpers the kernels call -- transform_fma, project<.., FAST>,
-// project_jac, bspline, bspline_deriv, load_patch on the strip-tiled padded bin image, to_fixed_dn -- which
+// project_jac, bspline6, bspline_deriv2, load_patch on the strip-tiled padded bin image, to_fixed_dn -- which
 // csrc/nid_device.hpp compiles for the host too.  The per-point bodies below MIRROR the kernels' (they are not shared
 // code: the kernels interleave them with LDS / wave plumbing); what this pins on a machine without a GPU is the
 // arithmetic design: 64-bit fixed-point accumulation (order independent, so the serial loop here and the GPU's
@@ -39,8 +39,8 @@ static int run(const CamParams<double>& cam, int W, int H, int B, const std::vec
   int nbits = 1;
   while ((int64_t(1) << nbits) <= N) nbits++;
   const int frac = std::min(40, 62 - nbits);
-  const double unit = 6.0 * std::rint(std::ldexp(1.0, frac) / 6.0), inv_unit = 1.0 / unit;  // nidreg.hip fixed_unit
-  const BsplineScale KS = bspline_scale(std::ldexp(unit / 6.0, -1074));
+  const double unit = 36.0 * std::rint(std::ldexp(1.0, frac) / 36.0), inv_unit = 1.0 / unit;  // nidreg.hip fixed_unit
+  const BsplineScale KS = bspline_scale(std::ldexp(unit / 36.0, -1074));
 
   // ---- pass A (k_spline_hist body): fixed-point joint histogram [bin_points][bin_image], inlier count
   std::vector<u64> hist(size_t(B) * B, 0);
@@ -58,7 +58,7 @@ static int run(const CamParams<double>& cam, int W, int H, int B, const std::vec
     inliers++;
     double bxs[4], by[4];
     bspline_scaled(std::fabs(m_fract(u)), KS, bxs);  // x-weights straight in fixed-point units (k_spline_hist's taps)
-    bspline<double>(std::fabs(m_fract(v)), by);
+    bspline6<double>(std::fabs(m_fract(v)), by);
     uint32_t cols[4];
     load_patch(img.data(), pitch, int(u), int(v), cols);
     for (int b = 0; b < 4; b++)
@@ -97,7 +97,7 @@ static int run(const CamParams<double>& cam, int W, int H, int B, const std::vec
   for (int c = 0; c < B; c++)
     for (int r = 0; r < B; r++) {
       const double p = double(hist[size_t(c) * B + r]) * scale;
-      G[size_t(c) * B + r] = coefA * (std::log(p + 1e-6) + p / (p + 1e-6)) + coefB * phi_q[size_t(r)];
+      G[size_t(c) * B + r] = (coefA * (std::log(p + 1e-6) + p / (p + 1e-6)) + coefB * phi_q[size_t(r)]) * (1.0 / 12.0);  // the taps use 6 b and 2 db/ds
     }
   double acc[12] = {0};
   for (int64_t i = 0; i < N; i++) {
@@ -110,10 +110,10 @@ static int run(const CamParams<double>& cam, int W, int H, int B, const std::vec
     if (!in) continue;
     const double sx = std::fabs(m_fract(uu)), sy = std::fabs(m_fract(vv));
     double bx[4], by[4], dbx[4], dby[4];
-    bspline<double>(sx, bx);
-    bspline<double>(sy, by);
-    bspline_deriv<double>(sx, dbx);
-    bspline_deriv<double>(sy, dby);
+    bspline6<double>(sx, bx);
+    bspline6<double>(sy, by);
+    bspline_deriv2<double>(sx, dbx);
+    bspline_deriv2<double>(sy, dby);
     uint32_t cols[4];
     load_patch(img.data(), pitch, int(uu), int(vv), cols);
     const double* gcol = G.data() + size_t(bin_pts[size_t(i)]) * B;
