@@ -145,6 +145,25 @@ __device__ __forceinline__ void grad_final_body(const double* partials, int nblo
   }
 }
 
+// Issue priority by progress (s_setprio).  The SIMD's arbiter serves the oldest ready wave first, so of the workgroups
+// co-resident on a CU the first-dispatched one runs at its solo speed and the last one is left to finish alone, at
+// single-wave issue rate (PMC: on average only 2.4 of the 4 resident waves per SIMD are alive over the gradient kernel).
+// A wave that has done less of its chunk gets the higher priority: the waves of a SIMD stay within a quarter of a chunk
+// of each other.  Measured on cfg 2 (profiles/r02g_variants_prio.txt): histogram pass 57.5 -> 53.0 us, gradient pass
+// 84.0 -> 78.6 us; the thresholds hardly matter (quarters, 1/2-3/4-7/8, per point instead of per batch: all within 1 us); a
+// purely phase-based toggle (either direction) or a rotating priority gain half as much -- what helps is that co-resident
+// waves stop being served strictly by age.
+// `done` / `total` are uniform: scalar compares only.  -DNID_NO_PRIO builds the kernels without it (A/B runs).
+__device__ __forceinline__ void set_progress_priority(uint32_t done, uint32_t total) {
+#ifndef NID_NO_PRIO
+  const uint32_t quarter = total >> 2;
+  if (done < quarter) __builtin_amdgcn_s_setprio(3);
+  else if (done < 2u * quarter) __builtin_amdgcn_s_setprio(2);
+  else if (done < 3u * quarter) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+#endif
+}
+
 // ------------------------------------------------------------------------------------------
 // pass A (SPLINE): joint histogram with bicubic B-spline soft assignment.
 // LDS: tile[GW*B << cshift] u64 (this workgroup's GW histogram columns, 2^cshift copies) + 1 u32 inlier counter.
@@ -244,6 +263,7 @@ __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_spline_hist(
   // geometry of all of them comes first, then -- wave-uniform choice -- the tap code with uniform or per-lane
   // constants.  Both are branch-free per point, so the scheduler interleaves the kUnroll independent points.
   for (uint32_t base = 0; base < ch.count; base += kT * kUnroll) {
+    set_progress_priority(base, ch.count);
     real xs[kUnroll], ys[kUnroll], zs[kUnroll];
     uint32_t bins_[kUnroll];
 #pragma unroll
@@ -345,6 +365,7 @@ __global__ __launch_bounds__(kThreads) void k_nearest_hist(
   // kUnroll records per thread are fetched before any of them is processed: one 16-B load per wave
   // in flight is latency bound (measured 1.45 TB/s); four keep ~64 KB per CU outstanding
   for (uint32_t base = 0; base < ch.count; base += kThreads * kUnroll) {
+    set_progress_priority(base, ch.count);
     real xs[kUnroll], ys[kUnroll], zs[kUnroll];
     uint32_t bins_[kUnroll];
 #pragma unroll
@@ -719,6 +740,7 @@ __global__ __launch_bounds__(kThreads, NID_GRAD_MIN_WAVES) void k_spline_grad(
 
   const char* rec_base = reinterpret_cast<const char*>(pts + ch.start);  // uniform base + 32-bit byte offsets per lane
   for (uint32_t base = 0; base < ch.count; base += kThreads * kUnroll) {
+    set_progress_priority(base, ch.count);
     real xs[kUnroll], ys[kUnroll], zs[kUnroll];
     uint32_t bins_[kUnroll];
 #pragma unroll
