@@ -364,8 +364,9 @@ __global__ __launch_bounds__(kThreads) void k_nearest_hist(
 
   // kUnroll records per thread are fetched before any of them is processed: one 16-B load per wave
   // in flight is latency bound (measured 1.45 TB/s); four keep ~64 KB per CU outstanding
+  // (no progress priority here: this pass is a third of the spline passes' arithmetic per point and lives on memory-level
+  // parallelism -- with it the kernel was 10 % slower on cfg 2, 67.2 -> 73.8 us, profiles/r02g_kernel_gaps.txt)
   for (uint32_t base = 0; base < ch.count; base += kThreads * kUnroll) {
-    set_progress_priority(base, ch.count);
     real xs[kUnroll], ys[kUnroll], zs[kUnroll];
     uint32_t bins_[kUnroll];
 #pragma unroll
