@@ -57,11 +57,50 @@ __device__ __forceinline__ void stamp_begin() {}
 __device__ __forceinline__ void stamp_end() {}
 #endif
 
+// Sum over the 64 lanes of a wave, returned to every lane.  Cross-lane moves by DPP (v_mov_b32_dpp on the two halves of
+// the double: row_shr 1 / 2 / 4 / 8 with out-of-row sources reading 0, then row_bcast:15 into rows 1 and 3 and row_bcast:31
+// into rows 2 and 3) instead of __shfl_down's ds_bpermute pairs: 18 VALU instructions and two v_readlane per sum, no LDS
+// crossbar traffic -- the gradient kernel's epilogue runs twelve of these in every wave (144 ds_bpermute before, all of a
+// CU's workgroups at about the same time).  Fixed association: lane 63 ends up with ((rows 0 + 1) + (rows 2 + 3)).
+#ifndef NID_WAVE_SUM_SHFL
+template <int CTRL, int ROW_MASK, bool BOUND_ZERO>
+__device__ __forceinline__ double dpp_move(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, BOUND_ZERO);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, BOUND_ZERO);
+  return __hiloint2double(hi, lo);  // lanes the control does not write (disabled rows, out-of-row sources) get +0.0
+}
+__device__ __forceinline__ double wave_sum(double v) {
+  v += dpp_move<0x111, 0xf, true>(v);   // row_shr:1
+  v += dpp_move<0x112, 0xf, true>(v);   // row_shr:2
+  v += dpp_move<0x114, 0xf, true>(v);   // row_shr:4
+  v += dpp_move<0x118, 0xf, true>(v);   // row_shr:8 -> lane 15 of every row holds its row's sum
+  v += dpp_move<0x142, 0xa, false>(v);  // row_bcast:15 -> rows 1 and 3
+  v += dpp_move<0x143, 0xc, false>(v);  // row_bcast:31 -> rows 2 and 3: lane 63 holds the total
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+// the same for a 32-bit count (the inlier counters of the histogram passes)
+__device__ __forceinline__ unsigned int wave_sum(unsigned int v) {
+  v += unsigned(__builtin_amdgcn_update_dpp(0, int(v), 0x111, 0xf, 0xf, true));
+  v += unsigned(__builtin_amdgcn_update_dpp(0, int(v), 0x112, 0xf, 0xf, true));
+  v += unsigned(__builtin_amdgcn_update_dpp(0, int(v), 0x114, 0xf, 0xf, true));
+  v += unsigned(__builtin_amdgcn_update_dpp(0, int(v), 0x118, 0xf, 0xf, true));
+  v += unsigned(__builtin_amdgcn_update_dpp(0, int(v), 0x142, 0xa, 0xf, false));
+  v += unsigned(__builtin_amdgcn_update_dpp(0, int(v), 0x143, 0xc, 0xf, false));
+  return unsigned(__builtin_amdgcn_readlane(int(v), 63));
+}
+#else
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
   return v;
 }
+__device__ __forceinline__ unsigned int wave_sum(unsigned int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+#endif
 
 // ------------------------------------------------------------------------------------------
 // "last workgroup finalises" hand-off (cdna_hip_programming.md Guideline 16): every workgroup's
@@ -306,9 +345,7 @@ __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_spline_hist(
   }
 
   // inlier count: wave-reduce, one LDS add per wave
-  unsigned int winl = inl;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) winl += __shfl_down(winl, off, 64);
+  const unsigned int winl = wave_sum(inl);
   if ((tid & 63) == 0 && winl) atomicAdd(s_inl, winl);
   __syncthreads();
 
@@ -400,9 +437,7 @@ __global__ __launch_bounds__(kThreads) void k_nearest_hist(
     }
   }
 
-  unsigned int winl = inl;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) winl += __shfl_down(winl, off, 64);
+  const unsigned int winl = wave_sum(inl);
   if ((tid & 63) == 0 && winl) atomicAdd(s_inl, winl);
   __syncthreads();
 
@@ -562,10 +597,9 @@ __global__ __launch_bounds__(kEntropyThreads) void k_entropy(
   if ((tid & 63) == 0) s_red[tid >> 6] = acc;
   __syncthreads();
   if (q == 0 && r < B) row_part[size_t(j) * size_t(B) + r] = row + s_row[0][r] + s_row[1][r] + s_row[2][r];
-  if (tid == 0) {
-    double t = 0.0;
-    for (int w = 0; w < kEntropyWaves; w++) t += s_red[w];
-    part_hj[j] = t;
+  if (tid < 64) {  // the sixteen wave partials, summed by one wave instead of a serial loop of LDS reads
+    const double t = wave_sum(tid < kEntropyWaves ? s_red[tid] : 0.0);
+    if (tid == 0) part_hj[j] = t;
   }
   const u64* col_sum = hist + size_t(B) * size_t(B) + kTailWords;  // accumulated by the histogram kernels' flush
   // the tail's loops stride by kThreads = 256 over B <= 256 items: threads beyond 255 find nothing to do but take part
