@@ -1,0 +1,71 @@
+"""Register / scratch budget of the hot kernels, read from the gfx950 assembly hipcc emits for the double-precision
+translation unit (no GPU needed: hipcc cross-compiles).  The two spline passes of the headline configuration run 16 waves
+per CU -- two 8-wave histogram workgroups, four 4-wave gradient workgroups -- which needs <= 128 VGPRs per lane and no
+scratch; the chunk tables are sized from that occupancy (nidreg.hip), so a change that pushes a kernel over the limit
+silently costs a quarter of the latency hiding ("forcing 4 waves/EU ... +55 %")."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "direct_visual_lidar_calibration_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.fixture(scope="module")
+def kernel_metadata(tmp_path_factory):
+    if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("asm") / "nid_kernels_f64.s"
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S", "--cuda-device-only", os.path.join(CSRC, "nid_kernels_f64.hip"), "-o", str(out)]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=900)
+    text = out.read_text()
+    meta = {}
+    # the amdhsa.kernels YAML block: one entry per kernel with .name, .vgpr_count, .sgpr_spill_count, .vgpr_spill_count, .private_segment_fixed_size
+    for block in text.split("  - .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block)
+        if not name:
+            continue
+        get = lambda key: int(re.search(rf"\.{key}:\s+(\d+)", block).group(1))  # noqa: E731
+        meta[name.group(1)] = {"vgpr": get("vgpr_count"), "vgpr_spill": get("vgpr_spill_count"), "scratch": get("private_segment_fixed_size"), "lds_static": get("group_segment_fixed_size")}
+    assert meta, "no kernel metadata found in the assembly"
+    return text, meta
+
+
+def _find(meta, fragment):
+    hits = [k for k in meta if fragment in k]
+    assert hits, fragment
+    return {k: meta[k] for k in hits}
+
+
+def test_headline_spline_kernels_fit_four_waves_per_simd(kernel_metadata):
+    _, meta = kernel_metadata
+    # k_spline_hist<plumb_bob, Rec32, double, WIDE, single / multi pair>, k_spline_grad<plumb_bob, Rec32, double, GW1, ...>
+    for fragment in ("k_spline_histILi0ENS_5Rec32EdLb1E", "k_spline_gradILi0ENS_5Rec32EdLb1E"):
+        for name, m in _find(meta, fragment).items():
+            assert m["vgpr"] <= 128, (name, m)
+            assert m["vgpr_spill"] == 0 and m["scratch"] == 0, (name, m)
+
+
+def test_no_spline_kernel_uses_scratch(kernel_metadata):
+    _, meta = kernel_metadata
+    for name, m in {**_find(meta, "k_spline_hist"), **_find(meta, "k_spline_grad")}.items():
+        assert m["vgpr_spill"] == 0 and m["scratch"] == 0, (name, m)
+        assert m["vgpr"] <= 168, (name, m)  # at least three waves per SIMD for every camera model
+
+
+def test_wave_sums_use_dpp_not_the_lds_crossbar(kernel_metadata):
+    text, _ = kernel_metadata
+    start = text.index("k_spline_gradILi0ENS_5Rec32EdLb1ELb0E")
+    body = text[start:text.index(".Lfunc_end", start)]
+    assert "row_bcast:31" in body and "ds_bpermute" not in body
+
+
+def test_wide_histogram_kernel_keeps_the_tile_at_lds_address_zero(kernel_metadata):
+    # the WIDE kernel builds a tap's LDS address with one v_perm_b32 on the assumption that its dynamic tile starts at 0
+    _, meta = kernel_metadata
+    for name, m in _find(meta, "k_spline_histILi0ENS_5Rec32EdLb1E").items():
+        assert m["lds_static"] == 0, (name, m)
