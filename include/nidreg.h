@@ -28,6 +28,9 @@
  *   NIDREG_DEVICES           splits the cloud over the listed GPUs and nidreg_eval* exchange the histogram
  *                            GPU to GPU themselves (the reference's calibrate is a single process,
  *                            src/calibrate.cpp:117-120)
+ *   NIDREG_COMBINE=1         (environment, experimental) concurrent nidreg_eval callers on one device at one pose -- the
+ *                            reference's OpenMP loop over the pairs of a MultiNIDCost, visual_camera_calibration.cpp:161 --
+ *                            are collected and evaluated as ONE grid like nidreg_eval_multi's
  *   nidreg_destroy           ~NIDCost / ~CostCalculatorNID
  *
  * Conventions
