@@ -54,7 +54,9 @@ int main(int argc, char** argv) {
       se3[4] = 0.01 * std::sin(0.05 * r), se3[5] = 0.01 * std::cos(0.07 * r), se3[6] = 0.005;
     };
     double t_omp = 0, t_multi = 0;
-    for (int phase = 0; phase < 2; phase++) {
+    const bool multi_first = std::getenv("OMP_PAIRS_MULTI_FIRST") != nullptr;  // order of the two measurements
+    for (int ph = 0; ph < 2; ph++) {
+      const int phase = multi_first ? 1 - ph : ph;
       for (int r = -10; r < reps; r++) {
         double se3[7];
         pose(r, se3);
