@@ -69,6 +69,26 @@ def _matching_pmc(n_points, width, height, bins, precision, build=None):
     return best
 
 
+def _matching_kernel_stats(n_points, width, height, bins, precision, build):
+    """The newest committed rocprofv3 kernel-stats summary (profiles/*_kernel_stats.json, tools/kernel_stats_json.py) of this
+    workload measured on THIS kernel build: average kernel durations without HIP-event markers inside them."""
+    import glob
+
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kernel_stats.json"))):
+        try:
+            with open(path) as f:
+                t = json.load(f)
+        except (OSError, ValueError):
+            continue
+        w = t.get("workload", {})
+        if (w.get("points"), w.get("width"), w.get("height"), w.get("bins"), w.get("precision")) != (n_points, width, height, bins, precision) or t.get("kernel_build") != build:
+            continue
+        best = t
+        best["_file"] = os.path.basename(path)
+    return best
+
+
 def pmc_traffic(kernel, n_points, width, height, bins, precision, build=None):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_traffic.json:
     FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of the same workload, FETCH_SIZE doubled
@@ -256,7 +276,7 @@ def main():
     inner = cost.inner if hasattr(cost, "inner") else cost
     plain = not hasattr(cost, "inner")
 
-    # ---- per-kernel timing with HIP events on the handle's own stream (extra, untimed evaluations)
+    # ---- kernel timing with HIP events on the handle's own stream (extra, untimed evaluations)
     roof = None
     python_call_rate = None
     if rank == 0 and plain:
@@ -264,9 +284,17 @@ def main():
         for k in range(args.steps):
             cost(poses[k % len(poses)])
         python_call_rate = args.steps / (time.perf_counter() - t1)
+        reps = max(10, min(args.steps, 30))
+        # (a) the evaluation as it runs in the timed region -- ONE kernel (k_fused) when the handle has the GPU to itself --
+        # between two events; (b) the three-kernel route (k_spline_hist / k_entropy / k_spline_grad) with an event after
+        # every kernel (it is what runs when several callers share the GPU, and the per-pass breakdown)
+        inner.set_timing(2)
+        whole = []
+        for k in range(reps):
+            inner(poses[k % len(poses)])
+            whole.append(inner.timing_ms()["total"])
         inner.set_timing(True)
         acc = {}
-        reps = max(10, min(args.steps, 30))
         for k in range(reps):
             inner(poses[k % len(poses)])
             tm = inner.timing_ms()
@@ -274,34 +302,43 @@ def main():
                 acc.setdefault(key, []).append(v)
         inner.set_timing(False)
         kt = {key: float(np.mean(v)) for key, v in acc.items()}
+        whole_ms = float(np.mean(whole))
         n_local = pts.shape[0]
-        dom = "k_spline_hist" if kt["hist"] >= kt["grad"] else "k_spline_grad"
-        dom_ms = max(kt["hist"], kt["grad"])
-        # algorithmic bytes ONE launch of the dominant kernel moves: 16 B/point + the 8-bit image +
-        # the B x B 64-bit histogram tile traffic (written by pass A, read by pass B)
-        launch_bytes = 16 * n_local + scene.width * scene.height + 8 * args.bins * args.bins
-        kernel_achieved = launch_bytes / (dom_ms * 1e-3) / 1e9
+        fused = bool(inner.info().get("fused"))
+        build = _lib.kernel_source_hash()
+        kstats = _matching_kernel_stats(n_local, scene.width, scene.height, args.bins, args.precision, build)
+        ks = {k_: v["avg_ns"] * 1e-6 for k_, v in kstats["kernels"].items()} if kstats else {}
         eval_bytes = algorithmic_bytes(n_local, scene.width, scene.height, args.bins)
         eval_achieved = eval_bytes / (ms_per_step * 1e-3) / 1e9
-        build = _lib.kernel_source_hash()
+        if fused:
+            # one launch = one evaluation: it moves the evaluation's algorithmic bytes (the point records are streamed twice
+            # inside it -- histogram phase and gradient phase -- and counted once)
+            dom, dom_ms_events, launch_bytes = "k_fused", whole_ms, eval_bytes
+        else:
+            dom = "k_spline_hist" if kt["hist"] >= kt["grad"] else "k_spline_grad"
+            dom_ms_events = max(kt["hist"], kt["grad"])
+            # algorithmic bytes ONE launch of a streaming pass moves: 16 B/point + the 8-bit image + the B x B 64-bit histogram
+            launch_bytes = 16 * n_local + scene.width * scene.height + 8 * args.bins * args.bins
+        dom_ms = ks.get(dom, dom_ms_events)  # rocprof average of this kernel build when committed, else the event-timed one
+        kernel_achieved = launch_bytes / (dom_ms * 1e-3) / 1e9
         pmc = _matching_pmc(n_local, scene.width, scene.height, args.bins, args.precision, build)
-        traffic = pmc["kernels"][dom]["hbm_bytes_corrected"] if pmc and dom in pmc.get("kernels", {}) else None
-        # VALU issue roof: wave-instructions the two streaming kernels issue (PMC SQ_INSTS_VALU of this kernel build)
+        pk = pmc.get("kernels", {}) if pmc else {}
+        traffic = pk[dom]["hbm_bytes_corrected"] if dom in pk else None
+        route = ["k_fused"] if fused else ["k_spline_hist", "k_entropy", "k_spline_grad"]
+        eval_traffic = sum(pk[k_]["hbm_bytes_corrected"] for k_ in route) if all(k_ in pk for k_ in route) else None
+        # VALU issue roof: wave-instructions the evaluation's kernels issue (PMC SQ_INSTS_VALU of this kernel build)
         # at one quad-cycle (4 clocks) each on 1024 SIMDs -- the roof that actually binds
         valu = None
-        if pmc:
-            ks = pmc["kernels"]
-            insts = {k_: ks[k_].get("valu_insts") for k_ in ("k_spline_hist", "k_spline_grad") if k_ in ks}
-            if all(v for v in insts.values()) and len(insts) == 2:
-                floor_us = {k_: v * 4.0 / NUM_SIMDS / (SHADER_GHZ * 1e3) for k_, v in insts.items()}
-                valu = {
-                    "insts_per_point": {k_: round(v * 64.0 / n_local, 1) for k_, v in insts.items()},
-                    "issue_floor_us": {k_: round(v, 2) for k_, v in floor_us.items()},
-                    "frac": {"k_spline_hist": round(floor_us["k_spline_hist"] / (kt["hist"] * 1e3), 3), "k_spline_grad": round(floor_us["k_spline_grad"] / (kt["grad"] * 1e3), 3),
-                             "evaluation": round(sum(floor_us.values()) / (ms_per_step * 1e3), 3)},
-                    "model": "SQ_INSTS_VALU x 4 clk / (1024 SIMDs x 2.4 GHz)",
-                    "source": pmc["_file"],
-                }
+        insts = {k_: pk[k_].get("valu_insts") for k_ in route if k_ in pk and k_ != "k_entropy"}
+        if insts and all(v for v in insts.values()):
+            floor_us = {k_: v * 4.0 / NUM_SIMDS / (SHADER_GHZ * 1e3) for k_, v in insts.items()}
+            valu = {
+                "insts_per_point": {k_: round(v * 64.0 / n_local, 1) for k_, v in insts.items()},
+                "issue_floor_us": {k_: round(v, 2) for k_, v in floor_us.items()},
+                "frac_of_evaluation": round(sum(floor_us.values()) / (ms_per_step * 1e3), 3),
+                "model": "SQ_INSTS_VALU x 4 clk / (1024 SIMDs x 2.4 GHz)",
+                "source": pmc["_file"],
+            }
         roof = {
             "bound": "hbm",
             "binding_roof": "valu-issue (fp64)",
@@ -310,13 +347,18 @@ def main():
             "unit": "GB/s",
             "frac": round(eval_achieved / HBM_PEAK_GBS, 4),  # algorithmic bytes of ONE evaluation / time of one evaluation
             "traffic": traffic,
+            "eval_traffic": eval_traffic,  # counter bytes of every kernel of one evaluation (the records are streamed twice)
             "traffic_source": pmc["_file"] if pmc else f"no PMC summary of kernel build {build} committed",
             "kernel": dom,
             "kernel_achieved": round(kernel_achieved, 1),
             "kernel_frac": round(kernel_achieved / HBM_PEAK_GBS, 4),
+            "kernel_ms_used": round(dom_ms, 4),
+            "kernel_ms_source": (kstats["_file"] + " (rocprofv3 --kernel-trace --stats average, same kernel build)") if dom in ks else "HIP events around the launch, this run (a few us of event markers included)",
             "launch_bytes": launch_bytes,
             "eval_bytes": eval_bytes,
-            "kernel_ms": {k_: round(v, 4) for k_, v in kt.items()},
+            "route": "one fused kernel per evaluation" if fused else "three kernels per evaluation",
+            "kernel_ms_events": {"whole_evaluation": round(whole_ms, 4), "three_kernel_route": {k_: round(v, 4) for k_, v in kt.items()}},
+            "kernel_ms_rocprof": {k_: round(v, 4) for k_, v in ks.items()} or None,
             "kernel_build": build,
             "valu": valu,
         }
@@ -365,14 +407,17 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib  # test infrastructure, used here only as the timed CPU baseline
 
-        ns = min(args.cpu_sample, pts.shape[0])
-        # every (N/ns)-th sweep-ordered point keeps the spatial / intensity distribution
+        # >= 3 cost+Jacobian evaluations of the WHOLE cloud on one core when that takes <= ~25 s (10M points: ~4.8 s each);
+        # larger clouds: every (N/ns)-th sweep-ordered point (keeps the spatial / intensity distribution), scaled, with the
+        # per-point cost at a second sample size next to it
+        full = pts.shape[0] <= 12_000_000 and args.cpu_sample > 0
+        ns = pts.shape[0] if full else min(args.cpu_sample, pts.shape[0])
         sel = np.linspace(0, pts.shape[0] - 1, ns).astype(np.int64)
-        sp, si = np.ascontiguousarray(pts[sel]), np.ascontiguousarray(ints[sel])
+        sp, si = (pts, ints) if full else (np.ascontiguousarray(pts[sel]), np.ascontiguousarray(ints[sel]))
         img64 = scene.image_f64
         ts = []
         t_budget = time.time()
-        for k in range(8):  # ~10 s of CPU work on the default sample (2M points x 8 evaluations), capped at 25 s
+        for k in range(3 if full else 8):
             t1 = time.perf_counter()
             oracle_lib.nid_cost(scene.model, scene.intrinsics, scene.distortion, img64, sp, si, args.bins, poses[k % len(poses)], want_grad=True, threads=1)
             ts.append(time.perf_counter() - t1)
@@ -380,15 +425,31 @@ def main():
                 break
         t_med = float(np.median(ts))
         scale = pts.shape[0] / ns
+        try:
+            with open("/proc/cpuinfo") as f:
+                cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
+        except OSError:
+            cpu_model = "unknown"
         cpu = {
             "value": round(1.0 / (t_med * scale), 6),
             "unit": "evals/s",
             "cores": 1,
             "kind": "port",
-            "sample": f"{len(ts)} cost+Jacobian evals of the oracle (Jet<7>, serial loop like the reference) on {ns} of the {pts.shape[0]} points, "
-            f"median {t_med:.3f} s, scaled linearly x{scale:.1f}; host cpus={os.cpu_count()}",
+            "sample": (f"{len(ts)} cost+Jacobian evals of the oracle (Jet<7>, serial loop like the reference) on all {ns} points, median {t_med:.3f} s" if full else
+                       f"{len(ts)} cost+Jacobian evals of the oracle (Jet<7>, serial loop like the reference) on {ns} of the {pts.shape[0]} points, median {t_med:.3f} s, scaled linearly x{scale:.1f}")
+            + f"; host cpus={os.cpu_count()}, {cpu_model}",
             "ns_per_point": round(1e9 * t_med / ns, 1),
+            "cpu_model": cpu_model,
         }
+        if full:  # the per-point cost at a fifth of the cloud, so that the (non-)linearity is on record
+            sel5 = np.linspace(0, pts.shape[0] - 1, pts.shape[0] // 5).astype(np.int64)
+            s5p, s5i = np.ascontiguousarray(pts[sel5]), np.ascontiguousarray(ints[sel5])
+            t1 = time.perf_counter()
+            oracle_lib.nid_cost(scene.model, scene.intrinsics, scene.distortion, img64, s5p, s5i, args.bins, poses[0], want_grad=True, threads=1)
+            cpu["ns_per_point_at_one_fifth"] = round(1e9 * (time.perf_counter() - t1) / sel5.shape[0], 1)
+            sel = np.linspace(0, pts.shape[0] - 1, min(2_000_000, pts.shape[0])).astype(np.int64)
+            sp, si = np.ascontiguousarray(pts[sel]), np.ascontiguousarray(ints[sel])  # the informational legs below stay on a 2M sample
+            scale = pts.shape[0] / sp.shape[0]
         # informational: the reference's OWN source (include/vlcal/costs/nid_cost.hpp, Jet<7>) when
         # oracle/_ref/libref.so travelled with the snapshot -- compiled against the stand-in Eigen of
         # oracle/shim/, so its speed is not real Eigen's; the headline CPU figure stays the port
@@ -408,9 +469,12 @@ def main():
         # generous variant: same arithmetic, OpenMP over points on all host cores
         nthr = oracle_lib.num_threads()
         if nthr > 1:
-            t1 = time.perf_counter()
-            oracle_lib.nid_cost(scene.model, scene.intrinsics, scene.distortion, img64, sp, si, args.bins, poses[0], want_grad=True, threads=nthr)
-            tg = time.perf_counter() - t1
+            tgs = []
+            for k in range(3):  # the first run warms the thread pool and the per-thread histograms
+                t1 = time.perf_counter()
+                oracle_lib.nid_cost(scene.model, scene.intrinsics, scene.distortion, img64, sp, si, args.bins, poses[k], want_grad=True, threads=nthr)
+                tgs.append(time.perf_counter() - t1)
+            tg = min(tgs[1:])
             cpu["generous_value"] = round(1.0 / (tg * scale), 6)
             cpu["generous_cores"] = nthr
 

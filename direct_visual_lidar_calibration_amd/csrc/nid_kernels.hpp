@@ -102,6 +102,41 @@ __device__ __forceinline__ unsigned int wave_sum(unsigned int v) {
 }
 #endif
 
+// the same for a 64-bit integer (fixed-point entropy partials, row sums): integer sums are order independent
+#ifndef NID_WAVE_SUM_SHFL
+template <int CTRL, int ROW_MASK, bool BOUND_ZERO>
+__device__ __forceinline__ long long dpp_move_i64(long long v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, int(uint32_t(u64(v))), CTRL, ROW_MASK, 0xf, BOUND_ZERO);
+  const int hi = __builtin_amdgcn_update_dpp(0, int(uint32_t(u64(v) >> 32)), CTRL, ROW_MASK, 0xf, BOUND_ZERO);
+  return (long long)((u64(uint32_t(hi)) << 32) | u64(uint32_t(lo)));
+}
+__device__ __forceinline__ long long wave_sum(long long v) {
+  v += dpp_move_i64<0x111, 0xf, true>(v);
+  v += dpp_move_i64<0x112, 0xf, true>(v);
+  v += dpp_move_i64<0x114, 0xf, true>(v);
+  v += dpp_move_i64<0x118, 0xf, true>(v);
+  v += dpp_move_i64<0x142, 0xa, false>(v);
+  v += dpp_move_i64<0x143, 0xc, false>(v);
+  const int lo = __builtin_amdgcn_readlane(int(uint32_t(u64(v))), 63), hi = __builtin_amdgcn_readlane(int(uint32_t(u64(v) >> 32)), 63);
+  return (long long)((u64(uint32_t(hi)) << 32) | u64(uint32_t(lo)));
+}
+#else
+__device__ __forceinline__ long long wave_sum(long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+#endif
+
+// Entropy terms t = p log(p + 1e-6) (|t| < 0.37; sum over a distribution <= log(bins^2) < 12) are accumulated as 64-bit
+// FIXED POINT with 50 fractional bits: t + 6 lies in [4, 8), where a double's ulp is 2^-50, so bits(t + 6) - bits(6) is
+// round(t 2^50) -- one fp64 add and one 64-bit integer subtract.  Integer sums do not depend on their order, so every
+// decomposition of the entropy work (k_entropy's column blocks, k_fused's row segments, the shards of a pair spread over
+// several GPUs, a multi-pair group) gives the SAME three entropies bit for bit, hence the same NID.  Quantisation: <= 2^-51
+// per term, 65 536 terms -> |dH| < 3e-11 worst case (1e-13 typical) on H ~ 5-10, far inside the 1e-10 parity bar.
+__device__ __forceinline__ long long ent_fixed(double t) { return __double_as_longlong(t + 6.0) - __double_as_longlong(6.0); }
+__device__ __forceinline__ double ent_value(long long k) { return double(k) * 0x1p-50; }
+
 // ------------------------------------------------------------------------------------------
 // "last workgroup finalises" hand-off (cdna_hip_programming.md Guideline 16): every workgroup's
 // stores -> __syncthreads -> one lane: agent-scope release, drained vmcnt, relaxed agent-scope ticket.
@@ -135,12 +170,13 @@ __device__ __forceinline__ bool last_workgroup_arrives(unsigned int* counter, un
 //   grad_v = 2 w A + 2 (M v + M^T v - 2 tr(M) v);  grad_t = gt.
 // out[1..7] = d NID / d [qx qy qz qw tx ty tz]; out_host (nullable) = host-mapped mirror.
 // s_red: kWaves * 12 doubles of LDS.
+template <int kT>
 __device__ __forceinline__ void grad_final_body(const double* partials, int nblocks, double qx, double qy, double qz, double qw, double* out, double* out_host, double tag, double* s_red) {
   const int tid = threadIdx.x;
   double acc[12];
 #pragma unroll
   for (int k = 0; k < 12; k++) acc[k] = 0.0;
-  for (int b = tid; b < nblocks; b += kThreads) {
+  for (int b = tid; b < nblocks; b += kT) {
 #pragma unroll
     for (int k = 0; k < 12; k++) acc[k] += partials[size_t(k) * nblocks + b];
   }
@@ -155,7 +191,7 @@ __device__ __forceinline__ void grad_final_body(const double* partials, int nblo
     double M[12];
     for (int k = 0; k < 12; k++) {
       double t = 0.0;
-      for (int w = 0; w < kWaves; w++) t += s_red[w * 12 + k];
+      for (int w = 0; w < kT / 64; w++) t += s_red[w * 12 + k];
       M[k] = t;
     }
     const double A0 = M[7] - M[5], A1 = M[2] - M[6], A2 = M[3] - M[1];
@@ -177,6 +213,12 @@ __device__ __forceinline__ void grad_final_body(const double* partials, int nblo
     for (int k = 0; k < 7; k++) out[1 + k] = g[k];
     if (out_host) {
       for (int k = 0; k < 7; k++) out_host[1 + k] = g[k];
+      // cost / status / inlier count: k_entropy has mirrored them already; in the one-launch evaluation (k_fused) another
+      // workgroup of THIS kernel wrote them to `out` (agent scope, before its ticket) and this is their way to the host --
+      // every host-visible word of an evaluation is then written by one thread, in order, ahead of the tag
+      out_host[0] = __hip_atomic_load(&out[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      out_host[8] = __hip_atomic_load(&out[8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      out_host[9] = __hip_atomic_load(&out[9], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __threadfence_system();
       // completion tag of this evaluation: the host polls this word instead of synchronising the stream
       __hip_atomic_store(&out_host[15], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -193,8 +235,12 @@ __device__ __forceinline__ void grad_final_body(const double* partials, int nblo
 // purely phase-based toggle (either direction) or a rotating priority gain half as much -- what helps is that co-resident
 // waves stop being served strictly by age.
 // `done` / `total` are uniform: scalar compares only.  -DNID_NO_PRIO builds the kernels without it (A/B runs).
-__device__ __forceinline__ void set_progress_priority(uint32_t done, uint32_t total) {
+// `on` (uniform, a kernel argument): the host sets it when the evaluation is the only one in flight on its device -- with
+// several callers' kernels sharing the GPU (the reference's OpenMP loop over pairs, visual_camera_calibration.cpp:161) the
+// rule made the last kernels 5-16 % slower (profiles/r02h_multi_pair_threads.txt), so they run without it.
+__device__ __forceinline__ void set_progress_priority(bool on, uint32_t done, uint32_t total) {
 #ifndef NID_NO_PRIO
+  if (!on) return;
   const uint32_t quarter = total >> 2;
   if (done < quarter) __builtin_amdgcn_s_setprio(3);
   else if (done < 2u * quarter) __builtin_amdgcn_s_setprio(2);
@@ -219,11 +265,12 @@ __device__ __forceinline__ void set_progress_priority(uint32_t done, uint32_t to
 #endif
 constexpr int kWideThreads = NID_WIDE_THREADS;
 constexpr int kWideShift = 5;
-template <int MODEL, typename Rec, typename real, bool WIDE, bool MULTI>
-__global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_spline_hist(
-  const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint8_t* __restrict__ img, int pitch, int W, int H, PoseParams<real> pose, CamParams<real> cam, int B,
-  int GW, int cshift, double dn_scale, u64* __restrict__ hist, const MultiEntry* __restrict__ multi, typename multi_dyn_of<MULTI>::type dyn) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// The pass as a device function: k_spline_hist runs it as a kernel of its own, k_fused (nid_fused.hpp) as the first phase
+// of the one-launch evaluation.  `smem` = the workgroup's dynamic LDS (tile at its start); kT = threads per workgroup.
+template <int MODEL, typename Rec, typename real, bool WIDE, int kT>
+__device__ __forceinline__ void spline_hist_body(
+  const Rec* __restrict__ pts, const Chunk ch, const uint8_t* __restrict__ img, int pitch, int W, int H, const PoseParams<real>& pose, const CamParams<real>& cam, int B, int GW,
+  int cshift, double dn_scale, u64* __restrict__ hist, unsigned char* smem, bool prio) {
   u64* tile = reinterpret_cast<u64*>(smem);
   if (WIDE) {  // the specialisation's tiling is fixed: compile-time constants instead of three SGPRs
     B = 256;
@@ -240,16 +287,7 @@ __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_spline_hist(
   u64* s_colsum = tile + tile_w;  // GW words: this workgroup's contribution to each column sum
   unsigned int* s_inl = reinterpret_cast<unsigned int*>(s_colsum + GW);
 
-  constexpr int kT = WIDE ? kWideThreads : kThreads;
   const int tid = threadIdx.x;
-  const Chunk ch = chunks[blockIdx.x];
-  if constexpr (MULTI) {  // one grid over several pairs: this chunk's pair brings its own records, bin image, histogram and unit
-    const MultiEntry& e = multi[ch.pad];
-    pts = static_cast<const Rec*>(e.pts);
-    img = e.img;
-    hist = e.hist_buf[dyn.cur[ch.pad]];
-    dn_scale = e.k16;
-  }
   stamp_begin();
   for (int k = tid; k < tile_w; k += kT) tile[k] = 0;
   if (tid == 0) *s_inl = 0;
@@ -302,7 +340,7 @@ __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_spline_hist(
   // geometry of all of them comes first, then -- wave-uniform choice -- the tap code with uniform or per-lane
   // constants.  Both are branch-free per point, so the scheduler interleaves the kUnroll independent points.
   for (uint32_t base = 0; base < ch.count; base += kT * kUnroll) {
-    set_progress_priority(base, ch.count);
+    set_progress_priority(prio, base, ch.count);
     real xs[kUnroll], ys[kUnroll], zs[kUnroll];
     uint32_t bins_[kUnroll];
 #pragma unroll
@@ -363,6 +401,26 @@ __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_spline_hist(
   if (tid < GW && s_colsum[tid]) atomicAdd(&hist[size_t(B) * size_t(B) + kTailWords + col0 + uint32_t(tid)], s_colsum[tid]);
   if (tid == 0 && *s_inl) atomicAdd(&hist[size_t(B) * size_t(B) + kTailInliers], u64(*s_inl));
   stamp_end();
+}
+
+// LDS bytes spline_hist_body uses (nidreg.hip sizes lds_hist the same way)
+__host__ __device__ __forceinline__ size_t spline_hist_lds_bytes(int B, int GW, int cshift) { return (size_t(GW) * size_t(B) * 8 << cshift) + size_t(GW) * 8 + 16; }
+
+template <int MODEL, typename Rec, typename real, bool WIDE, bool MULTI>
+__global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_spline_hist(
+  const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint8_t* __restrict__ img, int pitch, int W, int H, PoseParams<real> pose, CamParams<real> cam, int B,
+  int GW, int cshift, double dn_scale, u64* __restrict__ hist, int prio, const MultiEntry* __restrict__ multi, typename multi_dyn_of<MULTI>::type dyn) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int kT = WIDE ? kWideThreads : kThreads;
+  const Chunk ch = chunks[blockIdx.x];
+  if constexpr (MULTI) {  // one grid over several pairs: this chunk's pair brings its own records, bin image, histogram and unit
+    const MultiEntry& e = multi[ch.pad];
+    pts = static_cast<const Rec*>(e.pts);
+    img = e.img;
+    hist = e.hist_buf[dyn.cur[ch.pad]];
+    dn_scale = e.k16;
+  }
+  spline_hist_body<MODEL, Rec, real, WIDE, kT>(pts, ch, img, pitch, W, H, pose, cam, B, GW, cshift, dn_scale, hist, smem, prio != 0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -455,6 +513,27 @@ __global__ __launch_bounds__(kThreads) void k_nearest_hist(
   if (tid == 0 && *s_inl) atomicAdd(&hist[size_t(B) * size_t(B) + kTailInliers], u64(*s_inl));
 }
 
+// nid_cost.hpp:86-104 from the three entropies (fixed point, see ent_fixed) and the inlier count: NID = (Hj - MI) / Hj,
+// MI = Hi + Hp - Hj; the gradient pass's coefficients; status 1 when the NID is not finite (sum == 0 -> 0/0 in the
+// reference, nid_cost.hpp:98-102: the functor returns false).  One definition for every path, so that they agree bit for bit.
+__device__ __forceinline__ EntropyScalars entropy_scalars(long long hi_k, long long hp_k, long long hj_k, double S) {
+  const bool empty = !(S > 0.0);  // the reference divides the histograms by sum = 0: every entropy is NaN
+  const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+  const double Hi = empty ? qnan : -ent_value(hi_k), Hp = empty ? qnan : -ent_value(hp_k), Hj = empty ? qnan : -ent_value(hj_k);
+  const double MI = Hi + Hp - Hj;
+  const double nid = (Hj - MI) / Hj;
+  EntropyScalars e;
+  e.nid = nid;
+  e.S = S;
+  e.coefA = -(Hi + Hp) / (Hj * Hj * S);
+  e.coefB = 1.0 / (Hj * S);
+  e.Hi = Hi;
+  e.Hp = Hp;
+  e.Hj = Hj;
+  e.status = isfinite(nid) ? 0.0 : 1.0;
+  return e;
+}
+
 #ifdef NID_COMMON_KERNELS
 // ------------------------------------------------------------------------------------------
 // entropy: one workgroup per block of CB histogram columns, the last one to finish runs the tail (independent of the point
@@ -465,24 +544,24 @@ __global__ __launch_bounds__(kThreads) void k_nearest_hist(
 // (partition of unity: the 16 weights of an inlier sum to 1), S = inlier count.
 // nid_cost.hpp:86-104: NID = (Hj - MI) / Hj, MI = Hi + Hp - Hj.
 __device__ __forceinline__ void entropy_final_body(
-  const u64* hist, int B, int NG, double inv_unit, const double* part_hj, const u64* row_part, const u64* col_sum, double* phi_q, double* hist_image_out, double* hist_points_out,
-  EntropyScalars* scal, double* out, double* out_host, double tag, double* s_red) {
+  const u64* hist, int B, int NG, double inv_unit, const long long* part_hj, const u64* row_part, const u64* col_sum, double* phi_q, double* hist_image_out, double* hist_points_out,
+  EntropyScalars* scal, double* out, double* out_host, double tag, long long* s_red) {
   const int tid = threadIdx.x;
   const double S = double(hist[size_t(B) * size_t(B) + kTailInliers]);
-  double hi_acc = 0.0, hp_acc = 0.0, hj_acc = 0.0;
+  long long hi_acc = 0, hp_acc = 0, hj_acc = 0;
   for (int r = tid; r < B; r += kThreads) {
     u64 t = 0;
     for (int g = 0; g < NG; g++) t += row_part[size_t(g) * size_t(B) + r];
     const double raw = double(t) * inv_unit;  // raw (un-normalised) hist_image[r]
     const double q = raw / S;
-    hi_acc += q * log(q + 1e-6);
+    hi_acc += ent_fixed(q * log(q + 1e-6));
     phi_q[r] = log(q + 1e-6) + q / (q + 1e-6);
     hist_image_out[r] = raw;
   }
   for (int c = tid; c < B; c += kThreads) {
     const double cnt = rint(double(col_sum[c]) * inv_unit);  // exact inlier count of column c
     const double p = cnt / S;
-    hp_acc += p * log(p + 1e-6);
+    hp_acc += ent_fixed(p * log(p + 1e-6));
     hist_points_out[c] = cnt;
   }
   for (int g = tid; g < NG; g += kThreads) hj_acc += part_hj[g];
@@ -496,30 +575,19 @@ __device__ __forceinline__ void entropy_final_body(
   }
   __syncthreads();
   if (tid == 0) {
-    double a = 0.0, b = 0.0, c = 0.0;
-    for (int w = 0; w < kWaves; w++) {
+    long long a = 0, b = 0, c = 0;
+    for (int w = 0; w < int(blockDim.x) / 64; w++) {
       a += s_red[w * 3 + 0];
       b += s_red[w * 3 + 1];
       c += s_red[w * 3 + 2];
     }
-    const double Hi = -a, Hp = -b, Hj = -c;
-    const double MI = Hi + Hp - Hj;
-    const double nid = (Hj - MI) / Hj;
-    EntropyScalars e;
-    e.nid = nid;
-    e.S = S;
-    e.coefA = -(Hi + Hp) / (Hj * Hj * S);
-    e.coefB = 1.0 / (Hj * S);
-    e.Hi = Hi;
-    e.Hp = Hp;
-    e.Hj = Hj;
-    e.status = isfinite(nid) ? 0.0 : 1.0;
+    const EntropyScalars e = entropy_scalars(a, b, c, S);
     *scal = e;
-    out[0] = nid;
+    out[0] = e.nid;
     out[8] = e.status;
     out[9] = S;
     if (out_host) {
-      out_host[0] = nid;
+      out_host[0] = e.nid;
       out_host[8] = e.status;
       out_host[9] = S;
       __threadfence_system();
@@ -537,10 +605,10 @@ constexpr int kEntropyThreads = 1024;
 constexpr int kEntropyWaves = kEntropyThreads / 64;
 template <bool MULTI>
 __global__ __launch_bounds__(kEntropyThreads) void k_entropy(
-  const u64* __restrict__ hist, int B, int CB, double inv_unit, double* part_hj, u64* row_part, double* phi_q, double* hist_image_out, double* hist_points_out,
+  const u64* __restrict__ hist, int B, int CB, double inv_unit, long long* part_hj, u64* row_part, double* phi_q, double* hist_image_out, double* hist_points_out,
   EntropyScalars* scal, double* out, double* out_host, double tag, unsigned int* counter, u64* __restrict__ zero_buf, long long zero_words, const MultiEntry* __restrict__ multi,
   typename multi_dyn_of<MULTI>::type dyn) {
-  __shared__ double s_red[3 * kEntropyWaves];
+  __shared__ long long s_red[3 * kEntropyWaves];
   __shared__ u64 s_row[3][256];
   __shared__ int s_flag;
   const int tid = threadIdx.x;
@@ -582,13 +650,13 @@ __global__ __launch_bounds__(kEntropyThreads) void k_entropy(
   }
   const double S = double(hist[size_t(B) * size_t(B) + kTailInliers]);
   const double scale = inv_unit / S;  // fixed-point word -> probability
-  double acc = 0.0;
+  long long acc = 0;
   u64 row = 0;
 #pragma unroll
   for (int c = 0; c < kPer; c++) {
     if (v[c]) {
       const double p = double(v[c]) * scale;
-      acc += p * log(p + 1e-6);
+      acc += ent_fixed(p * log(p + 1e-6));
     }
     row += v[c];
   }
@@ -598,7 +666,7 @@ __global__ __launch_bounds__(kEntropyThreads) void k_entropy(
   __syncthreads();
   if (q == 0 && r < B) row_part[size_t(j) * size_t(B) + r] = row + s_row[0][r] + s_row[1][r] + s_row[2][r];
   if (tid < 64) {  // the sixteen wave partials, summed by one wave instead of a serial loop of LDS reads
-    const double t = wave_sum(tid < kEntropyWaves ? s_red[tid] : 0.0);
+    const long long t = wave_sum(tid < kEntropyWaves ? s_red[tid] : 0ll);
     if (tid == 0) part_hj[j] = t;
   }
   const u64* col_sum = hist + size_t(B) * size_t(B) + kTailWords;  // accumulated by the histogram kernels' flush
@@ -719,11 +787,138 @@ __global__ void k_shard_pattern(u64* part, int words, u64 shard, u64 round) {
 #ifndef NID_GRAD_MIN_WAVES
 #define NID_GRAD_MIN_WAVES 1
 #endif
+// how a tap finds its G value in LDS
+enum { TAP_COPIES = 0,   // gtile[(cell << cshift) + lane copy]: lane-private copies like the histogram tile (several columns per workgroup)
+       TAP_SINGLE = 1,   // one column, ONE copy at LDS address 0: byte address = bin_image << 3 (one SDWA shift)
+       TAP_WIDE = 2 };   // one column, 32 copies at LDS address 0: byte address (bin_image << 8) | (copy << 3) from ONE v_perm_b32
+                         // (k_fused, 512-thread workgroups: the WIDE histogram tile's layout, conflict-free reads)
+
+// The point loop of the pass as a device function (k_spline_grad; third phase of k_fused): accumulates M += gp p^T, gt += gp
+// over the chunk into acc[12].
+template <int MODEL, typename Rec, typename real, int TAP, int kT>
+__device__ __forceinline__ void spline_grad_loop(
+  const Rec* __restrict__ pts, const Chunk ch, const uint8_t* __restrict__ img, int pitch, int W, int H, const PoseParams<real>& pose, const CamParams<real>& cam, int B, int GW,
+  int cshift, const double* gtile, double* acc, bool prio) {
+  const int tid = threadIdx.x;
+  if (TAP == TAP_SINGLE) cshift = 0;
+  if (TAP == TAP_WIDE) cshift = kWideShift;
+  const uint32_t cmask = (1u << cshift) - 1u;
+  const real fW = real(W), fH = real(H);
+  const uint32_t col0 = ch.group * uint32_t(GW);
+  const uint32_t lane_copy = uint32_t(tid) & cmask;
+
+  const char* rec_base = reinterpret_cast<const char*>(pts + ch.start);  // uniform base + 32-bit byte offsets per lane
+  for (uint32_t base = 0; base < ch.count; base += kT * kUnroll) {
+    set_progress_priority(prio, base, ch.count);
+    real xs[kUnroll], ys[kUnroll], zs[kUnroll];
+    uint32_t bins_[kUnroll];
+#pragma unroll
+    for (int k = 0; k < kUnroll; k++) {
+      const uint32_t ii = min(base + uint32_t(k) * kT + tid, ch.count - 1u);
+      load_rec<real>(reinterpret_cast<const Rec*>(rec_base + size_t(ii * uint32_t(sizeof(Rec)))), xs[k], ys[k], zs[k], bins_[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < kUnroll; k++) {
+      // (a branch-free body like k_spline_hist's was measured 15 % slower here: 173 VGPRs, 2 waves/SIMD)
+      if (base + uint32_t(k) * kT + tid >= ch.count) break;
+      const real x = xs[k], y = ys[k], z = zs[k];
+      real cx, cy, cz;
+      transform_fma<real>(pose, x, y, z, cx, cy, cz);
+      real uu, vv;
+      ProjCtx<real> ctx;
+      project_fwd<MODEL, real>(cam, cx, cy, cz, uu, vv, ctx);
+      const bool in = (uu >= real(0)) && (uu < fW) && (vv >= real(0)) && (vv < fH);
+      if (in) {
+        const int kx = int(uu), ky = int(vv);  // uu, vv >= 0 here: truncation is the floor knot
+        const real sx = m_abs(m_fract(uu)), sy = m_abs(m_fract(vv));  // |.| as in the histogram pass: identical fractions
+        real bx[4], by[4], dbx[4], dby[4];
+        bspline6<real>(sx, bx);
+        bspline6<real>(sy, by);
+        bspline_deriv2<real>(sx, dbx);
+        bspline_deriv2<real>(sy, dby);
+        typedef __attribute__((address_space(3))) const double lds_f64_t;
+        const double* gcol = gtile + ((((bins_[k] - col0) * uint32_t(B)) << cshift) + lane_copy);
+        uint32_t cols[4];
+#ifdef NID_EXP_GRAD_NOGATHER
+        cols[0] = uint32_t(kx) * 0x01010101u, cols[1] = cols[0] + 0x01010101u, cols[2] = uint32_t(ky) * 0x01010101u, cols[3] = cols[2] + 0x01010101u;
+#else
+        load_patch(img, pitch, kx, ky, cols);
+#endif
+#ifdef NID_EXP_GRAD_PAD
+        {  // experiment: NID_EXP_GRAD_PAD independent fp64 fmas per point (marginal cost of a VALU instruction)
+          double pa = double(sx), pb = double(sy), pc = double(uu), pd = double(vv);
+#pragma unroll
+          for (int q = 0; q < NID_EXP_GRAD_PAD / 4; q++) {
+            pa = fma(pa, 0.999, 0.25), pb = fma(pb, 0.999, 0.25), pc = fma(pc, 0.999, 0.25), pd = fma(pd, 0.999, 0.25);
+          }
+          acc[11] += (pa + pb + pc + pd) * 1e-300;
+        }
+#endif
+        real gx = real(0), gy = real(0);
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          real sa = real(0), sb = real(0);
+#pragma unroll
+          for (int a = 0; a < 4; a++) {
+            real g;
+            if (TAP == TAP_WIDE) {
+              const uint32_t addr = __builtin_amdgcn_perm(cols[a], lane_copy << 3, 0x0c0c0000u | (uint32_t(4 + b) << 8));  // [0, 0, byte b of cols[a], copy * 8]
+              g = real(*(lds_f64_t*)(uintptr_t)addr);
+            } else {
+              const uint32_t r = (cols[a] >> (8 * b)) & 0xffu;
+              g = TAP == TAP_SINGLE ? real(*(lds_f64_t*)(uintptr_t)(r << 3)) : real(gcol[r << cshift]);
+            }
+            sa = fma(g, dbx[a], sa);
+            sb = fma(g, bx[a], sb);
+          }
+          gx = fma(sa, by[b], gx);
+          gy = fma(sb, dby[b], gy);
+        }
+        real gpr[3];
+        project_bwd<MODEL, real>(cam, ctx, gx, gy, gpr);
+        const double gp0 = double(gpr[0]), gp1 = double(gpr[1]), gp2 = double(gpr[2]);
+        const double dx = double(x), dy = double(y), dz = double(z);
+        acc[0] = fma(gp0, dx, acc[0]);
+        acc[1] = fma(gp0, dy, acc[1]);
+        acc[2] = fma(gp0, dz, acc[2]);
+        acc[3] = fma(gp1, dx, acc[3]);
+        acc[4] = fma(gp1, dy, acc[4]);
+        acc[5] = fma(gp1, dz, acc[5]);
+        acc[6] = fma(gp2, dx, acc[6]);
+        acc[7] = fma(gp2, dy, acc[7]);
+        acc[8] = fma(gp2, dz, acc[8]);
+        acc[9] += gp0;
+        acc[10] += gp1;
+        acc[11] += gp2;
+      }
+    }
+  }
+}
+
+// the workgroup's 12 sums -> partials[k][my_block] ([12][nchunks]: coalesced for the final reduction), stored write-through
+// at agent scope.  s_red: (kT / 64) * 12 doubles of LDS.
+template <int kT>
+__device__ __forceinline__ void grad_reduce_store(const double* acc, double* s_red, double* partials, unsigned int my_block, unsigned int my_blocks) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 12; k++) {
+    const double t = wave_sum(acc[k]);
+    if ((tid & 63) == 0) s_red[(tid >> 6) * 12 + k] = t;
+  }
+  __syncthreads();
+  if (tid < 12) {
+    double t = 0.0;
+    for (int w = 0; w < kT / 64; w++) t += s_red[w * 12 + tid];
+    __hip_atomic_store(&partials[size_t(tid) * my_blocks + my_block], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 template <int MODEL, typename Rec, typename real, bool GW1, bool MULTI>
 __global__ __launch_bounds__(kThreads, NID_GRAD_MIN_WAVES) void k_spline_grad(
   const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint8_t* __restrict__ img, int pitch, int W, int H, PoseParams<real> pose, CamParams<real> cam, int B,
   int GW, int cshift, double inv_unit, const u64* __restrict__ hist, const double* __restrict__ phi_q, const EntropyScalars* __restrict__ scal, double* partials, double qx,
-  double qy, double qz, double qw, double* out, double* out_host, double tag, unsigned int* counter, const MultiEntry* __restrict__ multi, typename multi_dyn_of<MULTI>::type dyn) {
+  double qy, double qz, double qw, double* out, double* out_host, double tag, unsigned int* counter, int prio, const MultiEntry* __restrict__ multi,
+  typename multi_dyn_of<MULTI>::type dyn) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* gtile = reinterpret_cast<double*>(smem);
   const int tile_n = GW * B;
@@ -766,114 +961,19 @@ __global__ __launch_bounds__(kThreads, NID_GRAD_MIN_WAVES) void k_spline_grad(
   }
   __syncthreads();
 
-  const real fW = real(W), fH = real(H);
-  const uint32_t col0 = ch.group * uint32_t(GW);
-  const uint32_t lane_copy = uint32_t(tid) & cmask;
   double acc[12];
 #pragma unroll
   for (int k = 0; k < 12; k++) acc[k] = 0.0;
-
-  const char* rec_base = reinterpret_cast<const char*>(pts + ch.start);  // uniform base + 32-bit byte offsets per lane
-  for (uint32_t base = 0; base < ch.count; base += kThreads * kUnroll) {
-    set_progress_priority(base, ch.count);
-    real xs[kUnroll], ys[kUnroll], zs[kUnroll];
-    uint32_t bins_[kUnroll];
-#pragma unroll
-    for (int k = 0; k < kUnroll; k++) {
-      const uint32_t ii = min(base + uint32_t(k) * kThreads + tid, ch.count - 1u);
-      load_rec<real>(reinterpret_cast<const Rec*>(rec_base + size_t(ii * uint32_t(sizeof(Rec)))), xs[k], ys[k], zs[k], bins_[k]);
-    }
-#pragma unroll
-    for (int k = 0; k < kUnroll; k++) {
-      // (a branch-free body like k_spline_hist's was measured 15 % slower here: 173 VGPRs, 2 waves/SIMD)
-      if (base + uint32_t(k) * kThreads + tid >= ch.count) break;
-      const real x = xs[k], y = ys[k], z = zs[k];
-      real cx, cy, cz;
-      transform_fma<real>(pose, x, y, z, cx, cy, cz);
-      real uu, vv;
-      ProjCtx<real> ctx;
-      project_fwd<MODEL, real>(cam, cx, cy, cz, uu, vv, ctx);
-      const bool in = (uu >= real(0)) && (uu < fW) && (vv >= real(0)) && (vv < fH);
-      if (in) {
-        const int kx = int(uu), ky = int(vv);  // uu, vv >= 0 here: truncation is the floor knot
-        const real sx = m_abs(m_fract(uu)), sy = m_abs(m_fract(vv));  // |.| as in the histogram pass: identical fractions
-        real bx[4], by[4], dbx[4], dby[4];
-        bspline6<real>(sx, bx);
-        bspline6<real>(sy, by);
-        bspline_deriv2<real>(sx, dbx);
-        bspline_deriv2<real>(sy, dby);
-        typedef __attribute__((address_space(3))) const double lds_f64_t;
-        const double* gcol = gtile + ((((bins_[k] - col0) * uint32_t(B)) << cshift) + lane_copy);
-        uint32_t cols[4];
-#ifdef NID_EXP_GRAD_NOGATHER
-        cols[0] = uint32_t(kx) * 0x01010101u, cols[1] = cols[0] + 0x01010101u, cols[2] = uint32_t(ky) * 0x01010101u, cols[3] = cols[2] + 0x01010101u;
-#else
-        load_patch(img, pitch, kx, ky, cols);
-#endif
-#ifdef NID_EXP_GRAD_PAD
-        {  // experiment: NID_EXP_GRAD_PAD independent fp64 fmas per point (marginal cost of a VALU instruction)
-          double pa = double(sx), pb = double(sy), pc = double(uu), pd = double(vv);
-#pragma unroll
-          for (int q = 0; q < NID_EXP_GRAD_PAD / 4; q++) {
-            pa = fma(pa, 0.999, 0.25), pb = fma(pb, 0.999, 0.25), pc = fma(pc, 0.999, 0.25), pd = fma(pd, 0.999, 0.25);
-          }
-          acc[11] += (pa + pb + pc + pd) * 1e-300;
-        }
-#endif
-        real gx = real(0), gy = real(0);
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-          real sa = real(0), sb = real(0);
-#pragma unroll
-          for (int a = 0; a < 4; a++) {
-            const uint32_t r = (cols[a] >> (8 * b)) & 0xffu;
-            const real g = GW1 ? real(*(lds_f64_t*)(uintptr_t)(r << 3)) : real(gcol[r << cshift]);
-            sa = fma(g, dbx[a], sa);
-            sb = fma(g, bx[a], sb);
-          }
-          gx = fma(sa, by[b], gx);
-          gy = fma(sb, dby[b], gy);
-        }
-        real gpr[3];
-        project_bwd<MODEL, real>(cam, ctx, gx, gy, gpr);
-        const double gp0 = double(gpr[0]), gp1 = double(gpr[1]), gp2 = double(gpr[2]);
-        const double dx = double(x), dy = double(y), dz = double(z);
-        acc[0] = fma(gp0, dx, acc[0]);
-        acc[1] = fma(gp0, dy, acc[1]);
-        acc[2] = fma(gp0, dz, acc[2]);
-        acc[3] = fma(gp1, dx, acc[3]);
-        acc[4] = fma(gp1, dy, acc[4]);
-        acc[5] = fma(gp1, dz, acc[5]);
-        acc[6] = fma(gp2, dx, acc[6]);
-        acc[7] = fma(gp2, dy, acc[7]);
-        acc[8] = fma(gp2, dz, acc[8]);
-        acc[9] += gp0;
-        acc[10] += gp1;
-        acc[11] += gp2;
-      }
-    }
-  }
-
-#pragma unroll
-  for (int k = 0; k < 12; k++) {
-    const double t = wave_sum(acc[k]);
-    if ((tid & 63) == 0) s_red[(tid >> 6) * 12 + k] = t;
-  }
-  __syncthreads();
-  if (tid < 12) {
-    double t = 0.0;
-    for (int w = 0; w < kWaves; w++) t += s_red[w * 12 + tid];
-    // [12][nchunks] (coalesced for the final reduction), stored write-through at agent scope
-    __hip_atomic_store(&partials[size_t(tid) * my_blocks + my_block], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  if (last_workgroup_arrives<true>(counter, my_blocks, s_flag)) grad_final_body(partials, int(my_blocks), qx, qy, qz, qw, out, out_host, tag, s_red);
+  spline_grad_loop<MODEL, Rec, real, GW1 ? TAP_SINGLE : TAP_COPIES, kThreads>(pts, ch, img, pitch, W, H, pose, cam, B, GW, cshift, gtile, acc, prio != 0);
+  grad_reduce_store<kThreads>(acc, s_red, partials, my_block, my_blocks);
+  if (last_workgroup_arrives<true>(counter, my_blocks, s_flag)) grad_final_body<kThreads>(partials, int(my_blocks), qx, qy, qz, qw, out, out_host, tag, s_red);
 }
 
 #ifdef NID_COMMON_KERNELS
 // standalone finalisation (only launched for an empty cloud, where k_spline_grad has no workgroups)
 __global__ __launch_bounds__(kThreads) void k_grad_final(const double* partials, int nblocks, double qx, double qy, double qz, double qw, double* out, double* out_host, double tag) {
   __shared__ double s_red[kWaves * 12];
-  grad_final_body(partials, nblocks, qx, qy, qz, qw, out, out_host, tag, s_red);
+  grad_final_body<kThreads>(partials, nblocks, qx, qy, qz, qw, out, out_host, tag, s_red);
 }
 #endif  // NID_COMMON_KERNELS
 

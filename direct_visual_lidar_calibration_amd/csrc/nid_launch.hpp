@@ -45,11 +45,29 @@ struct PassArgs {
   size_t lds_hist, lds_grad;
   const MultiEntry* multi;  // non-NULL: one grid over several pairs (chunks / nchunks are then the combined table)
   MultiDyn dyn;
+  int prio;  // progress priority (s_setprio) in the spline passes: set when the evaluation has its device to itself
+  // the one-launch evaluation (k_fused, nid_fused.hpp); chunks / nchunks = the histogram pass's table
+  unsigned long long* zero_buf;
+  long long zero_words;
+  long long* part_hj;
+  unsigned long long* row_part;
+  double* hist_image;
+  double* hist_points;
+  EntropyScalars* scal_out;
+  unsigned int* counters;
+  unsigned int bar_base;
+  unsigned int* abort_flag;
+  double* abort_host;
+  unsigned long long timeout_ticks;
+  int want_grad;
+  size_t lds_fused;
 };
 
 template <typename real> hipError_t launch_spline_hist(const PassArgs& a);
 template <typename real> hipError_t launch_spline_grad(const PassArgs& a);
 template <typename real> hipError_t launch_nearest_hist(const PassArgs& a);
+template <typename real> hipError_t launch_fused(const PassArgs& a);
+template <typename real> int occupancy_fused(const PassArgs& a);
 // workgroups of the selected kernel instantiation (model, record type, tiling) that fit on one CU at once
 // (hipOccupancyMaxActiveBlocksPerMultiprocessor; 0 on error): a pass gets exactly one round of co-resident workgroups
 template <typename real> int occupancy_spline_hist(const PassArgs& a);

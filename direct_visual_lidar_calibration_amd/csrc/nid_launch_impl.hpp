@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "nid_kernels.hpp"
+#include "nid_fused.hpp"
 #include "nid_launch.hpp"
 
 namespace nidreg {
@@ -70,13 +71,13 @@ static hipError_t launch_spline_hist_rec(const PassArgs& a) {
     hipError_t e = ensure_lds(k, a.lds_hist);                                                                                                          \
     if (e != hipSuccess) return e;                                                                                                                     \
     hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(THREADS), a.lds_hist, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, pose, cam, \
-                       a.B, a.GW, a.cshift, a.magic, a.hist, a.multi, a.dyn);                                                                           \
+                       a.B, a.GW, a.cshift, a.magic, a.hist, a.prio, a.multi, a.dyn);                                                                           \
   } else {                                                                                                                                             \
     auto k = k_spline_hist<M, Rec, real, WIDE, false>;                                                                                                 \
     hipError_t e = ensure_lds(k, a.lds_hist);                                                                                                          \
     if (e != hipSuccess) return e;                                                                                                                     \
     hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(THREADS), a.lds_hist, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, pose, cam, \
-                       a.B, a.GW, a.cshift, a.magic, a.hist, a.multi, NoMultiDyn());                                                                    \
+                       a.B, a.GW, a.cshift, a.magic, a.hist, a.prio, a.multi, NoMultiDyn());                                                                    \
   }
   if (a.wide) {  // B = 256, GW = 1, 32 copies, 512 threads (see k_spline_hist)
 #define NID_LAUNCH(M) NID_LAUNCH_W(M, true, kWideThreads)
@@ -101,13 +102,13 @@ static hipError_t launch_spline_grad_rec(const PassArgs& a) {
     hipError_t e = ensure_lds(k, a.lds_grad);                                                                                                          \
     if (e != hipSuccess) return e;                                                                                                                     \
     hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(kThreads), a.lds_grad, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, pose, cam, \
-                       a.B, a.GW, a.cshift, a.inv_unit, a.hist, a.phi_q, a.scal, a.partials, a.q[0], a.q[1], a.q[2], a.q[3], a.out, a.out_host, a.tag, a.counter, a.multi, a.dyn); \
+                       a.B, a.GW, a.cshift, a.inv_unit, a.hist, a.phi_q, a.scal, a.partials, a.q[0], a.q[1], a.q[2], a.q[3], a.out, a.out_host, a.tag, a.counter, a.prio, a.multi, a.dyn); \
   } else {                                                                                                                                             \
     auto k = k_spline_grad<M, Rec, real, GW1, false>;                                                                                                  \
     hipError_t e = ensure_lds(k, a.lds_grad);                                                                                                          \
     if (e != hipSuccess) return e;                                                                                                                     \
     hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(kThreads), a.lds_grad, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, pose, cam, \
-                       a.B, a.GW, a.cshift, a.inv_unit, a.hist, a.phi_q, a.scal, a.partials, a.q[0], a.q[1], a.q[2], a.q[3], a.out, a.out_host, a.tag, a.counter, a.multi,        \
+                       a.B, a.GW, a.cshift, a.inv_unit, a.hist, a.phi_q, a.scal, a.partials, a.q[0], a.q[1], a.q[2], a.q[3], a.out, a.out_host, a.tag, a.counter, a.prio, a.multi, \
                        NoMultiDyn());                                                                                                                  \
   }
   if (a.GW == 1) {
@@ -196,6 +197,106 @@ static int occupancy_spline_grad_rec(const PassArgs& a) {
 #undef NID_LAUNCH
   }
 #undef NID_OCC_G
+  return n;
+}
+
+static FusedArgs make_fused_args(const PassArgs& a) {
+  FusedArgs f;
+  f.pts = a.pts;
+  f.chunks = a.chunks;
+  f.img = a.img;
+  f.pitch = a.pitch;
+  f.W = a.W;
+  f.H = a.H;
+  f.B = a.B;
+  f.GW = a.GW;
+  f.cshift = a.cshift;
+  f.dn_scale = a.magic;
+  f.inv_unit = a.inv_unit;
+  f.hist = a.hist;
+  f.zero_buf = a.zero_buf;
+  f.zero_words = a.zero_words;
+  f.part_hj = a.part_hj;
+  f.row_part = a.row_part;
+  f.phi_q = const_cast<double*>(a.phi_q);
+  f.hist_image = a.hist_image;
+  f.hist_points = a.hist_points;
+  f.scal = a.scal_out;
+  f.partials = a.partials;
+  for (int k = 0; k < 4; k++) f.q[k] = a.q[k];
+  f.out = a.out;
+  f.out_host = a.out_host;
+  f.tag = a.tag;
+  f.counters = a.counters;
+  f.bar_base = a.bar_base;
+  f.abort_flag = a.abort_flag;
+  f.abort_host = a.abort_host;
+  f.timeout_ticks = a.timeout_ticks;
+  f.want_grad = a.want_grad;
+  f.prio = a.prio;
+  return f;
+}
+
+template <typename real, typename Rec>
+static hipError_t launch_fused_rec(const PassArgs& a) {
+  const PoseParams<real> pose = make_pose<real>(a);
+  const CamParams<real> cam = make_cam<real>(a.intr, a.dist);
+  const FusedArgs f = make_fused_args(a);
+#define NID_LAUNCH_F(M, WIDE, THREADS)                                                        \
+  {                                                                                           \
+    auto k = k_fused<M, Rec, real, WIDE>;                                                     \
+    hipError_t e = ensure_lds(k, a.lds_fused);                                                \
+    if (e != hipSuccess) return e;                                                            \
+    hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(THREADS), a.lds_fused, a.stream, pose, cam, f); \
+  }
+  if (a.wide) {
+#define NID_LAUNCH(M) NID_LAUNCH_F(M, true, kWideThreads)
+    NID_MODEL_SWITCH(NID_LAUNCH)
+#undef NID_LAUNCH
+  } else {
+#define NID_LAUNCH(M) NID_LAUNCH_F(M, false, kThreads)
+    NID_MODEL_SWITCH(NID_LAUNCH)
+#undef NID_LAUNCH
+  }
+#undef NID_LAUNCH_F
+  return hipGetLastError();
+}
+
+template <typename real, typename Rec>
+static int occupancy_fused_rec(const PassArgs& a) {
+  int n = 0;
+#define NID_OCC_F(M, WIDE, THREADS)                                                                                                    \
+  {                                                                                                                                    \
+    auto k = k_fused<M, Rec, real, WIDE>;                                                                                              \
+    if (ensure_lds(k, a.lds_fused) != hipSuccess) return 0;                                                                            \
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(k), THREADS, a.lds_fused) != hipSuccess) n = 0; \
+  }
+  if (a.wide) {
+#define NID_LAUNCH(M) NID_OCC_F(M, true, kWideThreads)
+    switch (a.model) {
+      case MODEL_PLUMB_BOB: NID_LAUNCH(MODEL_PLUMB_BOB); break;
+      case MODEL_FISHEYE: NID_LAUNCH(MODEL_FISHEYE); break;
+      case MODEL_OMNIDIR: NID_LAUNCH(MODEL_OMNIDIR); break;
+      case MODEL_EQUIRECT: NID_LAUNCH(MODEL_EQUIRECT); break;
+      case MODEL_ATAN: NID_LAUNCH(MODEL_ATAN); break;
+      case MODEL_RATIONAL: NID_LAUNCH(MODEL_RATIONAL); break;
+      default: return 0;
+    }
+#undef NID_LAUNCH
+  } else {
+#define NID_LAUNCH(M) NID_OCC_F(M, false, kThreads)
+    switch (a.model) {
+      case MODEL_PLUMB_BOB: NID_LAUNCH(MODEL_PLUMB_BOB); break;
+      case MODEL_FISHEYE: NID_LAUNCH(MODEL_FISHEYE); break;
+      case MODEL_OMNIDIR: NID_LAUNCH(MODEL_OMNIDIR); break;
+      case MODEL_EQUIRECT: NID_LAUNCH(MODEL_EQUIRECT); break;
+      case MODEL_ATAN: NID_LAUNCH(MODEL_ATAN); break;
+      case MODEL_RATIONAL: NID_LAUNCH(MODEL_RATIONAL); break;
+      default: return 0;
+    }
+#undef NID_LAUNCH
+  }
+#undef NID_OCC_F
   return n;
 }
 

@@ -20,7 +20,7 @@ struct MultiEntry {
   u64* hist_buf[2];
   double k16;       // U/36 as a subnormal double (bspline_scale)
   double inv_unit;  // 1 / U
-  double* part_hj;
+  long long* part_hj;  // fixed-point entropy partials (ent_fixed)
   u64* row_part;
   double* phi_q;
   double* hist_image;

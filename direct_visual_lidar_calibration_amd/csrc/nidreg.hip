@@ -6,6 +6,7 @@
 // HIP kernels of nid_kernels.hpp, and creation fails when no gfx950 device is usable.
 #define NID_COMMON_KERNELS
 #include "nid_kernels.hpp"
+#include "nid_fused.hpp"
 #include "nid_launch.hpp"
 
 #include <algorithm>
@@ -18,6 +19,7 @@
 #include <cstring>
 #include <ctime>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -96,7 +98,7 @@ struct nidreg_handle {
   double* d_out = nullptr;
   bool own_out = false;
   void* d_scratch = nullptr;  // ONE allocation carved into the per-evaluation scratch below (zeroed at creation)
-  double* d_part_hj = nullptr;
+  long long* d_part_hj = nullptr;  // fixed-point entropy partials (nid_kernels.hpp ent_fixed)
   u64* d_row_part = nullptr;
   double* d_phi_q = nullptr;
   double* d_hist_image = nullptr;
@@ -115,7 +117,16 @@ struct nidreg_handle {
   std::vector<int64_t> gcount;  // record offsets of the column groups (host copy: multi-pair groups build their chunk tables from it)
   int num_cus = 256, per_cu_grad = 4, per_cu_hist = 2;
 
-  bool timing = false;
+  // the one-launch evaluation (k_fused, nid_fused.hpp): usable when the histogram pass's chunk table is one co-resident
+  // round of THAT kernel on this device; switched off for the handle after a launch had to be abandoned
+  bool fused_ok = false;
+  bool fused_off = false;
+  bool fused_inflight = false;
+  size_t lds_fused = 0;
+  unsigned int bar_base = 0;  // value of d_counters[3] (grid-barrier counter) before the next fused launch
+  unsigned long long fused_timeout_ticks = 500000ull;  // 5 ms of the 100 MHz wall clock
+
+  int timing = 0;  // 1: per-kernel events (three-kernel path), 2: events around whichever path runs
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool ev_grad = false;
   double last_q[4] = {0, 0, 0, 1};
@@ -234,6 +245,24 @@ inline void bump_seq(nidreg_handle* h) {
   std::memcpy(&h->seq_bits, &h->seq, sizeof(h->seq_bits));
 }
 
+// Evaluations in flight per device (this process).  An evaluation that has its device to itself runs with progress
+// priority in the spline passes and -- nidreg_eval -- as ONE fused kernel; with several callers on one GPU (the reference's
+// OpenMP loop over pairs, visual_camera_calibration.cpp:161) both are off: the priority rule made competing kernels 5-16 %
+// slower (profiles/r02h_multi_pair_threads.txt), and two grid-barrier kernels must not share a device.
+std::atomic<int> g_inflight[NIDREG_MAX_DEVICES];
+struct InflightGuard {
+  int dev;
+  bool alone;
+  explicit InflightGuard(int d) : dev(d >= 0 && d < NIDREG_MAX_DEVICES ? d : -1), alone(false) {
+    if (dev >= 0) alone = g_inflight[dev].fetch_add(1, std::memory_order_acq_rel) == 0;
+  }
+  ~InflightGuard() {
+    if (dev >= 0) g_inflight[dev].fetch_sub(1, std::memory_order_acq_rel);
+  }
+  InflightGuard(const InflightGuard&) = delete;
+  InflightGuard& operator=(const InflightGuard&) = delete;
+};
+
 // R = I + 2 w [v]x + 2 [v]x^2 from the un-normalised quaternion (Sophus SO3 * point expanded)
 void pose_from_se3(const double* se3, double* R, double* t) {
   const double x = se3[0], y = se3[1], z = se3[2], w = se3[3];
@@ -270,9 +299,10 @@ hipError_t begin_histogram(nidreg_handle* h, hipStream_t stream) {
 }
 hipError_t begin_histogram(nidreg_handle* h) { return begin_histogram(h, h->stream); }
 
-int launch_hist_spline(nidreg_handle* h, const double* se3) {
+int launch_hist_spline(nidreg_handle* h, const double* se3, bool alone = false) {
   PassArgs a;
   fill_pass_args(h, a);
+  a.prio = alone ? 1 : 0;
   if (h->d_chunks_hist) {
     a.chunks = h->d_chunks_hist;
     a.nchunks = h->nchunks_hist;
@@ -283,7 +313,7 @@ int launch_hist_spline(nidreg_handle* h, const double* se3) {
   std::memcpy(h->last_t, a.t, sizeof(a.t));
   HIP_TRY(begin_histogram(h));
   a.hist = h->d_hist;
-  if (h->timing) HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+  if (h->timing == 1) HIP_TRY(hipEventRecord(h->ev[1], h->stream));
   if (h->precision == NIDREG_PREC_FP32) {
     HIP_TRY(launch_spline_hist<float>(a));
   } else {
@@ -298,7 +328,7 @@ int launch_hist_nearest(nidreg_handle* h, const double* T) {
   for (int k = 0; k < 12; k++) a.iso[k] = T[k];
   HIP_TRY(begin_histogram(h));
   a.hist = h->d_hist;
-  if (h->timing) HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+  if (h->timing == 1) HIP_TRY(hipEventRecord(h->ev[1], h->stream));
   if (h->precision == NIDREG_PREC_FP32) {
     HIP_TRY(launch_nearest_hist<float>(a));
   } else {
@@ -318,9 +348,10 @@ int launch_entropy(nidreg_handle* h, double tag) {
   return NIDREG_OK;
 }
 
-int launch_grad(nidreg_handle* h) {
+int launch_grad(nidreg_handle* h, bool alone = false) {
   PassArgs a;
   fill_pass_args(h, a);
+  a.prio = alone ? 1 : 0;
   a.hist = hist_source(h);  // the finished (for a shard: all-reduced) histogram
   // same pose as the histogram pass of this evaluation
   std::memcpy(a.R, h->last_R, sizeof(a.R));
@@ -330,7 +361,7 @@ int launch_grad(nidreg_handle* h) {
   } else {
     HIP_TRY(launch_spline_grad<double>(a));
   }
-  if (h->timing) HIP_TRY(hipEventRecord(h->ev[4], h->stream));
+  if (h->timing == 1) HIP_TRY(hipEventRecord(h->ev[4], h->stream));
   if (h->nchunks == 0) {  // empty cloud: no gradient workgroups ran, finalise (zeros) stand-alone
     hipLaunchKernelGGL(k_grad_final, dim3(1), dim3(kThreads), 0, h->stream, h->d_partials, 0, h->last_q[0], h->last_q[1], h->last_q[2], h->last_q[3], h->d_out, h->d_out_host, h->seq);
     HIP_TRY(hipGetLastError());
@@ -340,38 +371,106 @@ int launch_grad(nidreg_handle* h) {
 
 // asynchronous part of nidreg_eval, in two steps so that a multi-handle caller can put every GPU to work before it
 // queues the rest: eval_launch_first = the histogram pass, eval_launch_rest = entropy (+ gradient)
-int eval_launch_first(nidreg_handle* h, const double* se3) {
+int eval_launch_first(nidreg_handle* h, const double* se3, bool alone = false) {
   if (h->mode != NIDREG_MODE_SPLINE) return fail(NIDREG_ERR_INVALID, "nidreg_eval: handle was created in NEAREST mode");
   HIP_TRY(hipSetDevice(h->device));
   bump_seq(h);
+  h->fused_inflight = false;
   if (h->timing) HIP_TRY(hipEventRecord(h->ev[0], h->stream));
-  const int rc = launch_hist_spline(h, se3);
+  const int rc = launch_hist_spline(h, se3, alone);
   if (rc) return rc;
-  if (h->timing) HIP_TRY(hipEventRecord(h->ev[2], h->stream));
+  if (h->timing == 1) HIP_TRY(hipEventRecord(h->ev[2], h->stream));
   return NIDREG_OK;
 }
-int eval_launch_rest(nidreg_handle* h, bool want_grad) {
+int eval_launch_rest(nidreg_handle* h, bool want_grad, bool alone = false) {
   HIP_TRY(hipSetDevice(h->device));
   int rc = launch_entropy(h, want_grad ? 0.0 : h->seq);
   if (rc) return rc;
-  if (h->timing) HIP_TRY(hipEventRecord(h->ev[3], h->stream));
+  if (h->timing == 1) HIP_TRY(hipEventRecord(h->ev[3], h->stream));
   h->ev_grad = want_grad;
   if (want_grad) {
-    rc = launch_grad(h);
+    rc = launch_grad(h, alone);
     if (rc) return rc;
-  } else if (h->timing) {
+  } else if (h->timing == 1) {
     HIP_TRY(hipEventRecord(h->ev[4], h->stream));
   }
   if (h->timing) HIP_TRY(hipEventRecord(h->ev[5], h->stream));
   if (!h->d_out_host) HIP_TRY(hipMemcpyAsync(h->h_out, h->d_out, NIDREG_OUT_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   return NIDREG_OK;
 }
-int eval_launch(nidreg_handle* h, const double* se3, bool want_grad) {
-  const int rc = eval_launch_first(h, se3);
-  if (rc) return rc;
-  return eval_launch_rest(h, want_grad);
+
+// The whole evaluation as ONE kernel (k_fused): histogram -> grid barrier -> distributed entropy -> grid barrier ->
+// gradient.  Only for an evaluation that is alone on its device (the barriers need every workgroup resident).
+bool fused_usable(const nidreg_handle* h) { return h->fused_ok && !h->fused_off && h->timing != 1; }
+int eval_launch_fused(nidreg_handle* h, const double* se3, bool want_grad) {
+  HIP_TRY(hipSetDevice(h->device));
+  bump_seq(h);
+  PassArgs a;
+  fill_pass_args(h, a);
+  if (h->d_chunks_hist) {
+    a.chunks = h->d_chunks_hist;
+    a.nchunks = h->nchunks_hist;
+  }
+  pose_from_se3(se3, a.R, a.t);
+  for (int k = 0; k < 4; k++) h->last_q[k] = a.q[k] = se3[k];
+  std::memcpy(h->last_R, a.R, sizeof(a.R));
+  std::memcpy(h->last_t, a.t, sizeof(a.t));
+  HIP_TRY(begin_histogram(h));
+  a.hist = h->d_hist;
+  a.prio = 1;
+  a.zero_buf = h->d_hist_buf[h->hist_cur ^ 1];
+  a.zero_words = h->hist_words;
+  a.part_hj = h->d_part_hj;
+  a.row_part = h->d_row_part;
+  a.hist_image = h->d_hist_image;
+  a.hist_points = h->d_hist_points;
+  a.scal_out = h->d_scal;
+  a.counters = h->d_counters;
+  a.bar_base = h->bar_base;
+  a.abort_flag = h->d_counters + 5;
+  a.abort_host = h->d_out_host + 11;
+  a.timeout_ticks = h->fused_timeout_ticks;
+  a.want_grad = want_grad ? 1 : 0;
+  a.lds_fused = h->lds_fused;
+  a.tag = h->seq;
+  if (h->timing) HIP_TRY(hipEventRecord(h->ev[0], h->stream));
+  if (h->precision == NIDREG_PREC_FP32) {
+    HIP_TRY(launch_fused<float>(a));
+  } else {
+    HIP_TRY(launch_fused<double>(a));
+  }
+  if (h->timing) HIP_TRY(hipEventRecord(h->ev[5], h->stream));
+  h->bar_base += unsigned(a.nchunks) * (want_grad ? 2u : 1u);
+  h->hist_zeroed[h->hist_cur ^ 1] = true;  // zeroed by phase 2 for the next evaluation
+  h->ev_grad = want_grad;
+  h->fused_inflight = true;
+  return NIDREG_OK;
 }
 
+// after an abandoned fused launch: tickets, barrier counter and abort flag back to zero, both histogram buffers dirty
+int fused_recover(nidreg_handle* h) {
+  static std::atomic<bool> warned{false};
+  if (!warned.exchange(true))
+    std::fprintf(stderr, "nidreg: the one-launch evaluation could not get the whole GPU (another kernel holds compute units); handle falls back to three kernels per evaluation\n");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemsetAsync(h->d_counters, 0, 8 * sizeof(unsigned int), h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->h_out[11] = 0.0;
+  h->bar_base = 0;
+  h->hist_zeroed[0] = h->hist_zeroed[1] = false;
+  h->fused_off = true;
+  h->fused_inflight = false;
+  return NIDREG_OK;
+}
+
+int eval_launch(nidreg_handle* h, const double* se3, bool want_grad, bool alone = false) {
+  const int rc = eval_launch_first(h, se3, alone);
+  if (rc) return rc;
+  return eval_launch_rest(h, want_grad, alone);
+}
+
+constexpr int kRetryUnfused = -100;  // internal: the fused kernel abandoned the evaluation (not an ABI return value)
 int eval_finish_on(nidreg_handle* h, hipStream_t stream, double* cost, double* grad7);
 int eval_finish(nidreg_handle* h, double* cost, double* grad7) { return eval_finish_on(h, h->stream, cost, grad7); }
 // `stream` = the stream the evaluation's kernels were queued on (the handle's own, or a multi-pair group's)
@@ -405,6 +504,7 @@ int eval_finish_on(nidreg_handle* h, hipStream_t stream, double* cost, double* g
           const hipError_t q = hipStreamQuery(stream);
           if (q == hipSuccess) {
             if (!tag_seen()) HIP_TRY(hipStreamSynchronize(stream));
+            if (!tag_seen() && h->fused_inflight && h->h_out[11] != 0.0) return kRetryUnfused;  // a grid barrier of k_fused timed out
             if (!tag_seen()) return fail(NIDREG_ERR_HIP, "nidreg_eval: stream drained but the completion tag is missing");
             break;
           }
@@ -433,6 +533,7 @@ int iso_launch(nidreg_handle* h, const double* T) {
   if (h->mode != NIDREG_MODE_NEAREST) return fail(NIDREG_ERR_INVALID, "nidreg_eval_iso: handle was created in SPLINE mode");
   HIP_TRY(hipSetDevice(h->device));
   bump_seq(h);
+  h->fused_inflight = false;
   if (h->timing) HIP_TRY(hipEventRecord(h->ev[0], h->stream));
   int rc = launch_hist_nearest(h, T);
   if (rc) return rc;
@@ -778,18 +879,19 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
       off = (off + bytes + 255) & ~size_t(255);
       return at;
     };
-    const size_t o_part_hj = carve(size_t(h->NEB) * sizeof(double));
-    const size_t o_row_part = carve(size_t(h->NEB) * B * sizeof(u64));
+    const int chunks_max = std::max(std::max(h->nchunks, h->nchunks_hist), 1);
+    const size_t o_part_hj = carve(size_t(std::max(h->NEB, chunks_max)) * sizeof(long long));    // k_entropy: per column block; k_fused: per workgroup
+    const size_t o_row_part = carve(size_t(std::max(h->NEB, kFusedMaxSegs)) * B * sizeof(u64));  // k_entropy: [NEB][B]; k_fused: [segments][B]
     const size_t o_phi_q = carve(size_t(B) * sizeof(double));
     const size_t o_hist_image = carve(size_t(B) * sizeof(double));
     const size_t o_hist_points = carve(size_t(B) * sizeof(double));
     const size_t o_scal = carve(sizeof(EntropyScalars));
-    const size_t o_partials = carve(std::max<size_t>(h->nchunks, 1) * 12 * sizeof(double));
+    const size_t o_partials = carve(size_t(chunks_max) * 12 * sizeof(double));
     const size_t o_counters = carve(8 * sizeof(unsigned int));
     CREATE_TRY(hipMalloc(&h->d_scratch, off));
     CREATE_TRY(hipMemset(h->d_scratch, 0, off));
     char* base = static_cast<char*>(h->d_scratch);
-    h->d_part_hj = reinterpret_cast<double*>(base + o_part_hj);
+    h->d_part_hj = reinterpret_cast<long long*>(base + o_part_hj);
     h->d_row_part = reinterpret_cast<u64*>(base + o_row_part);
     h->d_phi_q = reinterpret_cast<double*>(base + o_phi_q);
     h->d_hist_image = reinterpret_cast<double*>(base + o_hist_image);
@@ -807,6 +909,24 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
     h->d_out_host = static_cast<double*>(dp);
   }
   for (int i = 0; i < 6; i++) CREATE_TRY(hipEventCreate(&h->ev[i]));
+  // ---- the one-launch evaluation (k_fused): its grid barriers need the histogram pass's whole chunk table resident at
+  // once, which the table's construction aimed at for k_spline_hist -- checked here against k_fused's own occupancy
+  // (the fisheye / equirectangular instantiations hold more registers: they keep the three-kernel path)
+  if (d->mode == NIDREG_MODE_SPLINE && h->own_hist && h->d_out_host && !opts.shard && h->own_stream) {
+    const char* env = std::getenv("NIDREG_FUSED");
+    const bool enabled = !(env && *env == '0');
+    const int table = h->d_chunks_hist ? h->nchunks_hist : h->nchunks;
+    const int threads = h->wide ? kWideThreads : kThreads;
+    h->lds_fused = fused_lds_bytes(B, h->GW, h->cshift, threads);
+    if (enabled && table > 0) {
+      PassArgs oa;
+      fill_pass_args(h, oa);
+      oa.lds_fused = h->lds_fused;
+      const int occ = h->precision == NIDREG_PREC_FP32 ? occupancy_fused<float>(oa) : occupancy_fused<double>(oa);
+      h->fused_ok = occ > 0 && int64_t(occ) * h->num_cus >= table;
+    }
+    if (const char* t = std::getenv("NIDREG_FUSED_TIMEOUT_US")) h->fused_timeout_ticks = 100ull * (unsigned long long)std::max(1L, std::strtol(t, nullptr, 10));
+  }
 #undef CREATE_TRY
   *out = h;
   return NIDREG_OK;
@@ -957,6 +1077,8 @@ int group_eval(MultiGroup* g, const double* se3, bool want_grad, double* costs, 
   a.multi = g->d_table;
   a.dyn.want_grad = want_grad ? 1 : 0;
   a.dyn.neb = h0->NEB;
+  InflightGuard guard(g->device);
+  a.prio = guard.alone ? 1 : 0;
   pose_from_se3(se3, a.R, a.t);
   for (int k = 0; k < 4; k++) a.q[k] = se3[k];
   for (int i = 0; i < n; i++) {
@@ -969,6 +1091,7 @@ int group_eval(MultiGroup* g, const double* se3, bool want_grad, double* costs, 
     std::memcpy(h->last_R, a.R, sizeof(a.R));
     std::memcpy(h->last_t, a.t, sizeof(a.t));
     h->ev_grad = want_grad;
+    h->fused_inflight = false;
   }
   // pass A
   a.chunks = h0->wide ? g->d_chunks_hist : g->d_chunks;
@@ -980,7 +1103,7 @@ int group_eval(MultiGroup* g, const double* se3, bool want_grad, double* costs, 
   }
   // entropy: NEB workgroups per pair
   hipLaunchKernelGGL(
-    k_entropy<true>, dim3(h0->NEB * n), dim3(kEntropyThreads), 0, g->stream, static_cast<const u64*>(nullptr), h0->bins, kEntropyCols, 0.0, static_cast<double*>(nullptr),
+    k_entropy<true>, dim3(h0->NEB * n), dim3(kEntropyThreads), 0, g->stream, static_cast<const u64*>(nullptr), h0->bins, kEntropyCols, 0.0, static_cast<long long*>(nullptr),
     static_cast<u64*>(nullptr), static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<EntropyScalars*>(nullptr), static_cast<double*>(nullptr),
     static_cast<double*>(nullptr), 0.0, static_cast<unsigned int*>(nullptr), static_cast<u64*>(nullptr), 0ll, static_cast<const MultiEntry*>(g->d_table), a.dyn);
   HIP_TRY(hipGetLastError());
@@ -1040,7 +1163,7 @@ int group_eval_iso(MultiGroup* g, const double* T, double* costs) {
     HIP_TRY(launch_nearest_hist<double>(a));
   }
   hipLaunchKernelGGL(
-    k_entropy<true>, dim3(h0->NEB * n), dim3(kEntropyThreads), 0, g->stream, static_cast<const u64*>(nullptr), h0->bins, kEntropyCols, 0.0, static_cast<double*>(nullptr),
+    k_entropy<true>, dim3(h0->NEB * n), dim3(kEntropyThreads), 0, g->stream, static_cast<const u64*>(nullptr), h0->bins, kEntropyCols, 0.0, static_cast<long long*>(nullptr),
     static_cast<u64*>(nullptr), static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<EntropyScalars*>(nullptr), static_cast<double*>(nullptr),
     static_cast<double*>(nullptr), 0.0, static_cast<unsigned int*>(nullptr), static_cast<u64*>(nullptr), 0ll, static_cast<const MultiEntry*>(g->d_table), a.dyn);
   HIP_TRY(hipGetLastError());
@@ -1062,126 +1185,6 @@ bool can_group(nidreg_handle* const* handles, int n) {
     for (int j = i + 1; j < n; j++)
       if (handles[i] == handles[j]) return false;
   return true;
-}
-
-// ---- concurrent callers -> one grid (opt-in: NIDREG_COMBINE=1) ---------------------------------------------------
-// The reference's MultiNIDCost evaluates its pairs from an OpenMP loop (visual_camera_calibration.cpp:161): one thread per
-// pair, every one calling its own NIDCost functor with the SAME pose.  Through nidreg_eval these are k independent
-// evaluations whose kernels compete for the GPU (measured, 8 x 1.25M points: 278-304 us against 207 us for the single
-// grid of nidreg_eval_multi).  With the combiner the callers that arrive together on one device are collected by the
-// first of them, evaluated as ONE group (group_eval: one grid per pass over all pairs, bit-identical results) and woken
-// with their own cost / gradient.  A caller that is alone -- the history of the device says so -- is not delayed at all.
-struct CombSlot {
-  nidreg_handle* h;
-  const double* se3;
-  double* cost;
-  double* grad7;
-  int rc = 0;
-  std::atomic<int> done{0};
-};
-struct Combiner {
-  std::mutex mu;
-  std::vector<CombSlot*> waiting;  // the batch being assembled
-  bool leader = false;             // somebody is assembling it
-  int expect = 1;                  // callers per batch seen lately
-  std::atomic<int> inflight{0};
-};
-Combiner g_comb[NIDREG_MAX_DEVICES];
-
-bool combine_enabled() {
-  static const bool on = [] {
-    const char* e = std::getenv("NIDREG_COMBINE");
-    return e && *e && *e != '0';
-  }();
-  return on;
-}
-
-double now_us() {
-  struct timespec t;
-  clock_gettime(CLOCK_MONOTONIC, &t);
-  return t.tv_sec * 1e6 + t.tv_nsec * 1e-3;
-}
-
-int eval_one(nidreg_handle* h, const double* se3, double* cost, double* grad7) {
-  const int rc = eval_launch(h, se3, grad7 != nullptr);
-  if (rc) return rc;
-  return eval_finish(h, cost, grad7);
-}
-
-// the leader's part: evaluate a batch (>= 1 slots) and publish every slot's result
-void run_batch(std::vector<CombSlot*>& batch) {
-  const int n = int(batch.size());
-  bool uniform = n >= 2 && n <= kMaxMulti;
-  for (int i = 1; i < n && uniform; i++)
-    uniform = std::memcmp(batch[size_t(i)]->se3, batch[0]->se3, 7 * sizeof(double)) == 0 && (batch[size_t(i)]->grad7 != nullptr) == (batch[0]->grad7 != nullptr);
-  bool grouped = false;
-  if (uniform) {
-    std::sort(batch.begin(), batch.end(), [](const CombSlot* a, const CombSlot* b) { return a->h < b->h; });  // one canonical order per set of pairs
-    nidreg_handle* hs[kMaxMulti];
-    for (int i = 0; i < n; i++) hs[i] = batch[size_t(i)]->h;
-    if (can_group(hs, n)) {
-      if (MultiGroup* g = find_or_make_group(hs, n)) {
-        double costs[kMaxMulti], grads[kMaxMulti * 7];
-        int rcs[kMaxMulti];
-        bool all_ok = true;
-        const bool want_grad = batch[0]->grad7 != nullptr;
-        const int rc = group_eval(g, batch[0]->se3, want_grad, costs, want_grad ? grads : nullptr, &all_ok, rcs);
-        for (int i = 0; i < n; i++) {
-          CombSlot* s = batch[size_t(i)];
-          s->rc = rc < 0 ? rc : rcs[i];
-          if (rc >= 0) {
-            if (s->cost) *s->cost = costs[i];
-            if (s->grad7) std::memcpy(s->grad7, grads + 7 * i, 7 * sizeof(double));
-          }
-        }
-        grouped = true;
-      }
-    }
-  }
-  if (!grouped)
-    for (CombSlot* s : batch) s->rc = eval_one(s->h, s->se3, s->cost, s->grad7);
-  for (CombSlot* s : batch) s->done.store(1, std::memory_order_release);
-}
-
-int combine_eval(nidreg_handle* h, const double* se3, double* cost, double* grad7) {
-  Combiner& c = g_comb[h->device];
-  CombSlot slot{h, se3, cost, grad7};
-  const int conc = c.inflight.fetch_add(1, std::memory_order_acq_rel) + 1;
-  std::vector<CombSlot*> batch;
-  {
-    std::unique_lock<std::mutex> lk(c.mu);
-    if (conc > c.expect) c.expect = std::min(conc, kMaxMulti);
-    c.waiting.push_back(&slot);
-    if (!c.leader) {
-      c.leader = true;
-      // wait for the callers the history promises, for at most 100 us (they leave the same barrier: microseconds apart)
-      const double deadline = now_us() + 100.0;
-      while (int(c.waiting.size()) < c.expect && now_us() < deadline) {
-        lk.unlock();
-        for (int k = 0; k < 32; k++) __builtin_ia32_pause();
-        lk.lock();
-      }
-      batch.swap(c.waiting);
-      c.leader = false;  // later arrivals assemble the next batch
-      c.expect = std::max(1, int(batch.size()));
-    }
-  }
-  if (!batch.empty()) {
-    run_batch(batch);
-  } else {
-    const double t0 = now_us();
-    unsigned spins = 0;
-    while (!slot.done.load(std::memory_order_acquire)) {
-      __builtin_ia32_pause();
-      if ((++spins & 0xffu) == 0 && now_us() - t0 > 2000.0) {
-        struct timespec ts = {0, 50000};
-        nanosleep(&ts, nullptr);
-      }
-    }
-  }
-  c.inflight.fetch_sub(1, std::memory_order_acq_rel);
-  if (slot.rc < 0 && batch.empty()) return fail(slot.rc, "nidreg_eval: the combined evaluation of concurrent callers failed (the thread that ran it holds the HIP error text)");
-  return slot.rc;
 }
 
 // ---- sharded pairs ----------------------------------------------------------------------------------------------
@@ -1226,11 +1229,13 @@ int launch_exchange(ShardSet* set, int g) {
 int run_shard(ShardSet* set, int g) {
   nidreg_handle* h = set->shards[size_t(g)];
   HIP_TRY(hipSetDevice(h->device));
+  InflightGuard guard(h->device);
   bump_seq(h);
+  h->fused_inflight = false;
   if (h->timing) HIP_TRY(hipEventRecord(h->ev[0], h->stream));
   int rc;
   if (set->job_mode == NIDREG_MODE_SPLINE) {
-    rc = launch_hist_spline(h, set->job_pose);
+    rc = launch_hist_spline(h, set->job_pose, guard.alone);
   } else {
     rc = launch_hist_nearest(h, set->job_pose);
   }
@@ -1243,7 +1248,7 @@ int run_shard(ShardSet* set, int g) {
   if (rc) return rc;
   if (h->timing) HIP_TRY(hipEventRecord(h->ev[3], h->stream));
   if (grad) {
-    rc = launch_grad(h);  // records ev[4]
+    rc = launch_grad(h, guard.alone);  // records ev[4]
     if (rc) return rc;
   } else if (h->timing) {
     HIP_TRY(hipEventRecord(h->ev[4], h->stream));
@@ -1571,8 +1576,19 @@ void nidreg_destroy(nidreg_handle* h) { free_handle(h); }
 int nidreg_eval(nidreg_handle* h, const double* se3, double* cost, double* grad7) {
   if (!h || !se3) return fail(NIDREG_ERR_INVALID, "nidreg_eval: null argument");
   if (h->set) return set_eval(h->set, NIDREG_MODE_SPLINE, se3, cost, grad7);
-  if (combine_enabled() && h->mode == NIDREG_MODE_SPLINE && h->device >= 0 && h->device < NIDREG_MAX_DEVICES) return combine_eval(h, se3, cost, grad7);
-  const int rc = eval_launch(h, se3, grad7 != nullptr);
+  InflightGuard guard(h->device);
+  if (guard.alone && h->mode == NIDREG_MODE_SPLINE && fused_usable(h)) {
+    int rc = eval_launch_fused(h, se3, grad7 != nullptr);
+    if (rc) return rc;
+    rc = eval_finish(h, cost, grad7);
+    if (rc != kRetryUnfused) return rc;
+    // Not every workgroup became resident within the timeout (something else holds CUs of this GPU): the kernel has
+    // ended by itself.  Put the handle back into a clean state and repeat the evaluation with the three-kernel path;
+    // the handle stays on that path.
+    rc = fused_recover(h);
+    if (rc) return rc;
+  }
+  const int rc = eval_launch(h, se3, grad7 != nullptr, guard.alone);
   if (rc) return rc;
   return eval_finish(h, cost, grad7);
 }
@@ -1625,14 +1641,24 @@ int nidreg_eval_multi(nidreg_handle* const* handles, int n, const double* init_s
       }
     }
   }
+  // progress priority only for a pair that is alone on its device
+  std::vector<std::unique_ptr<InflightGuard>> guards(static_cast<size_t>(n));
+  std::vector<char> alone(static_cast<size_t>(n), 0);
+  for (int i = 0; i < n; i++) {
+    if (handles[i]->set) continue;
+    guards[size_t(i)].reset(new InflightGuard(handles[i]->device));
+    int same = 0;
+    for (int j = 0; j < n; j++) same += (!handles[j]->set && handles[j]->device == handles[i]->device) ? 1 : 0;
+    alone[size_t(i)] = guards[size_t(i)]->alone && same == 1;
+  }
   for (int i = 0; i < n; i++) {
     if (handles[i]->set) continue;  // a pair sharded over several GPUs: evaluated through its set below
-    const int rc = eval_launch_first(handles[i], se3);  // every pair's (every GPU's) histogram pass is running ...
+    const int rc = eval_launch_first(handles[i], se3, alone[size_t(i)] != 0);  // every pair's (every GPU's) histogram pass is running ...
     if (rc) return rc;
   }
   for (int i = 0; i < n; i++) {
     if (handles[i]->set) continue;
-    const int rc = eval_launch_rest(handles[i], grad7 != nullptr);  // ... while the rest is queued behind it
+    const int rc = eval_launch_rest(handles[i], grad7 != nullptr, alone[size_t(i)] != 0);  // ... while the rest is queued behind it
     if (rc) return rc;
   }
   double csum = 0.0, gsum[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -1825,7 +1851,7 @@ int nidreg_shard_finish(nidreg_handle* h, double* cost, double* grad7) {
 
 int nidreg_set_timing(nidreg_handle* h, int enable) {
   if (!h) return fail(NIDREG_ERR_INVALID, "nidreg_set_timing: null handle");
-  h->timing = enable != 0;
+  h->timing = enable == 2 ? 2 : (enable != 0 ? 1 : 0);  // 1: per-kernel events (three-kernel path); 2: the whole evaluation, whichever path runs
   return NIDREG_OK;
 }
 
@@ -1835,7 +1861,9 @@ int nidreg_get_timing(nidreg_handle* h, float* ms6) {
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipEventSynchronize(h->ev[5]));
   HIP_TRY(hipEventElapsedTime(&ms6[0], h->ev[0], h->ev[5]));
-  for (int k = 0; k < 5; k++) HIP_TRY(hipEventElapsedTime(&ms6[1 + k], h->ev[k], h->ev[k + 1]));
+  for (int k = 0; k < 5; k++) ms6[1 + k] = 0.f;
+  if (h->timing == 1)
+    for (int k = 0; k < 5; k++) HIP_TRY(hipEventElapsedTime(&ms6[1 + k], h->ev[k], h->ev[k + 1]));
   return NIDREG_OK;
 }
 
@@ -1882,7 +1910,7 @@ int nidreg_get_info(nidreg_handle* h, int64_t* info8) {
     info8[6] = 0;
     for (nidreg_handle* sh : h->set->shards) info8[6] += sh->num_points;
   }
-  info8[7] = (h->rec64 ? 0 : 1) | (int64_t(1 << h->cshift) << 8);
+  info8[7] = (h->rec64 ? 0 : 1) | (h->fused_ok && !h->fused_off ? 2 : 0) | (int64_t(1 << h->cshift) << 8);
   return NIDREG_OK;
 }
 

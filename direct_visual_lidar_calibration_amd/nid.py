@@ -234,7 +234,10 @@ class _Handle:
         return joint, inl.value, frac.value
 
     def set_timing(self, enable=True):
-        _lib.check(self._lib.nidreg_set_timing(self.h, 1 if enable else 0), "nidreg_set_timing")
+        """True / 1: HIP events around every kernel (the evaluation then runs as three kernels); 2: events around the
+        whole evaluation, whichever route runs it (timing_ms()["total"]); False / 0: off."""
+        mode = 2 if enable == 2 and enable is not True else (1 if enable else 0)
+        _lib.check(self._lib.nidreg_set_timing(self.h, mode), "nidreg_set_timing")
 
     def timing_ms(self):
         ms = (ctypes.c_float * 6)()
@@ -247,6 +250,7 @@ class _Handle:
         keys = ["record_bytes", "num_chunks", "columns_per_group", "frac_bits", "lds_bytes", "image_pitch", "num_points", "float32_records"]
         out = dict(zip(keys, [int(x) for x in v]))
         out["lds_copies"] = out["float32_records"] >> 8
+        out["fused"] = (out["float32_records"] >> 1) & 1  # evaluations run as one kernel (k_fused) when alone on the device
         out["float32_records"] &= 1
         return out
 

@@ -265,7 +265,9 @@ int nidreg_get_timing(nidreg_handle* h, float* ms6);
 
 /* layout facts for DESIGN.md / bench: [0]=record bytes per point on device, [1]=number of chunks,
  * [2]=columns per group, [3]=fixed-point fraction bits, [4]=LDS bytes per workgroup,
- * [5]=padded image pitch, [6]=points stored, [7]=bit0: float32 records, bits 8..: LDS copies per histogram cell */
+ * [5]=padded image pitch, [6]=points stored, [7]=bit0: float32 records, bit1: nidreg_eval runs as ONE fused kernel when the
+ * handle has its device to itself (csrc/nid_fused.hpp; NIDREG_FUSED=0 in the environment at creation keeps three kernels),
+ * bits 8..: LDS copies per histogram cell */
 int nidreg_get_info(nidreg_handle* h, int64_t* info8);
 
 const char* nidreg_last_error(void);

@@ -1,4 +1,4 @@
-"""Helper of test_combine.py (run in its own process so that NIDREG_COMBINE is read when the library takes its first call):
+"""Helper of test_concurrent_callers.py (its own process: NIDREG_FUSED is read when a handle is created):
 k pairs evaluated one by one, then by k threads that call their own NIDCost at the same pose behind a barrier -- the
 reference's OpenMP loop over pairs (visual_camera_calibration.cpp:161).  Prints one JSON line."""
 import json
@@ -38,11 +38,12 @@ for t in th:
 for t in th:
     t.join()
 dt = time.perf_counter() - t0
-# the cost comes from the integer histogram: identical bit for bit whatever the tiling; the gradient's workgroup partials are
-# summed per chunk, and a group has its own chunk table: equal to rounding
+# the cost comes from the integer histogram and integer entropy sums: identical bit for bit whichever route (one fused kernel
+# when the caller is alone on the device, three kernels otherwise) evaluates it; the gradient's workgroup partials follow
+# the route's chunk table: equal to rounding
 same = all(a[0] == b[0] and a[1] == b[1] and np.allclose(a[2], b[2], rtol=1e-12, atol=1e-15) for ra, rb in zip(single, threaded) for a, b in zip(ra, rb))
 maxdiff = max(abs(a[1] - b[1]) for ra, rb in zip(single, threaded) for a, b in zip(ra, rb))
-# mixed use afterwards: different poses per thread (nothing to combine: evaluated one by one by the collecting thread)
+# mixed use afterwards: different poses per thread
 mixed = [None] * k
 
 
@@ -57,7 +58,7 @@ for t in th:
 for t in th:
     t.join()
 mixed_ok = all(mixed[i][1] == single[i % len(poses)][i][1] for i in range(k))
-print(json.dumps({"pairs": k, "combine": os.environ.get("NIDREG_COMBINE", ""), "cost_identical_grad_equal": bool(same), "max_cost_diff": float(maxdiff), "mixed_poses_ok": bool(mixed_ok),
+print(json.dumps({"pairs": k, "fused": os.environ.get("NIDREG_FUSED", ""), "cost_identical_grad_equal": bool(same), "max_cost_diff": float(maxdiff), "mixed_poses_ok": bool(mixed_ok),
                   "us_per_multi_eval": round(1e6 * dt / len(poses), 1)}))
 for c in costs:
     c.close()

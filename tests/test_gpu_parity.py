@@ -488,6 +488,51 @@ def test_headline_workload_10m_points_matches_oracle():
     cost.close()
 
 
+def test_nearest_twin_10m_points_bit_exact():
+    """CostCalculatorNID::calculate (cost_calculator_nid.cpp:21-67) on the headline cloud: the integer joint histogram of
+    10M points bit for bit against the oracle's serial loop (~1 s of CPU), NID to 1e-12."""
+    import torch
+
+    s = synth.make_scene("pinhole_1080p", num_points=10_000_000, seed=20250523 + 2, device="cuda:0" if torch.cuda.is_available() else "cpu")
+    proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
+    max_fov = oracle_lib.estimate_camera_fov(s.model, s.intrinsics, s.distortion, s.width, s.height)
+    calc = nid.CostCalculatorNID(proj, s.image_u8, s.points, s.intensities, nid.NIDCostParams(256), max_fov=max_fov)
+    rng = np.random.default_rng(77)
+    T = se3.to_matrix(synth.random_pose_near(s.T_camera_lidar_true, rng))
+    rc, rh = oracle_lib.cost_calculator_nid(s.model, s.intrinsics, s.distortion, s.image_u8, s.points, s.intensities, 256, max_fov, T, want_hist=True)
+    c = calc.calculate(T)
+    fx, inl, frac = calc.histogram_fixed()
+    assert frac == 0 and np.array_equal(fx, rh) and int(fx.sum()) == inl
+    assert abs(c - rc) <= 1e-12
+    calc.close()
+
+
+def test_dense_map_50m_points_4k_image_matches_oracle():
+    """BASELINE configs[4] at its full size: 50M-point map, 3840x2160 plumb_bob, 256 bins.  At this N the fixed-point
+    fraction drops to 36 bits (62 - bits(N)), the 32-bit chunk arithmetic sees offsets up to 8e8 bytes and the 8 MB bin image
+    no longer fits one XCD's L2; the oracle runs with its OpenMP split over points on every host core."""
+    import torch
+
+    s = synth.make_scene("pinhole_4k", num_points=50_000_000, seed=20250523 + 5, device="cuda:0" if torch.cuda.is_available() else "cpu")
+    proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
+    cost = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, 256)
+    info = cost.info()
+    assert info["num_points"] == 50_000_000 and info["frac_bits"] == 36
+    rng = np.random.default_rng(4321)
+    x = synth.random_pose_near(s.T_camera_lidar_true, rng)
+    ref = oracle_nid(s, 256, x, want_hist=True, threads=oracle_lib.num_threads())
+    ok, c, g = cost(x)
+    assert ok and ref["ok"] and abs(c - ref["cost"]) <= 1e-10
+    assert np.allclose(g, ref["grad"], rtol=1e-7, atol=1e-10)
+    joint, hi, hp = cost.histograms()
+    # 2^-36 per tap, <= ~12 000 taps in the fullest bin
+    assert np.abs(joint - ref["hist"]).max() <= 1e-7 and np.array_equal(hp, ref["hist_points"])
+    assert hp.sum() == ref["hist_points"].sum()
+    ok2, c2, g2 = cost(x, want_grad=False)
+    assert ok2 and c2 == c
+    cost.close()
+
+
 @pytest.mark.parametrize("model", ["plumb_bob", "fisheye", "equirectangular"])
 def test_device_resident_cull_and_build_matches_host_path(model):
     """nidreg_create_from_cloud: ViewCulling + bucketing + sort + gather on the GPU gives the same handle

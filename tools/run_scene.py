@@ -34,6 +34,22 @@ NW = 200
 for k in range(NW):
     cost(poses[k & 7])
 wall_ms = (time.perf_counter() - t0) * 1e3 / NW
+# the same through nidreg_eval_batch (no Python between the evaluations: what bench.py times), median of 5 blocks
+block = np.ascontiguousarray([poses[k & 7] for k in range(50)])
+wb = []
+for _ in range(5):
+    t0 = time.perf_counter()
+    cost.eval_batch(block)
+    wb.append((time.perf_counter() - t0) * 1e3 / len(block))
+wall_batch_ms = float(np.median(wb))
+# the whole evaluation between two HIP events, whichever route runs it (one fused kernel unless NIDREG_FUSED=0)
+cost.set_timing(2)
+whole = []
+for k in range(max(steps, 10)):
+    cost(poses[k & 7])
+    if k >= 2:
+        whole.append(cost.timing_ms()["total"])
+whole_ms = float(np.mean(whole))
 cost.set_timing(True)
 rng = np.random.default_rng(1)
 acc = {}
@@ -43,4 +59,4 @@ for k in range(steps):
     if k >= 2:
         for key, v in cost.timing_ms().items():
             acc.setdefault(key, []).append(v)
-print(json.dumps({"prec": prec, "bins": bins, "info": cost.info(), "kernel_ms": {k: round(float(np.mean(v)), 4) for k, v in acc.items()}, "wall_ms": round(wall_ms, 4), "last_cost": c, "last_grad": [float(v) for v in g], "evals_per_s": round(1e3 / float(np.mean(acc["total"])), 1) if "total" in acc else None}))
+print(json.dumps({"prec": prec, "bins": bins, "info": cost.info(), "kernel_ms": {k: round(float(np.mean(v)), 4) for k, v in acc.items()}, "wall_ms": round(wall_ms, 4), "wall_batch_ms": round(wall_batch_ms, 4), "whole_eval_event_ms": round(whole_ms, 4), "fused_env": os.environ.get("NIDREG_FUSED", ""), "last_cost": c, "last_grad": [float(v) for v in g], "evals_per_s": round(1e3 / float(np.mean(acc["total"])), 1) if "total" in acc else None}))
