@@ -48,8 +48,9 @@ struct FusedArgs {
   double* out;
   double* out_host;
   double tag;
-  unsigned int* counters;     // [1] gradient ticket, [3] grid barrier, [4] entropy ticket (cost-only evaluations)
-  unsigned int bar_base;      // value of counters[3] when this launch starts
+  unsigned int* counters;     // [1] gradient ticket, [4] entropy ticket (cost-only evaluations)
+  unsigned int* barrier;      // grid-barrier block (kBarrierWords words, zero at handle creation)
+  unsigned int bar_base;      // number of grid barriers this handle has completed before this launch
   unsigned int* abort_flag;   // device word; non-zero = a barrier timed out, the evaluation was abandoned
   double* abort_host;         // host-mapped mirror (nullable)
   unsigned long long timeout_ticks;  // of the 100 MHz wall clock
@@ -65,18 +66,36 @@ __device__ __forceinline__ void store_agent(u64* p, u64 v) { __hip_atomic_store(
 __device__ __forceinline__ void store_agent(long long* p, long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void store_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// All workgroups of the grid meet: counter reaches `target` (wrap-safe compare; the host advances the base per launch).
+// Grid barrier, two levels.  Device-scope atomics on ONE word are serialised at the memory side (tens of nanoseconds each):
+// 512 workgroups arriving at one counter within a few microseconds queue up for ~20 us (measured: the first version of this
+// kernel, with a flat counter per barrier, was 23 us slower than the three kernels it replaces,
+// profiles/r03a_fused_flat_barrier_kernel_stats.csv).  Here a workgroup arrives at one of kBarrierGroups group counters
+// (blockIdx mod kBarrierGroups; 128 bytes apart), the last arrival of a group arrives at the top counter, and the last of
+// those publishes the barrier's number in a `go` word that everybody polls (plain sc1 loads, no read-modify-write).
+// Counters run on and are never reset: barrier number b (1, 2, ... over the handle's lifetime; the host passes how many
+// were completed before the launch) is complete for a group of m members when its counter reaches m b.
 // Precondition: everything this workgroup published was stored by device-scope atomics or agent-scope stores.
 // Returns false when the evaluation is abandoned (timeout here or in another workgroup).
-__device__ __forceinline__ bool grid_barrier(unsigned int* ctr, unsigned int target, unsigned int* abort_flag, unsigned long long timeout_ticks, int* s_flag) {
+constexpr int kBarrierGroups = 32;
+constexpr int kBarrierStride = 32;  // words between counters: 128 bytes
+constexpr int kBarrierWords = (kBarrierGroups + 2) * kBarrierStride;  // groups, top, go
+__device__ __forceinline__ bool grid_barrier(unsigned int* bar, unsigned int b, unsigned int* abort_flag, unsigned long long timeout_ticks, int* s_flag) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this thread's stores / atomics have been acknowledged
   __syncthreads();
   if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned int nW = gridDim.x, w = blockIdx.x;
+    const unsigned int groups = nW < unsigned(kBarrierGroups) ? nW : unsigned(kBarrierGroups);
+    const unsigned int g = w % groups;
+    const unsigned int members = nW / groups + (g < nW % groups ? 1u : 0u);
+    unsigned int* go = bar + (kBarrierGroups + 1) * kBarrierStride;
+    if (__hip_atomic_fetch_add(bar + g * kBarrierStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == members * b) {
+      if (__hip_atomic_fetch_add(bar + kBarrierGroups * kBarrierStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == groups * b)
+        __hip_atomic_store(go, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     int ok = 1;
     const unsigned long long t0 = wall_clock64();
     unsigned int spins = 0;
-    while (int(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+    while (int(__hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - b) < 0) {
       __builtin_amdgcn_s_sleep(2);
       if ((spins++ & 15u) == 0u) {
         if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || wall_clock64() - t0 > timeout_ticks) {
@@ -93,6 +112,14 @@ __device__ __forceinline__ bool grid_barrier(unsigned int* ctr, unsigned int tar
   __syncthreads();
   return *s_flag != 0;
 }
+
+#ifdef NID_FUSED_STAMP
+// development aid (tools/fused_stamps.py): wall-clock stamps (100 MHz) of every workgroup at the phase boundaries
+__device__ unsigned long long g_fused_stamp[8 * 2048];
+#define NID_FSTAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_fused_stamp[8 * blockIdx.x + (k)] = wall_clock64(); } while (0)
+#else
+#define NID_FSTAMP(k) do { } while (0)
+#endif
 
 // Row segments of phase 2: with nW >= B workgroups a row of hist_image is cut into `segs` segments of L columns, one per
 // workgroup (workgroups beyond B * segs have no entropy work); with fewer workgroups each takes ceil(B / nW) whole rows.
@@ -194,11 +221,14 @@ __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_fused(PosePa
   int* s_flag = reinterpret_cast<int*>(s_row + kNW);
 
   // ---- phase 1: joint histogram of this chunk
+  NID_FSTAMP(0);
   spline_hist_body<MODEL, Rec, real, WIDE, kT>(pts, ch, a.img, a.pitch, a.W, a.H, pose, cam, B, GW, cshift, a.dn_scale, a.hist, smem, a.prio != 0);
-  if (!grid_barrier(a.counters + 3, a.bar_base + unsigned(nW), a.abort_flag, a.timeout_ticks, s_flag)) {
+  NID_FSTAMP(1);
+  if (!grid_barrier(a.barrier, a.bar_base + 1u, a.abort_flag, a.timeout_ticks, s_flag)) {
     if (tid == 0 && a.abort_host) *a.abort_host = 1.0;
     return;
   }
+  NID_FSTAMP(2);
 
   // ---- phase 2: this workgroup's row segment(s): sum p log(p + eps) (fixed point), row-segment sums
   {
@@ -251,6 +281,7 @@ __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_fused(PosePa
       for (long long k = (long long)w * kT + tid; k < a.zero_words; k += (long long)nW * kT) store_agent(a.zero_buf + k, u64(0));
   }
 
+  NID_FSTAMP(3);
   if (!a.want_grad) {
     // cost only: the last workgroup to get here finalises (every partial above was stored at agent scope)
     if (last_workgroup_arrives<true>(a.counters + 4, unsigned(nW), s_flag)) {
@@ -265,10 +296,11 @@ __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_fused(PosePa
     }
     return;
   }
-  if (!grid_barrier(a.counters + 3, a.bar_base + 2u * unsigned(nW), a.abort_flag, a.timeout_ticks, s_flag)) {
+  if (!grid_barrier(a.barrier, a.bar_base + 2u, a.abort_flag, a.timeout_ticks, s_flag)) {
     if (tid == 0 && a.abort_host) *a.abort_host = 1.0;
     return;
   }
+  NID_FSTAMP(4);
 
   // ---- phase 3: entropies -> G tile -> gradient of this chunk
   const EntropyScalars e = fused_scalars<kT>(a, B, nW, s_phi, s_redk, w == 0);
@@ -298,13 +330,16 @@ __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_fused(PosePa
     }
   }
   __syncthreads();
+  NID_FSTAMP(5);
 
   double acc[12];
 #pragma unroll
   for (int k = 0; k < 12; k++) acc[k] = 0.0;
   spline_grad_loop<MODEL, Rec, real, WIDE ? TAP_WIDE : TAP_COPIES, kT>(pts, ch, a.img, a.pitch, a.W, a.H, pose, cam, B, GW, cshift, gtile, acc, a.prio != 0);
+  NID_FSTAMP(6);
   __syncthreads();  // s_red aliases the reduction scratch of fused_scalars
   grad_reduce_store<kT>(acc, s_red, a.partials, unsigned(w), unsigned(nW));
+  NID_FSTAMP(7);
   if (last_workgroup_arrives<true>(a.counters + 1, unsigned(nW), s_flag))
     grad_final_body<kT>(a.partials, nW, a.q[0], a.q[1], a.q[2], a.q[3], a.out, a.out_host, a.tag, s_red);
 }

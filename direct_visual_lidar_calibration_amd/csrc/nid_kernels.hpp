@@ -249,6 +249,49 @@ __device__ __forceinline__ void set_progress_priority(bool on, uint32_t done, ui
 #endif
 }
 
+// ---- one pair spread over several GPUs (protocol: see the k_entropy_owned section below)
+constexpr int kMaxShards = 16;
+struct ShardTable {            // device-resident, one per shard, constant over the set's lifetime
+  u64* flags[kMaxShards];      // flag block of every shard: [2][kMaxShards] words, [phase][source shard]
+  u64* gather[kMaxShards];     // gather block of every shard (layout below)
+  int n, me;
+  int col_lo, col_hi;          // histogram columns this shard owns
+};
+// gather block (64-bit words)
+constexpr int kGatherS = 0;                      // [kMaxShards] inlier count of shard g
+constexpr int kGatherHj = kMaxShards;            // [kMaxShards] fixed-point entropy partial of shard g
+constexpr int kGatherRows = 2 * kMaxShards;      // [kMaxShards][B] row sums over shard g's columns
+__host__ __device__ __forceinline__ int gather_cols(int B) { return 2 * kMaxShards + kMaxShards * B; }  // [B] column sums (each written by its owner)
+__host__ __device__ __forceinline__ int gather_words(int B) { return gather_cols(B) + B; }
+
+__device__ __forceinline__ u64 load_sys(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void store_sys(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+// waits until flag word `p` reaches `seq`; false after ~timeout_ticks of the 100 MHz wall clock
+__device__ __forceinline__ bool wait_flag(const u64* p, u64 seq, unsigned long long timeout_ticks) {
+  const unsigned long long t0 = wall_clock64();
+  while (load_sys(p) < seq) {
+    __builtin_amdgcn_s_sleep(2);
+    if (wall_clock64() - t0 > timeout_ticks) return false;
+  }
+  return true;
+}
+
+// the histogram kernels' last workgroup: S_g to every shard, then flag 0.  Called by thread 0 of every workgroup AFTER its
+// own inlier-count atomic (only that word is published here; the tile flushes of the other waves may still be in flight).
+__device__ __forceinline__ void shard_announce(const ShardTable* tab, u64 seq, unsigned int* ticket, const u64* inlier_word) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (t != gridDim.x - 1u) return;
+  __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const u64 S = __hip_atomic_load(inlier_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int n = tab->n, me = tab->me;
+  for (int q = 0; q < n; q++) store_sys(tab->gather[q] + kGatherS + me, S);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int q = 0; q < n; q++) store_sys(&tab->flags[q][0 * kMaxShards + me], seq);
+}
+
 // ------------------------------------------------------------------------------------------
 // pass A (SPLINE): joint histogram with bicubic B-spline soft assignment.
 // LDS: tile[GW*B << cshift] u64 (this workgroup's GW histogram columns, 2^cshift copies) + 1 u32 inlier counter.
@@ -409,7 +452,8 @@ __host__ __device__ __forceinline__ size_t spline_hist_lds_bytes(int B, int GW, 
 template <int MODEL, typename Rec, typename real, bool WIDE, bool MULTI>
 __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_spline_hist(
   const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint8_t* __restrict__ img, int pitch, int W, int H, PoseParams<real> pose, CamParams<real> cam, int B,
-  int GW, int cshift, double dn_scale, u64* __restrict__ hist, int prio, const MultiEntry* __restrict__ multi, typename multi_dyn_of<MULTI>::type dyn) {
+  int GW, int cshift, double dn_scale, u64* __restrict__ hist, int prio, const ShardTable* __restrict__ ann, u64 ann_seq, unsigned int* ann_ticket,
+  const MultiEntry* __restrict__ multi, typename multi_dyn_of<MULTI>::type dyn) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int kT = WIDE ? kWideThreads : kThreads;
   const Chunk ch = chunks[blockIdx.x];
@@ -421,6 +465,8 @@ __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_spline_hist(
     dn_scale = e.k16;
   }
   spline_hist_body<MODEL, Rec, real, WIDE, kT>(pts, ch, img, pitch, W, H, pose, cam, B, GW, cshift, dn_scale, hist, smem, prio != 0);
+  // a shard of a pair spread over several GPUs: the last workgroup sends this shard's inlier count to every shard
+  if (!MULTI && ann && threadIdx.x == 0) shard_announce(ann, ann_seq, ann_ticket, hist + size_t(WIDE ? 256 : B) * size_t(WIDE ? 256 : B) + kTailInliers);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -431,7 +477,8 @@ __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_spline_hist(
 template <int MODEL, typename Rec, typename real, bool MULTI>
 __global__ __launch_bounds__(kThreads) void k_nearest_hist(
   const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint8_t* __restrict__ img, int pitch, int W, int H, IsoParams<real> iso, CamParams<real> cam, int B,
-  int GW, int cshift, real cos_fov, u64* __restrict__ hist, const MultiEntry* __restrict__ multi, typename multi_dyn_of<MULTI>::type dyn) {
+  int GW, int cshift, real cos_fov, u64* __restrict__ hist, const ShardTable* __restrict__ ann, u64 ann_seq, unsigned int* ann_ticket, const MultiEntry* __restrict__ multi,
+  typename multi_dyn_of<MULTI>::type dyn) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u64* tile = reinterpret_cast<u64*>(smem);
   const int tile_n = GW * B;
@@ -511,6 +558,7 @@ __global__ __launch_bounds__(kThreads) void k_nearest_hist(
   __syncthreads();
   if (tid < GW && s_colsum[tid]) atomicAdd(&hist[size_t(B) * size_t(B) + kTailWords + col0 + uint32_t(tid)], s_colsum[tid]);
   if (tid == 0 && *s_inl) atomicAdd(&hist[size_t(B) * size_t(B) + kTailInliers], u64(*s_inl));
+  if (!MULTI && ann && tid == 0) shard_announce(ann, ann_seq, ann_ticket, hist + size_t(B) * size_t(B) + kTailInliers);
 }
 
 // nid_cost.hpp:86-104 from the three entropies (fixed point, see ent_fixed) and the inlier count: NID = (Hj - MI) / Hj,
@@ -544,10 +592,9 @@ __device__ __forceinline__ EntropyScalars entropy_scalars(long long hi_k, long l
 // (partition of unity: the 16 weights of an inlier sum to 1), S = inlier count.
 // nid_cost.hpp:86-104: NID = (Hj - MI) / Hj, MI = Hi + Hp - Hj.
 __device__ __forceinline__ void entropy_final_body(
-  const u64* hist, int B, int NG, double inv_unit, const long long* part_hj, const u64* row_part, const u64* col_sum, double* phi_q, double* hist_image_out, double* hist_points_out,
+  double S, int B, int NG, double inv_unit, const long long* part_hj, const u64* row_part, const u64* col_sum, double* phi_q, double* hist_image_out, double* hist_points_out,
   EntropyScalars* scal, double* out, double* out_host, double tag, long long* s_red) {
   const int tid = threadIdx.x;
-  const double S = double(hist[size_t(B) * size_t(B) + kTailInliers]);
   long long hi_acc = 0, hp_acc = 0, hj_acc = 0;
   for (int r = tid; r < B; r += kThreads) {
     u64 t = 0;
@@ -673,101 +720,143 @@ __global__ __launch_bounds__(kEntropyThreads) void k_entropy(
   // the tail's loops stride by kThreads = 256 over B <= 256 items: threads beyond 255 find nothing to do but take part
   // in its barriers and (with zeros) in its wave reductions -- s_red holds 3 slots for each of the 16 waves
   if (last_workgroup_arrives<false>(counter, unsigned(nblocks), &s_flag))
-    entropy_final_body(hist, B, nblocks, inv_unit, part_hj, row_part, col_sum, phi_q, hist_image_out, hist_points_out, scal, out, out_host, tag, s_red);
+    entropy_final_body(S, B, nblocks, inv_unit, part_hj, row_part, col_sum, phi_q, hist_image_out, hist_points_out, scal, out, out_host, tag, s_red);
 }
 
 #endif  // NID_COMMON_KERNELS
 
 #ifdef NID_COMMON_KERNELS
 // ------------------------------------------------------------------------------------------
-// One pair whose points are sharded over several GPUs: NID is nonlinear in the histogram,
-// so the per-shard fixed-point partial histograms are summed (exactly: they are integers) before the
-// entropy tail.  All shards are driven by ONE host process (nidreg.hip, ShardSet), every buffer below is
-// fine-grained device memory mapped into every peer, and the all-reduce is ONE kernel per shard, launched
-// on the shard's stream right behind its histogram kernel -- a one-shot reduce-scatter + all-gather over
-// the point-to-point xGMI links (each shard pulls its 1/n slice from every peer, pushes the sums back to
-// every peer; 2 x (n-1)/n x 514 KB per GPU at 256 bins), with no host round trip and no stream-level
-// cross-device dependency (hipStreamWaitEvent across devices costs more than the kernels it orders):
-//   phase 0  "my partial histogram is complete" (it is: the previous kernel on this stream wrote it) ->
-//            push the evaluation number into every peer's flag block; wait for every peer's number
-//   reduce   slice `me` of the words: sum over the shards' partials, store the sum into every shard's FULL buffer
-//   phase 1  last workgroup: system-scope release, push "my slice is delivered" to every peer, then wait for every
-//            peer's phase-1 number -- the kernel ends only when this shard's FULL buffer is complete, so the
-//            entropy / gradient kernels queued behind it need nothing else.
-// Flag waits are bounded (wall clock): a lost peer sets *err instead of hanging the GPU.
-constexpr int kMaxShards = 16;
-struct ExchangeArgs {
-  const u64* part[kMaxShards];  // this evaluation's partial histogram of every shard
-  u64* full[kMaxShards];        // all-reduced histogram buffer of every shard
-  u64* flags[kMaxShards];       // flag block of every shard: [2][kMaxShards] words, [phase][source shard]
-  int n, me;
-  int words;
-  u64 seq;
-};
-
-__device__ __forceinline__ u64 load_sys(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ void store_sys(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-
-// waits until flag word `p` reaches `seq`; false after ~timeout_ticks of the 100 MHz wall clock
-__device__ __forceinline__ bool wait_flag(const u64* p, u64 seq, unsigned long long timeout_ticks) {
-  const unsigned long long t0 = wall_clock64();
-  while (load_sys(p) < seq) {
-    __builtin_amdgcn_s_sleep(2);
-    if (wall_clock64() - t0 > timeout_ticks) return false;
-  }
-  return true;
+// One pair spread over several GPUs by ONE host process (nidreg.hip ShardSet): the points are partitioned by
+// their pose-independent histogram column -- GPU g owns a contiguous range of column groups, balanced by their point
+// counts -- so the shards' joint histograms have DISJOINT support and nothing of the B x B table ever crosses a link.
+// What the NID needs from the other GPUs is: the total inlier count S (inside the logarithm: p = h / S), then per shard
+// one fixed-point entropy partial, the B row sums of its columns (hist_image is a sum over ALL columns) and the column
+// sums of its columns -- an all-gather of (2 + B + B/n) words, pushed straight into every peer's fine-grained gather block:
+//   k_*_hist            last workgroup (ticket): S_g -> every peer, then flag 0
+//   k_entropy_owned     waits for every flag 0; sum p log(p + eps) and row sums over the OWNED columns; last workgroup:
+//                       pushes the partials to every peer, then flag 1
+//   k_entropy_gather    one workgroup: waits for every flag 1; entropy tail on the gathered partials (integer sums: every
+//                       shard computes the same three entropies, hence the same cost, bit for bit) -> scalars for k_spline_grad
+//   k_spline_grad       the shard's own points against its own columns of G; the host adds the n gradient partials.
+// Every in-kernel wait is for something a kernel launched EARLIER (in the set's launch order) produces, and the host
+// serialises the sets of a process per device: no circular wait (nidreg.hip set_eval).  Waits are bounded by the wall clock:
+// a lost peer becomes an error code, not a hung GPU.
+// a shard without points launches no histogram kernel: announce S_g = 0
+__global__ void k_shard_announce(const ShardTable* tab, u64 seq) {
+  if (threadIdx.x != 0) return;
+  const int n = tab->n, me = tab->me;
+  for (int q = 0; q < n; q++) store_sys(tab->gather[q] + kGatherS + me, u64(0));
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int q = 0; q < n; q++) store_sys(&tab->flags[q][0 * kMaxShards + me], seq);
 }
 
-__global__ __launch_bounds__(kThreads) void k_shard_exchange(ExchangeArgs a, unsigned int* counter, double* err_out, double* err_host, unsigned long long timeout_ticks) {
+// entropy partials over the OWNED columns (k_entropy's thread layout: 16 columns per 1024-thread workgroup), pushed to
+// every shard by the last workgroup.  err_out / err_host: set to `seq` when a flag wait times out.
+__global__ __launch_bounds__(kEntropyThreads) void k_entropy_owned(
+  const u64* __restrict__ hist, int B, double inv_unit, const ShardTable* __restrict__ tab, u64 seq, long long* part_hj, u64* row_part, unsigned int* counter,
+  u64* __restrict__ zero_buf, long long zero_words, double* err_out, double* err_host, unsigned long long timeout_ticks) {
+  __shared__ long long s_red[kEntropyWaves];
+  __shared__ u64 s_row[3][256];
   __shared__ int s_flag;
   __shared__ int s_bad;
   const int tid = threadIdx.x;
+  const int j = blockIdx.x, nblocks = int(gridDim.x);
+  const int n = tab->n, me = tab->me;
   if (tid == 0) s_bad = 0;
   __syncthreads();
-  if (blockIdx.x == 0 && tid < a.n) store_sys(&a.flags[tid][0 * kMaxShards + a.me], a.seq);
-  if (tid < a.n && !wait_flag(&a.flags[a.me][0 * kMaxShards + tid], a.seq, timeout_ticks)) s_bad = 1;
+  if (tid < n && !wait_flag(&tab->flags[me][0 * kMaxShards + tid], seq, timeout_ticks)) s_bad = 1;
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-  const int lo = int((long long)a.words * a.me / a.n), hi = int((long long)a.words * (a.me + 1) / a.n);
-  for (int k = lo + int(blockIdx.x) * kThreads + tid; k < hi; k += int(gridDim.x) * kThreads) {
-    u64 v[kMaxShards];
+  u64 Sn = 0;
+  for (int g = 0; g < n; g++) Sn += load_sys(tab->gather[me] + kGatherS + g);
+  const double S = double(Sn);
+  // double-buffered histogram: clear the buffer the NEXT evaluation accumulates into
+  if (zero_buf)
+    for (long long k = (long long)j * kEntropyThreads + tid; k < zero_words; k += (long long)nblocks * kEntropyThreads) zero_buf[k] = 0;
+  const int r = tid & 255, q = tid >> 8;
+  const int c0 = tab->col_lo + j * kEntropyColsMax;
+  const int ncols = min(kEntropyColsMax, tab->col_hi - c0);
+  constexpr int kPer = kEntropyColsMax / (kEntropyThreads / 256);
+  u64 v[kPer];
 #pragma unroll
-    for (int p = 0; p < kMaxShards; p++) v[p] = p < a.n ? load_sys(a.part[p] + k) : 0;  // independent loads, all links at once
-    u64 sum = 0;
-#pragma unroll
-    for (int p = 0; p < kMaxShards; p++) sum += v[p];
-#pragma unroll
-    for (int q = 0; q < kMaxShards; q++)
-      if (q < a.n) store_sys(a.full[q] + k, sum);
+  for (int c = 0; c < kPer; c++) {
+    const int col = q * kPer + c;
+    v[c] = (r < B && col < ncols) ? hist[size_t(c0 + col) * size_t(B) + r] : 0;
   }
-  // every workgroup's stores -> one lane: system-scope release -> ticket; the last one announces and waits
+  const double scale = inv_unit / S;
+  long long acc = 0;
+  u64 row = 0;
+#pragma unroll
+  for (int c = 0; c < kPer; c++) {
+    if (v[c]) {
+      const double p = double(v[c]) * scale;
+      acc += ent_fixed(p * log(p + 1e-6));
+    }
+    row += v[c];
+  }
+  if (q > 0) s_row[q - 1][r] = row;
+  acc = wave_sum(acc);
+  if ((tid & 63) == 0) s_red[tid >> 6] = acc;
+  __syncthreads();
+  if (q == 0 && r < B) row_part[size_t(j) * size_t(B) + r] = row + s_row[0][r] + s_row[1][r] + s_row[2][r];
+  if (tid < 64) {
+    const long long t = wave_sum(tid < kEntropyWaves ? s_red[tid] : 0ll);
+    if (tid == 0) part_hj[j] = t;
+  }
+  if (s_bad && tid == 0) {
+    *err_out = double(seq);
+    if (err_host) *err_host = double(seq);
+  }
+  if (!last_workgroup_arrives<false>(counter, unsigned(nblocks), &s_flag)) return;
+  // the last workgroup: this shard's totals -> every shard's gather block
+  const u64* col_sum = hist + size_t(B) * size_t(B) + kTailWords;
+  if (tid < B) {
+    u64 t = 0;
+    for (int g = 0; g < nblocks; g++) t += row_part[size_t(g) * size_t(B) + tid];
+    for (int p = 0; p < n; p++) store_sys(tab->gather[p] + kGatherRows + me * B + tid, t);
+    if (tid >= tab->col_lo && tid < tab->col_hi) {
+      const u64 cs = col_sum[tid];
+      for (int p = 0; p < n; p++) store_sys(tab->gather[p] + gather_cols(B) + tid, cs);
+    }
+  }
+  if (tid == 0) {
+    long long t = 0;
+    for (int g = 0; g < nblocks; g++) t += part_hj[g];
+    for (int p = 0; p < n; p++) store_sys(tab->gather[p] + kGatherHj + me, u64(t));
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned int t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = (t == gridDim.x - 1u) ? 1 : 0;
-    if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_flag = last;
+    for (int p = 0; p < n; p++) store_sys(&tab->flags[p][1 * kMaxShards + me], seq);
   }
-  __syncthreads();
-  if (s_bad && tid == 0) {
-    *err_out = 1.0;
-    if (err_host) *err_host = 1.0;
-  }
-  if (!s_flag) return;
-  if (tid < a.n) store_sys(&a.flags[tid][1 * kMaxShards + a.me], a.seq);
-  if (tid < a.n && !wait_flag(&a.flags[a.me][1 * kMaxShards + tid], a.seq, timeout_ticks)) {
-    *err_out = 1.0;
-    if (err_host) *err_host = 1.0;
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 }
 
-// self-test pattern of the exchange (ShardSet creation): part[k] = f(shard, round, k)
-__global__ void k_shard_pattern(u64* part, int words, u64 shard, u64 round) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < words) part[k] = (shard + 1) * 1000003ull + round * 7919ull + u64(k) * (shard + 3);
+// entropy tail on the gathered partials: every shard runs it on the same integers
+__global__ __launch_bounds__(kThreads) void k_entropy_gather(
+  int B, double inv_unit, const ShardTable* __restrict__ tab, u64 seq, double* phi_q, double* hist_image_out, double* hist_points_out, EntropyScalars* scal, double* out,
+  double* out_host, double tag, double* err_out, double* err_host, unsigned long long timeout_ticks) {
+  __shared__ long long s_red[3 * kWaves];
+  __shared__ int s_bad;
+  const int tid = threadIdx.x;
+  const int n = tab->n, me = tab->me;
+  if (tid == 0) s_bad = 0;
+  __syncthreads();
+  if (tid < n && !wait_flag(&tab->flags[me][1 * kMaxShards + tid], seq, timeout_ticks)) s_bad = 1;
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  if (s_bad && tid == 0) {
+    *err_out = double(seq);
+    if (err_host) *err_host = double(seq);
+  }
+  const u64* gb = tab->gather[me];
+  u64 Sn = 0;
+  for (int g = 0; g < n; g++) Sn += load_sys(gb + kGatherS + g);
+  entropy_final_body(double(Sn), B, n, inv_unit, reinterpret_cast<const long long*>(gb + kGatherHj), gb + kGatherRows, gb + gather_cols(B), phi_q, hist_image_out, hist_points_out, scal,
+                     out, out_host, tag, s_red);
 }
 
 #endif  // NID_COMMON_KERNELS

@@ -32,3 +32,10 @@ template <> hipError_t launch_project<double>(int model, const double* intr, con
 }
 
 }  // namespace nidreg
+
+#ifdef NID_FUSED_STAMP
+// development aid: per-workgroup phase stamps of the most recent k_fused launch of this translation unit's instantiations
+extern "C" int nidreg_debug_fused_stamps(unsigned long long* out, int words) {
+  return int(hipMemcpyFromSymbol(out, HIP_SYMBOL(nidreg::g_fused_stamp), size_t(words) * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost));
+}
+#endif

@@ -16,6 +16,7 @@ namespace nidreg {
 
 struct Chunk;
 struct EntropyScalars;
+struct ShardTable;
 
 struct PassArgs {
   int model;
@@ -45,6 +46,10 @@ struct PassArgs {
   size_t lds_hist, lds_grad;
   const MultiEntry* multi;  // non-NULL: one grid over several pairs (chunks / nchunks are then the combined table)
   MultiDyn dyn;
+  // a shard of a pair spread over several GPUs (nid_kernels.hpp ShardTable): the histogram kernel's last workgroup announces
+  const ShardTable* ann;
+  unsigned long long ann_seq;
+  unsigned int* ann_ticket;
   int prio;  // progress priority (s_setprio) in the spline passes: set when the evaluation has its device to itself
   // the one-launch evaluation (k_fused, nid_fused.hpp); chunks / nchunks = the histogram pass's table
   unsigned long long* zero_buf;
@@ -55,6 +60,7 @@ struct PassArgs {
   double* hist_points;
   EntropyScalars* scal_out;
   unsigned int* counters;
+  unsigned int* barrier;
   unsigned int bar_base;
   unsigned int* abort_flag;
   double* abort_host;

@@ -71,13 +71,13 @@ static hipError_t launch_spline_hist_rec(const PassArgs& a) {
     hipError_t e = ensure_lds(k, a.lds_hist);                                                                                                          \
     if (e != hipSuccess) return e;                                                                                                                     \
     hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(THREADS), a.lds_hist, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, pose, cam, \
-                       a.B, a.GW, a.cshift, a.magic, a.hist, a.prio, a.multi, a.dyn);                                                                           \
+                       a.B, a.GW, a.cshift, a.magic, a.hist, a.prio, a.ann, a.ann_seq, a.ann_ticket, a.multi, a.dyn);                                                                           \
   } else {                                                                                                                                             \
     auto k = k_spline_hist<M, Rec, real, WIDE, false>;                                                                                                 \
     hipError_t e = ensure_lds(k, a.lds_hist);                                                                                                          \
     if (e != hipSuccess) return e;                                                                                                                     \
     hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(THREADS), a.lds_hist, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, pose, cam, \
-                       a.B, a.GW, a.cshift, a.magic, a.hist, a.prio, a.multi, NoMultiDyn());                                                                    \
+                       a.B, a.GW, a.cshift, a.magic, a.hist, a.prio, a.ann, a.ann_seq, a.ann_ticket, a.multi, NoMultiDyn());                                                                    \
   }
   if (a.wide) {  // B = 256, GW = 1, 32 copies, 512 threads (see k_spline_hist)
 #define NID_LAUNCH(M) NID_LAUNCH_W(M, true, kWideThreads)
@@ -228,6 +228,7 @@ static FusedArgs make_fused_args(const PassArgs& a) {
   f.out_host = a.out_host;
   f.tag = a.tag;
   f.counters = a.counters;
+  f.barrier = a.barrier;
   f.bar_base = a.bar_base;
   f.abort_flag = a.abort_flag;
   f.abort_host = a.abort_host;
@@ -310,13 +311,13 @@ static hipError_t launch_nearest_hist_rec(const PassArgs& a) {
     hipError_t e = ensure_lds(k, a.lds_hist);                                                                                                          \
     if (e != hipSuccess) return e;                                                                                                                     \
     hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(kThreads), a.lds_hist, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, iso, cam,  \
-                       a.B, a.GW, a.cshift, real(a.cos_fov), a.hist, a.multi, a.dyn);                                                                   \
+                       a.B, a.GW, a.cshift, real(a.cos_fov), a.hist, a.ann, a.ann_seq, a.ann_ticket, a.multi, a.dyn);                                                                   \
   } else {                                                                                                                                             \
     auto k = k_nearest_hist<M, Rec, real, false>;                                                                                                      \
     hipError_t e = ensure_lds(k, a.lds_hist);                                                                                                          \
     if (e != hipSuccess) return e;                                                                                                                     \
     hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(kThreads), a.lds_hist, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, iso, cam,  \
-                       a.B, a.GW, a.cshift, real(a.cos_fov), a.hist, a.multi, NoMultiDyn());                                                            \
+                       a.B, a.GW, a.cshift, real(a.cos_fov), a.hist, a.ann, a.ann_seq, a.ann_ticket, a.multi, NoMultiDyn());                                                            \
   }
   NID_MODEL_SWITCH(NID_LAUNCH)
 #undef NID_LAUNCH

@@ -83,12 +83,14 @@ struct nidreg_handle {
   Chunk* d_chunks_hist = nullptr;
   uint8_t* d_img = nullptr;
   u64* d_hist = nullptr;      // histogram of the current / most recent evaluation (accumulation target of pass A)
-  // a shard of a ShardSet accumulates its PARTIAL histogram into d_hist; the set's exchange kernel leaves the sum
-  // over all shards in d_hist_full, which is what the entropy and gradient kernels then read (NULL = d_hist itself)
-  u64* d_hist_full = nullptr;
-  bool finegrained = false;   // histogram buffers are fine-grained device memory (mapped into peer GPUs)
+  // a shard of a ShardSet owns a range of histogram COLUMN GROUPS: it holds the points of those columns only, and its
+  // histogram is the pair's histogram restricted to them (the other columns stay zero)
   struct ShardSet* set = nullptr;  // non-NULL on the leader (shard 0) of a set: nidreg_eval* fan out over the shards
   bool is_shard = false;
+  int shard_index = 0;
+  ShardTable* d_shard_tab = nullptr;  // device copy of this shard's ShardTable (peer flag / gather blocks, owned columns)
+  int col_lo = 0, col_hi = 0;         // owned histogram columns
+  size_t img_bytes = 0;
   // double buffering of the histogram (own buffers only): evaluation k accumulates into one buffer and
   // its k_entropy zeroes the OTHER one for evaluation k + 1, so no memset sits on the critical path
   u64* d_hist_buf[2] = {nullptr, nullptr};
@@ -123,7 +125,8 @@ struct nidreg_handle {
   bool fused_off = false;
   bool fused_inflight = false;
   size_t lds_fused = 0;
-  unsigned int bar_base = 0;  // value of d_counters[3] (grid-barrier counter) before the next fused launch
+  unsigned int* d_barrier = nullptr;  // grid-barrier block of k_fused (kBarrierWords words, carved from d_scratch)
+  unsigned int bar_base = 0;          // grid barriers completed by this handle's fused launches so far
   unsigned long long fused_timeout_ticks = 500000ull;  // 5 ms of the 100 MHz wall clock
 
   int timing = 0;  // 1: per-kernel events (three-kernel path), 2: events around whichever path runs
@@ -134,16 +137,23 @@ struct nidreg_handle {
   double last_t[3] = {0, 0, 0};
 };
 
-// One LiDAR-camera pair whose points are split over several GPUs (BASELINE north_star: "disjoint point slices with a
-// final all-reduce of the 2D histogram over xGMI"), driven by ONE host process: shard g lives on device g's own
-// nidreg_handle; per evaluation every shard runs  histogram -> k_shard_exchange (one-shot peer-to-peer all-reduce of the
-// fixed-point histogram, nid_kernels.hpp) -> entropy -> gradient  on its own stream, launched by its own host thread
-// (the caller for shard 0), and the host adds the n 7-double gradient partials (the chain rule is linear in them).
-// The cost is computed redundantly -- and bit-identically: same integer histogram -- on every shard.
+// One LiDAR-camera pair spread over several GPUs (BASELINE north_star: "disjoint point slices with a final all-reduce of the
+// 2D histogram over xGMI"), driven by ONE host process.  The slices are cut along the pose-independent histogram column
+// ("shard by histogram column"): shard g holds the points of a contiguous range of column groups, chosen from
+// the groups' point counts so that the shards are balanced to within one group.  The shards' histograms then have disjoint
+// support, the all-reduce of the B x B table degenerates to an all-gather of (2 + B + B/n) words per shard (inlier count,
+// entropy partial, row sums, column sums; nid_kernels.hpp k_entropy_owned), and the gradient pass of a shard needs only its
+// own columns of G.  Per evaluation every shard runs  histogram (+ inlier-count announce) -> k_entropy_owned ->
+// k_entropy_gather -> gradient  on its own stream, launched by its own host thread (the caller for shard 0), and the host adds
+// the n 7-double gradient partials.  Every shard computes the cost from the same gathered integers: bit-identical, which
+// the host CHECKS after every evaluation (a stale cross-device read cannot go unnoticed).
 struct ShardSet {
   std::vector<nidreg_handle*> shards;  // [0] = the leader (owns this set), the rest are owned by the set
   std::vector<u64*> flags;             // per shard: fine-grained [2][kMaxShards] flag block on its device
-  ExchangeArgs xargs[2][kMaxShards];   // per histogram buffer parity, per shard
+  std::vector<u64*> gather;            // per shard: fine-grained gather block (gather_words(B))
+  std::vector<int> lock_devices;       // distinct devices of the set, ascending: set_eval locks them in this order
+  bool colocated = false;              // a device is listed more than once (a 1-GPU box exercising the protocol)
+  bool poisoned = false;               // an evaluation failed half way: the flag sequence is no longer trustworthy
   u64 seq = 0;
   unsigned long long timeout_ticks = 300000000ull;  // 3 s of the 100 MHz wall clock
   // worker threads (one per shard >= 1): spin briefly on `gen`, then sleep on the condition variable
@@ -184,7 +194,7 @@ void free_handle(nidreg_handle* h) {
     if (h->d_hist_buf[0]) (void)hipFree(h->d_hist_buf[0]);
     if (h->d_hist_buf[1]) (void)hipFree(h->d_hist_buf[1]);
   }
-  if (h->d_hist_full) (void)hipFree(h->d_hist_full);
+  if (h->d_shard_tab) (void)hipFree(h->d_shard_tab);
   if (h->own_out && h->d_out) (void)hipFree(h->d_out);
   if (h->d_scratch) (void)hipFree(h->d_scratch);
   if (h->h_out) (void)hipHostFree(h->h_out);
@@ -194,7 +204,6 @@ void free_handle(nidreg_handle* h) {
   delete h;
 }
 
-inline u64* hist_source(const nidreg_handle* h) { return h->d_hist_full ? h->d_hist_full : h->d_hist; }
 
 // The fixed-point unit of the SPLINE histogram: U = 36 round(2^frac / 36) -- within 18 of 2^frac, and a multiple of 36
 // so that the constants U/36, 3U/36, 4U/36, 6U/36 of the x-weight polynomial are integers (nid_device.hpp
@@ -299,10 +308,15 @@ hipError_t begin_histogram(nidreg_handle* h, hipStream_t stream) {
 }
 hipError_t begin_histogram(nidreg_handle* h) { return begin_histogram(h, h->stream); }
 
-int launch_hist_spline(nidreg_handle* h, const double* se3, bool alone = false) {
+int launch_hist_spline(nidreg_handle* h, const double* se3, bool alone = false, u64 ann_seq = 0) {
   PassArgs a;
   fill_pass_args(h, a);
   a.prio = alone ? 1 : 0;
+  if (ann_seq) {  // a shard of a pair spread over several GPUs: the kernel's last workgroup announces the inlier count
+    a.ann = h->d_shard_tab;
+    a.ann_seq = ann_seq;
+    a.ann_ticket = h->d_counters + 2;
+  }
   if (h->d_chunks_hist) {
     a.chunks = h->d_chunks_hist;
     a.nchunks = h->nchunks_hist;
@@ -322,9 +336,14 @@ int launch_hist_spline(nidreg_handle* h, const double* se3, bool alone = false) 
   return NIDREG_OK;
 }
 
-int launch_hist_nearest(nidreg_handle* h, const double* T) {
+int launch_hist_nearest(nidreg_handle* h, const double* T, u64 ann_seq = 0) {
   PassArgs a;
   fill_pass_args(h, a);
+  if (ann_seq) {
+    a.ann = h->d_shard_tab;
+    a.ann_seq = ann_seq;
+    a.ann_ticket = h->d_counters + 2;
+  }
   for (int k = 0; k < 12; k++) a.iso[k] = T[k];
   HIP_TRY(begin_histogram(h));
   a.hist = h->d_hist;
@@ -340,7 +359,7 @@ int launch_hist_nearest(nidreg_handle* h, const double* T) {
 int launch_entropy(nidreg_handle* h, double tag) {
   const double inv_unit = 1.0 / fixed_unit(h);
   hipLaunchKernelGGL(
-    k_entropy<false>, dim3(h->NEB), dim3(kEntropyThreads), 0, h->stream, hist_source(h), h->bins, kEntropyCols, inv_unit, h->d_part_hj, h->d_row_part, h->d_phi_q, h->d_hist_image,
+    k_entropy<false>, dim3(h->NEB), dim3(kEntropyThreads), 0, h->stream, h->d_hist, h->bins, kEntropyCols, inv_unit, h->d_part_hj, h->d_row_part, h->d_phi_q, h->d_hist_image,
     h->d_hist_points, h->d_scal, h->d_out, h->d_out_host, tag, h->d_counters, h->own_hist ? h->d_hist_buf[h->hist_cur ^ 1] : nullptr, h->hist_words, static_cast<const MultiEntry*>(nullptr),
     NoMultiDyn());
   HIP_TRY(hipGetLastError());
@@ -352,7 +371,7 @@ int launch_grad(nidreg_handle* h, bool alone = false) {
   PassArgs a;
   fill_pass_args(h, a);
   a.prio = alone ? 1 : 0;
-  a.hist = hist_source(h);  // the finished (for a shard: all-reduced) histogram
+  a.hist = h->d_hist;  // the finished histogram (for a shard: its own columns)
   // same pose as the histogram pass of this evaluation
   std::memcpy(a.R, h->last_R, sizeof(a.R));
   std::memcpy(a.t, h->last_t, sizeof(a.t));
@@ -426,6 +445,7 @@ int eval_launch_fused(nidreg_handle* h, const double* se3, bool want_grad) {
   a.hist_points = h->d_hist_points;
   a.scal_out = h->d_scal;
   a.counters = h->d_counters;
+  a.barrier = h->d_barrier;
   a.bar_base = h->bar_base;
   a.abort_flag = h->d_counters + 5;
   a.abort_host = h->d_out_host + 11;
@@ -440,7 +460,7 @@ int eval_launch_fused(nidreg_handle* h, const double* se3, bool want_grad) {
     HIP_TRY(launch_fused<double>(a));
   }
   if (h->timing) HIP_TRY(hipEventRecord(h->ev[5], h->stream));
-  h->bar_base += unsigned(a.nchunks) * (want_grad ? 2u : 1u);
+  h->bar_base += want_grad ? 2u : 1u;
   h->hist_zeroed[h->hist_cur ^ 1] = true;  // zeroed by phase 2 for the next evaluation
   h->ev_grad = want_grad;
   h->fused_inflight = true;
@@ -455,6 +475,7 @@ int fused_recover(nidreg_handle* h) {
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemsetAsync(h->d_counters, 0, 8 * sizeof(unsigned int), h->stream));
+  HIP_TRY(hipMemsetAsync(h->d_barrier, 0, size_t(kBarrierWords) * sizeof(unsigned int), h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->h_out[11] = 0.0;
   h->bar_base = 0;
@@ -618,7 +639,11 @@ struct nidreg_cloud {
 namespace {
 
 struct CreateOpts {
-  bool shard = false;  // one shard of a ShardSet: fine-grained histogram buffers + the all-reduced copy
+  // one shard of a ShardSet: built from the column groups [group_lo, group_hi) of `master` (a complete handle of the pair
+  // on the owner device) -- its bin image and that slice of its bucketed records are copied device to device
+  bool shard = false;
+  const nidreg_handle* master = nullptr;
+  int group_lo = 0, group_hi = 0;
 };
 
 int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T_cull, double min_z, int enable_depth, const CreateOpts& opts, nidreg_handle** out) {
@@ -627,10 +652,12 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
   if (d->struct_size != int32_t(sizeof(nidreg_desc))) return fail(NIDREG_ERR_INVALID, "nidreg_create: struct_size mismatch");
   if (d->model_id < 0 || d->model_id > 5) return fail(NIDREG_ERR_INVALID, "nidreg_create: unknown camera model");
   if (d->bins < 2 || d->bins > NIDREG_MAX_BINS) return fail(NIDREG_ERR_INVALID, "nidreg_create: bins must be in [2, 256]");
-  if (d->width < 1 || d->height < 1 || !d->image) return fail(NIDREG_ERR_INVALID, "nidreg_create: bad image");
-  const int64_t n_in = cloud ? cloud->n : d->num_points;
+  if (d->width < 1 || d->height < 1 || (!d->image && !opts.shard)) return fail(NIDREG_ERR_INVALID, "nidreg_create: bad image");
+  const nidreg_handle* master = opts.shard ? opts.master : nullptr;
+  if (opts.shard && !master) return fail(NIDREG_ERR_INVALID, "nidreg_create: shard without a master");
+  const int64_t n_in = master ? master->gcount[size_t(opts.group_hi)] - master->gcount[size_t(opts.group_lo)] : (cloud ? cloud->n : d->num_points);
   if (n_in < 0 || n_in > int64_t(INT_MAX)) return fail(NIDREG_ERR_INVALID, "nidreg_create: bad num_points");
-  if (!cloud && n_in > 0 && (!d->points || !d->intensities)) return fail(NIDREG_ERR_INVALID, "nidreg_create: null points");
+  if (!master && !cloud && n_in > 0 && (!d->points || !d->intensities)) return fail(NIDREG_ERR_INVALID, "nidreg_create: null points");
   if (cloud && cloud->device != d->device_id) return fail(NIDREG_ERR_INVALID, "nidreg_create_from_cloud: cloud lives on another device");
   if (d->mode != NIDREG_MODE_SPLINE && d->mode != NIDREG_MODE_NEAREST) return fail(NIDREG_ERR_INVALID, "nidreg_create: bad mode");
   if (d->precision != NIDREG_PREC_FP64 && d->precision != NIDREG_PREC_FP32) return fail(NIDREG_ERR_INVALID, "nidreg_create: bad precision");
@@ -718,6 +745,29 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
     return fail(NIDREG_ERR_INVALID, "nidreg_create: point_stride must be a multiple of 8 and >= 32 ((x y z 1) doubles)");
   }
   std::vector<int64_t> gcount;
+  h->img_bytes = img_bytes;
+  if (master) {
+    // a shard: the master handle (same tiling, same bins) has built the padded bin image and the bucketed, Morton-ordered
+    // records on the owner device; this shard takes the records of its column groups and a copy of the image
+    if (master->GW != h->GW || master->NG != h->NG || master->bins != B || master->pitch != h->pitch || master->img_bytes != img_bytes) {
+      free_handle(h);
+      return fail(NIDREG_ERR_INVALID, "nidreg_create: shard / master layout mismatch");
+    }
+    const size_t rec_bytes = master->rec64 ? sizeof(Rec64) : sizeof(Rec32);
+    const int64_t lo = master->gcount[size_t(opts.group_lo)], hi = master->gcount[size_t(opts.group_hi)];
+    CREATE_TRY(hipMalloc(&h->d_img, img_bytes));
+    CREATE_TRY(hipMemcpyPeer(h->d_img, h->device, master->d_img, master->device, img_bytes));
+    CREATE_TRY(hipMalloc(&h->d_pts, std::max<size_t>(size_t(hi - lo), 1) * rec_bytes));
+    if (hi > lo) CREATE_TRY(hipMemcpyPeer(h->d_pts, h->device, static_cast<const char*>(master->d_pts) + size_t(lo) * rec_bytes, master->device, size_t(hi - lo) * rec_bytes));
+    h->rec64 = master->rec64;
+    gcount.assign(master->gcount.size(), 0);
+    for (size_t g = 0; g < master->gcount.size(); g++) gcount[g] = std::min(std::max(master->gcount[g], lo), hi) - lo;
+    N = hi - lo;
+    h->num_points = N;
+    h->is_shard = true;
+    h->col_lo = std::min(B, opts.group_lo * h->GW);
+    h->col_hi = std::min(B, opts.group_hi * h->GW);
+  } else
   {
     ScratchArena& arena = ScratchArena::of(h->device);
     std::lock_guard<ScratchArena> guard(arena);
@@ -843,19 +893,8 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
   if (d->ext_hist) {
     h->d_hist = static_cast<u64*>(d->ext_hist);
   } else {
-    if (opts.shard) {
-      // shards of one pair exchange their histograms directly between GPUs: fine-grained (coherent) device
-      // memory, mapped into every peer by the ShardSet
-      h->finegrained = true;
-      h->is_shard = true;
-      CREATE_TRY(hipExtMallocWithFlags(reinterpret_cast<void**>(&h->d_hist_buf[0]), size_t(h->hist_words) * sizeof(u64), hipDeviceMallocFinegrained));
-      CREATE_TRY(hipExtMallocWithFlags(reinterpret_cast<void**>(&h->d_hist_buf[1]), size_t(h->hist_words) * sizeof(u64), hipDeviceMallocFinegrained));
-      CREATE_TRY(hipExtMallocWithFlags(reinterpret_cast<void**>(&h->d_hist_full), size_t(h->hist_words) * sizeof(u64), hipDeviceMallocFinegrained));
-      CREATE_TRY(hipMemset(h->d_hist_full, 0, size_t(h->hist_words) * sizeof(u64)));
-    } else {
-      CREATE_TRY(hipMalloc(&h->d_hist_buf[0], size_t(h->hist_words) * sizeof(u64)));
-      CREATE_TRY(hipMalloc(&h->d_hist_buf[1], size_t(h->hist_words) * sizeof(u64)));
-    }
+    CREATE_TRY(hipMalloc(&h->d_hist_buf[0], size_t(h->hist_words) * sizeof(u64)));
+    CREATE_TRY(hipMalloc(&h->d_hist_buf[1], size_t(h->hist_words) * sizeof(u64)));
     CREATE_TRY(hipMemset(h->d_hist_buf[1], 0, size_t(h->hist_words) * sizeof(u64)));
     h->d_hist = h->d_hist_buf[0];
     h->hist_cur = 0;
@@ -888,6 +927,7 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
     const size_t o_scal = carve(sizeof(EntropyScalars));
     const size_t o_partials = carve(size_t(chunks_max) * 12 * sizeof(double));
     const size_t o_counters = carve(8 * sizeof(unsigned int));
+    const size_t o_barrier = carve(size_t(kBarrierWords) * sizeof(unsigned int));
     CREATE_TRY(hipMalloc(&h->d_scratch, off));
     CREATE_TRY(hipMemset(h->d_scratch, 0, off));
     char* base = static_cast<char*>(h->d_scratch);
@@ -899,6 +939,7 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
     h->d_scal = reinterpret_cast<EntropyScalars*>(base + o_scal);
     h->d_partials = reinterpret_cast<double*>(base + o_partials);
     h->d_counters = reinterpret_cast<unsigned int*>(base + o_counters);
+    h->d_barrier = reinterpret_cast<unsigned int*>(base + o_barrier);
   }
   CREATE_TRY(hipHostMalloc(&h->h_out, NIDREG_OUT_DOUBLES * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
   std::memset(h->h_out, 0, NIDREG_OUT_DOUBLES * sizeof(double));
@@ -1189,9 +1230,9 @@ bool can_group(nidreg_handle* const* handles, int n) {
 
 // ---- sharded pairs ----------------------------------------------------------------------------------------------
 
-// NIDREG_DEVICES="0,1,2,3": spread every SPLINE / NEAREST handle built from host arrays over these devices without
-// touching the caller -- this is how the reference's unchanged `new NIDCost(proj, image, points, bins)`
-// (visual_camera_calibration.cpp:206) uses all GPUs of a node for a one-bag dataset
+// NIDREG_DEVICES="0,1,2,3": spread every SPLINE / NEAREST handle over these devices without touching the caller -- this is
+// how the reference's unchanged `new NIDCost(proj, image, points, bins)` (visual_camera_calibration.cpp:206) uses all GPUs
+// of a node for a one-bag dataset
 std::vector<int> shard_devices(const nidreg_desc* d) {
   std::vector<int> ids;
   if (d->num_devices > 1) {
@@ -1215,50 +1256,81 @@ std::vector<int> shard_devices(const nidreg_desc* d) {
 }
 bool wants_shards(const nidreg_desc* d) { return !d->ext_hist && !d->ext_out && !d->ext_stream && !(d->flags & NIDREG_FLAG_EXT_STREAM) && shard_devices(d).size() > 1; }
 
-int launch_exchange(ShardSet* set, int g) {
-  nidreg_handle* h = set->shards[size_t(g)];
-  ExchangeArgs a = set->xargs[h->hist_cur][g];
-  a.seq = set->seq;
-  const int grid = std::max(1, std::min(16, (a.words / a.n + kThreads - 1) / kThreads));
-  hipLaunchKernelGGL(k_shard_exchange, dim3(grid), dim3(kThreads), 0, h->stream, a, h->d_counters + 2, h->d_out + 10, h->d_out_host ? h->d_out_host + 10 : nullptr, set->timeout_ticks);
-  HIP_TRY(hipGetLastError());
-  return NIDREG_OK;
-}
+// Sets of one process are evaluated one after the other on every device they share: an in-kernel wait of set X must never
+// sit in a hardware queue behind a kernel of set Y that waits for X on another device (the reference calls the pairs of a
+// multi-bag dataset from an OpenMP loop, visual_camera_calibration.cpp:161 -- with NIDREG_DEVICES every one of them is a
+// set).  One mutex per device, taken in ascending device order.
+std::mutex g_shard_device_mu[NIDREG_MAX_DEVICES];
 
-// one shard's part of one evaluation: launches + completion wait; called concurrently for different shards
-int run_shard(ShardSet* set, int g) {
+// one shard's launches of one evaluation, phase by phase (0 histogram, 1 owned entropy, 2 gathered tail, 3 gradient)
+int shard_launch_phase(ShardSet* set, int g, int phase, bool alone) {
   nidreg_handle* h = set->shards[size_t(g)];
   HIP_TRY(hipSetDevice(h->device));
-  InflightGuard guard(h->device);
-  bump_seq(h);
-  h->fused_inflight = false;
-  if (h->timing) HIP_TRY(hipEventRecord(h->ev[0], h->stream));
-  int rc;
-  if (set->job_mode == NIDREG_MODE_SPLINE) {
-    rc = launch_hist_spline(h, set->job_pose, guard.alone);
-  } else {
-    rc = launch_hist_nearest(h, set->job_pose);
-  }
-  if (rc) return rc;
-  if (h->timing) HIP_TRY(hipEventRecord(h->ev[2], h->stream));
-  rc = launch_exchange(set, g);
-  if (rc) return rc;
   const bool grad = set->job_mode == NIDREG_MODE_SPLINE && set->job_grad;
-  rc = launch_entropy(h, grad ? 0.0 : h->seq);  // timing: the "entropy" interval of a shard includes the exchange
-  if (rc) return rc;
-  if (h->timing) HIP_TRY(hipEventRecord(h->ev[3], h->stream));
+  if (phase == 0) {
+    bump_seq(h);
+    h->fused_inflight = false;
+    h->h_out[10] = 0.0;
+    if (h->timing) HIP_TRY(hipEventRecord(h->ev[0], h->stream));
+    if (h->nchunks == 0) {  // no points in this shard's columns: no histogram kernel runs, announce S_g = 0
+      HIP_TRY(begin_histogram(h));
+      hipLaunchKernelGGL(k_shard_announce, dim3(1), dim3(64), 0, h->stream, h->d_shard_tab, set->seq);
+      HIP_TRY(hipGetLastError());
+      if (set->job_mode == NIDREG_MODE_SPLINE) {
+        for (int k = 0; k < 4; k++) h->last_q[k] = set->job_pose[k];
+        pose_from_se3(set->job_pose, h->last_R, h->last_t);
+      }
+    } else {
+      const int rc = set->job_mode == NIDREG_MODE_SPLINE ? launch_hist_spline(h, set->job_pose, alone, set->seq) : launch_hist_nearest(h, set->job_pose, set->seq);
+      if (rc) return rc;
+    }
+    if (h->timing) HIP_TRY(hipEventRecord(h->ev[2], h->stream));
+    return NIDREG_OK;
+  }
+  if (phase == 1) {
+    const int ncols = std::max(0, h->col_hi - h->col_lo);
+    const int nblk = std::max(1, (ncols + kEntropyCols - 1) / kEntropyCols);
+    hipLaunchKernelGGL(k_entropy_owned, dim3(nblk), dim3(kEntropyThreads), 0, h->stream, h->d_hist, h->bins, 1.0 / fixed_unit(h), h->d_shard_tab, set->seq, h->d_part_hj, h->d_row_part, h->d_counters,
+                       h->d_hist_buf[h->hist_cur ^ 1], h->hist_words, h->d_out + 10, h->d_out_host ? h->d_out_host + 10 : nullptr, set->timeout_ticks);
+    HIP_TRY(hipGetLastError());
+    h->hist_zeroed[h->hist_cur ^ 1] = true;
+    return NIDREG_OK;
+  }
+  if (phase == 2) {
+    hipLaunchKernelGGL(k_entropy_gather, dim3(1), dim3(kThreads), 0, h->stream, h->bins, 1.0 / fixed_unit(h), h->d_shard_tab, set->seq, h->d_phi_q, h->d_hist_image, h->d_hist_points, h->d_scal, h->d_out,
+                       h->d_out_host, grad ? 0.0 : h->seq, h->d_out + 10, h->d_out_host ? h->d_out_host + 10 : nullptr, set->timeout_ticks);
+    HIP_TRY(hipGetLastError());
+    if (h->timing) HIP_TRY(hipEventRecord(h->ev[3], h->stream));
+    return NIDREG_OK;
+  }
   if (grad) {
-    rc = launch_grad(h, guard.alone);  // records ev[4]
+    const int rc = launch_grad(h, alone);  // records ev[4]; an empty shard finalises zeros stand-alone
     if (rc) return rc;
   } else if (h->timing) {
     HIP_TRY(hipEventRecord(h->ev[4], h->stream));
   }
   if (h->timing) HIP_TRY(hipEventRecord(h->ev[5], h->stream));
   h->ev_grad = grad;
+  return NIDREG_OK;
+}
+
+int shard_finish(ShardSet* set, int g) {
+  nidreg_handle* h = set->shards[size_t(g)];
+  const bool grad = set->job_mode == NIDREG_MODE_SPLINE && set->job_grad;
   std::array<double, 8>& r = set->res[size_t(g)];
-  rc = eval_finish(h, &r[0], grad ? &r[1] : nullptr);
-  if (rc >= 0 && h->h_out[10] != 0.0) return fail(NIDREG_ERR_HIP, "sharded evaluation: the histogram exchange timed out waiting for a peer GPU");
+  const int rc = eval_finish(h, &r[0], grad ? &r[1] : nullptr);
+  if (rc >= 0 && h->h_out[10] != 0.0) return fail(NIDREG_ERR_HIP, "sharded evaluation: timed out waiting for a peer GPU's partials");
   return rc;
+}
+
+// one shard's part of one evaluation: launches + completion wait; called concurrently for different shards (one shard per device)
+int run_shard(ShardSet* set, int g) {
+  InflightGuard guard(set->shards[size_t(g)]->device);
+  for (int phase = 0; phase < 4; phase++) {
+    const int rc = shard_launch_phase(set, g, phase, guard.alone);
+    if (rc) return rc;
+  }
+  return shard_finish(set, g);
 }
 
 void shard_worker(ShardSet* set, int g) {
@@ -1288,18 +1360,41 @@ void shard_worker(ShardSet* set, int g) {
 int set_eval(ShardSet* set, int mode, const double* pose, double* cost, double* grad7) {
   const int n = int(set->shards.size());
   if (set->shards[0]->mode != mode) return fail(NIDREG_ERR_INVALID, mode == NIDREG_MODE_SPLINE ? "nidreg_eval: handle was created in NEAREST mode" : "nidreg_eval_iso: handle was created in SPLINE mode");
+  if (set->poisoned) return fail(NIDREG_ERR_HIP, "sharded handle: an earlier evaluation failed half way; destroy and re-create the handle");
+  // one set at a time per device (see g_shard_device_mu)
+  struct Unlock {
+    const std::vector<int>& devs;
+    ~Unlock() {
+      for (size_t i = devs.size(); i-- > 0;) g_shard_device_mu[devs[i]].unlock();
+    }
+  };
+  for (int dev : set->lock_devices) g_shard_device_mu[dev].lock();
+  Unlock unlock{set->lock_devices};
   set->seq++;
   set->job_mode = mode;
   set->job_grad = grad7 != nullptr;
   std::memcpy(set->job_pose, pose, (mode == NIDREG_MODE_SPLINE ? 7 : 16) * sizeof(double));
-  set->pending.store(n - 1, std::memory_order_relaxed);
-  set->gen.fetch_add(1, std::memory_order_release);
-  if (set->sleepers.load() > 0) {
-    std::lock_guard<std::mutex> lk(set->mu);
-    set->cv.notify_all();
-  }
-  set->rc[0] = run_shard(set, 0);
-  {
+  if (set->colocated) {
+    // several shards on one device (a test configuration): their streams may share an in-order hardware queue, so the
+    // kernels are launched by this thread phase by phase -- every in-kernel wait then targets a kernel that sits AHEAD of
+    // it in whatever queue they share
+    for (int phase = 0; phase < 4; phase++)
+      for (int g = 0; g < n; g++) {
+        set->rc[size_t(g)] = shard_launch_phase(set, g, phase, false);
+        if (set->rc[size_t(g)] < 0) {
+          set->poisoned = true;
+          return fail(set->rc[size_t(g)], "sharded evaluation: launch failed on shard " + std::to_string(g) + ": " + g_last_error);
+        }
+      }
+    for (int g = 0; g < n; g++) set->rc[size_t(g)] = shard_finish(set, g);
+  } else {
+    set->pending.store(n - 1, std::memory_order_relaxed);
+    set->gen.fetch_add(1, std::memory_order_release);
+    if (set->sleepers.load() > 0) {
+      std::lock_guard<std::mutex> lk(set->mu);
+      set->cv.notify_all();
+    }
+    set->rc[0] = run_shard(set, 0);
     // the other shards finish within microseconds of this one: pause-spin (2 ms by the clock), then nap
     struct timespec t0;
     clock_gettime(CLOCK_MONOTONIC, &t0);
@@ -1318,10 +1413,21 @@ int set_eval(ShardSet* set, int mode, const double* pose, double* cost, double* 
   }
   bool all_ok = true;
   for (int g = 0; g < n; g++) {
-    if (set->rc[size_t(g)] < 0) return fail(set->rc[size_t(g)], "sharded evaluation failed on shard " + std::to_string(g) + " (device " + std::to_string(set->shards[size_t(g)]->device) + ")");
+    if (set->rc[size_t(g)] < 0) {
+      set->poisoned = true;
+      return fail(set->rc[size_t(g)], "sharded evaluation failed on shard " + std::to_string(g) + " (device " + std::to_string(set->shards[size_t(g)]->device) + ")");
+    }
     if (set->rc[size_t(g)] == NIDREG_FALSE) all_ok = false;
   }
-  if (cost) *cost = set->res[0][0];  // identical bits on every shard (same integer histogram, same arithmetic)
+  // every shard computed the cost from the same gathered integers: any difference means a shard read stale or torn data
+  for (int g = 1; g < n; g++) {
+    if (std::memcmp(&set->res[size_t(g)][0], &set->res[0][0], sizeof(double)) != 0) {
+      set->poisoned = true;
+      return fail(NIDREG_ERR_HIP, "sharded evaluation: shard " + std::to_string(g) + " (device " + std::to_string(set->shards[size_t(g)]->device) +
+                                    ") computed a different cost than shard 0 from the gathered partials -- cross-device visibility failure");
+    }
+  }
+  if (cost) *cost = set->res[0][0];
   if (grad7) {
     for (int k = 0; k < 7; k++) {
       double t = 0.0;
@@ -1348,83 +1454,48 @@ void free_shard_set(ShardSet* set) {
       if (h->stream) (void)hipStreamSynchronize(h->stream);
     }
   }
-  for (size_t g = 0; g < set->flags.size(); g++) {
-    if (set->flags[g]) {
-      (void)hipSetDevice(set->shards[g]->device);
-      (void)hipFree(set->flags[g]);
-    }
+  for (size_t g = 0; g < set->shards.size(); g++) {
+    if (!set->shards[g]) continue;
+    (void)hipSetDevice(set->shards[g]->device);
+    if (g < set->flags.size() && set->flags[g]) (void)hipFree(set->flags[g]);
+    if (g < set->gather.size() && set->gather[g]) (void)hipFree(set->gather[g]);
   }
   for (size_t g = 1; g < set->shards.size(); g++) free_handle(set->shards[g]);
   delete set;
 }
 
-// exchange self-test at creation: two rounds of a known pattern through the real kernel; the second round has
-// different values at the same addresses, so a peer read served from a stale cache line cannot pass
-int shard_self_test(ShardSet* set) {
-  const int n = int(set->shards.size());
-  const int words = int(set->shards[0]->hist_words);
-  std::vector<u64> got(static_cast<size_t>(words));
-  for (u64 round = 1; round <= 2; round++) {
-    set->seq++;
-    for (int g = 0; g < n; g++) {
-      nidreg_handle* h = set->shards[size_t(g)];
-      HIP_TRY(hipSetDevice(h->device));
-      HIP_TRY(begin_histogram(h));
-      hipLaunchKernelGGL(k_shard_pattern, dim3((words + 255) / 256), dim3(256), 0, h->stream, h->d_hist, words, u64(g), round);
-      HIP_TRY(hipGetLastError());
-      const int rc = launch_exchange(set, g);
-      if (rc) return rc;
-    }
-    for (int g = 0; g < n; g++) {
-      nidreg_handle* h = set->shards[size_t(g)];
-      HIP_TRY(hipSetDevice(h->device));
-      HIP_TRY(hipStreamSynchronize(h->stream));
-      double err = 0.0;
-      HIP_TRY(hipMemcpy(&err, h->d_out + 10, sizeof(double), hipMemcpyDeviceToHost));
-      if (err != 0.0) return fail(NIDREG_ERR_HIP, "sharded handle: exchange self-test timed out on device " + std::to_string(h->device) + " (peer access between the GPUs is not working)");
-      HIP_TRY(hipMemcpy(got.data(), h->d_hist_full, got.size() * sizeof(u64), hipMemcpyDeviceToHost));
-      for (int k = 0; k < words; k++) {
-        u64 want = 0;
-        for (int p = 0; p < n; p++) want += (u64(p) + 1) * 1000003ull + round * 7919ull + u64(k) * (u64(p) + 3);
-        if (got[size_t(k)] != want)
-          return fail(NIDREG_ERR_HIP, "sharded handle: exchange self-test mismatch on device " + std::to_string(h->device) + " word " + std::to_string(k) + " round " + std::to_string(round));
-      }
-      // leave the buffers as an evaluation expects them: the partial just used is dirty
-      h->hist_zeroed[h->hist_cur] = false;
-      HIP_TRY(hipMemsetAsync(h->d_hist_full, 0, got.size() * sizeof(u64), h->stream));
-    }
+// Cut the NG column groups into n contiguous ranges with (nearly) equal point counts: boundary g is the first group index
+// at which the running count reaches g / n of the total (the intensities are rank-equalised upstream, preprocess.cpp:464-473,
+// so the groups are close to uniform; view culling skews them a little).  Ranges may be empty when n > NG.
+std::vector<int> partition_groups(const std::vector<int64_t>& gcount, int NG, int n) {
+  std::vector<int> cut(static_cast<size_t>(n) + 1, 0);
+  const int64_t total = gcount[size_t(NG)];
+  cut[size_t(n)] = NG;
+  int g = 0;
+  for (int k = 1; k < n; k++) {
+    const int64_t want = total * k / n;
+    while (g < NG && gcount[size_t(g) + 1] <= want) g++;
+    // group g straddles the target: cut on the nearer side
+    if (g < NG && want - gcount[size_t(g)] > gcount[size_t(g) + 1] - want) g++;
+    g = std::max(g, cut[size_t(k) - 1]);
+    cut[size_t(k)] = std::min(g, NG);
   }
-  for (int g = 0; g < n; g++) {
-    nidreg_handle* h = set->shards[size_t(g)];
-    HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-  }
-  return NIDREG_OK;
+  if (total == 0)  // nothing to balance: equal column ranges
+    for (int k = 1; k < n; k++) cut[size_t(k)] = NG * k / n;
+  return cut;
 }
 
-int create_sharded(const nidreg_desc* d, nidreg_handle** out) {
+int create_sharded(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T_cull, double min_z, int enable_depth, nidreg_handle** out) {
   *out = nullptr;
   const std::vector<int> ids = shard_devices(d);
   const int n = int(ids.size());
   if (n > kMaxShards) return fail(NIDREG_ERR_INVALID, "nidreg_create: at most 16 shards");
-  if (d->num_points < 0 || (d->num_points > 0 && (!d->points || !d->intensities))) return fail(NIDREG_ERR_INVALID, "nidreg_create: null points");
+  if (!cloud && (d->num_points < 0 || (d->num_points > 0 && (!d->points || !d->intensities)))) return fail(NIDREG_ERR_INVALID, "nidreg_create: null points");
+  if (d->bins < 2 || d->bins > NIDREG_MAX_BINS) return fail(NIDREG_ERR_INVALID, "nidreg_create: bins must be in [2, 256]");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(NIDREG_ERR_NO_DEVICE, "nidreg_create: no HIP device (the NID core has no CPU path)");
   for (int id : ids)
     if (id < 0 || id >= ndev) return fail(NIDREG_ERR_INVALID, "nidreg_create: device id " + std::to_string(id) + " out of range (NIDREG_DEVICES / desc.device_ids)");
-  // The same device may be listed more than once (a 1-GPU box exercising the protocol), but the exchange kernels of
-  // co-located shards wait for each other while holding a hardware queue each: beyond three per device two of them
-  // share a queue (ROCm maps streams onto 4) and the wait could only end by its timeout.
-  {
-    bool colocated = false;
-    for (int id : ids) colocated = colocated || std::count(ids.begin(), ids.end(), id) > 1;
-    static std::atomic<bool> warned{false};
-    if (colocated && !warned.exchange(true))
-      std::fprintf(stderr, "nidreg: several shards of one pair share a device -- a test configuration: their streams must not share a hardware queue "
-                           "(set GPU_MAX_HW_QUEUES >= the number of streams in the process before HIP initialises)\n");
-  }
-  for (int id : ids)
-    if (std::count(ids.begin(), ids.end(), id) > 3) return fail(NIDREG_ERR_INVALID, "nidreg_create: at most 3 shards of one pair may share a device (device " + std::to_string(id) + " is listed more often)");
   // peer mappings, both directions, before any buffer is allocated
   for (int i = 0; i < n; i++) {
     for (int j = 0; j < n; j++) {
@@ -1438,15 +1509,39 @@ int create_sharded(const nidreg_desc* d, nidreg_handle** out) {
       (void)hipGetLastError();
     }
   }
+  // ---- the master: the complete pair on the owner device (where the cloud lives / the first listed device): upload,
+  // [ViewCulling::cull,] bucketing by column group, Morton sort, gather, bin image -- once; the shards then take their
+  // column groups' records (already in their final order) device to device
+  const int B = d->bins;
+  nidreg_desc md = *d;
+  md.num_devices = 1;
+  md.device_id = cloud ? cloud->device : ids[0];
+  if (md.columns_per_group <= 0) md.columns_per_group = std::max(1, std::min(std::max(1, 256 / B), B / (4 * n)));  // >= 4 column groups per shard where B allows
+  md.scale_points = std::max<int64_t>(cloud ? cloud->n : d->num_points, d->scale_points);  // the fixed-point unit of the unsharded handle
+  nidreg_handle* master = nullptr;
+  {
+    const int rc = create_impl(&md, cloud, T_cull, min_z, enable_depth, CreateOpts(), &master);
+    if (rc) return rc;
+  }
+  const std::vector<int> cut = partition_groups(master->gcount, master->NG, n);
+
   ShardSet* set = new ShardSet();
   set->shards.assign(size_t(n), nullptr);
   set->flags.assign(size_t(n), nullptr);
+  set->gather.assign(size_t(n), nullptr);
   set->rc.assign(size_t(n), 0);
   set->res.assign(size_t(n), std::array<double, 8>());
+  set->lock_devices = ids;
+  std::sort(set->lock_devices.begin(), set->lock_devices.end());
+  set->lock_devices.erase(std::unique(set->lock_devices.begin(), set->lock_devices.end()), set->lock_devices.end());
+  set->colocated = set->lock_devices.size() != ids.size();
+  // measurement knob (tools/shard_cost.py): co-located shards driven by their worker threads like shards on different
+  // devices -- only valid when the caller has made sure their streams do not share a hardware queue (GPU_MAX_HW_QUEUES)
+  if (set->colocated && std::getenv("NIDREG_SHARD_COLOCATED_WORKERS")) set->colocated = false;
   if (const char* t = std::getenv("NIDREG_SHARD_TIMEOUT_MS")) set->timeout_ticks = 100000ull * (unsigned long long)std::max(1L, std::strtol(t, nullptr, 10));
-  const int64_t N = d->num_points;
-  const int64_t pstride = d->point_stride > 0 ? d->point_stride : 32;
   auto bail = [&](int rc) {
+    const std::string msg = g_last_error;
+    free_handle(master);
     nidreg_handle* lead = set->shards[0];
     if (lead) {
       lead->set = set;
@@ -1454,26 +1549,23 @@ int create_sharded(const nidreg_desc* d, nidreg_handle** out) {
     } else {
       free_shard_set(set);
     }
+    g_last_error = msg;
     return rc;
   };
-  // contiguous, disjoint, exhaustive point slices; every shard uses the fixed-point unit of the WHOLE cloud.
-  // The shards are built concurrently (upload + sort per device).
   {
     std::vector<std::thread> th;
     std::vector<int> rcs(size_t(n), 0);
     std::vector<std::string> errs(static_cast<size_t>(n));
     for (int g = 0; g < n; g++) {
       th.emplace_back([&, g]() {
-        nidreg_desc sd = *d;
-        const int64_t lo = N * g / n, hi = N * (g + 1) / n;
+        nidreg_desc sd = md;
         sd.device_id = ids[size_t(g)];
-        sd.num_devices = 1;
-        sd.num_points = hi - lo;
-        sd.points = reinterpret_cast<const double*>(reinterpret_cast<const char*>(d->points) + lo * pstride);
-        sd.intensities = d->intensities + lo;
-        sd.scale_points = std::max<int64_t>(N, d->scale_points);
+        sd.columns_per_group = master->GW;
         CreateOpts o;
         o.shard = true;
+        o.master = master;
+        o.group_lo = cut[size_t(g)];
+        o.group_hi = cut[size_t(g) + 1];
         rcs[size_t(g)] = create_impl(&sd, nullptr, nullptr, 0.0, 0, o, &set->shards[size_t(g)]);
         if (rcs[size_t(g)]) errs[size_t(g)] = g_last_error;
       });
@@ -1482,37 +1574,41 @@ int create_sharded(const nidreg_desc* d, nidreg_handle** out) {
     for (int g = 0; g < n; g++)
       if (rcs[size_t(g)]) return bail(fail(rcs[size_t(g)], "shard " + std::to_string(g) + ": " + errs[size_t(g)]));
   }
+  // flag and gather blocks: fine-grained (coherent) device memory, mapped into every peer
+  const size_t gw = size_t(gather_words(B));
   for (int g = 0; g < n; g++) {
     nidreg_handle* h = set->shards[size_t(g)];
+    h->shard_index = g;
     hipError_t e = hipSetDevice(h->device);
     if (e == hipSuccess) e = hipExtMallocWithFlags(reinterpret_cast<void**>(&set->flags[size_t(g)]), 2 * kMaxShards * sizeof(u64), hipDeviceMallocFinegrained);
     if (e == hipSuccess) e = hipMemset(set->flags[size_t(g)], 0, 2 * kMaxShards * sizeof(u64));
-    if (e != hipSuccess) return bail(fail(NIDREG_ERR_HIP, std::string("sharded handle: flag block: ") + hipGetErrorString(e)));
+    if (e == hipSuccess) e = hipExtMallocWithFlags(reinterpret_cast<void**>(&set->gather[size_t(g)]), gw * sizeof(u64), hipDeviceMallocFinegrained);
+    if (e == hipSuccess) e = hipMemset(set->gather[size_t(g)], 0, gw * sizeof(u64));
+    if (e != hipSuccess) return bail(fail(NIDREG_ERR_HIP, std::string("sharded handle: flag / gather block: ") + hipGetErrorString(e)));
   }
-  for (int par = 0; par < 2; par++) {
-    for (int g = 0; g < n; g++) {
-      ExchangeArgs& a = set->xargs[par][g];
-      std::memset(&a, 0, sizeof(a));
-      for (int p = 0; p < n; p++) {
-        a.part[p] = set->shards[size_t(p)]->d_hist_buf[par];
-        a.full[p] = set->shards[size_t(p)]->d_hist_full;
-        a.flags[p] = set->flags[size_t(p)];
-      }
-      a.n = n;
-      a.me = g;
-      a.words = int(set->shards[0]->hist_words);
+  for (int g = 0; g < n; g++) {
+    nidreg_handle* h = set->shards[size_t(g)];
+    ShardTable tab;
+    std::memset(&tab, 0, sizeof(tab));
+    for (int p = 0; p < n; p++) {
+      tab.flags[p] = set->flags[size_t(p)];
+      tab.gather[p] = set->gather[size_t(p)];
     }
+    tab.n = n;
+    tab.me = g;
+    tab.col_lo = h->col_lo;
+    tab.col_hi = h->col_hi;
+    hipError_t e = hipSetDevice(h->device);
+    if (e == hipSuccess) e = hipMalloc(&h->d_shard_tab, sizeof(ShardTable));
+    if (e == hipSuccess) e = hipMemcpy(h->d_shard_tab, &tab, sizeof(ShardTable), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return bail(fail(NIDREG_ERR_HIP, std::string("sharded handle: shard table: ") + hipGetErrorString(e)));
   }
-  {
-    const int rc = shard_self_test(set);
-    if (rc) return bail(rc);
-  }
-  for (int g = 1; g < n; g++) set->workers.emplace_back(shard_worker, set, g);
+  free_handle(master);
+  master = nullptr;
+  if (!set->colocated)
+    for (int g = 1; g < n; g++) set->workers.emplace_back(shard_worker, set, g);
   nidreg_handle* lead = set->shards[0];
   lead->set = set;
-  int64_t total = 0;
-  for (int g = 0; g < n; g++) total += set->shards[size_t(g)]->num_points;
-  (void)total;
   *out = lead;
   return NIDREG_OK;
 }
@@ -1522,7 +1618,7 @@ int create_sharded(const nidreg_desc* d, nidreg_handle** out) {
 extern "C" {
 
 int nidreg_create(const nidreg_desc* d, nidreg_handle** out) {
-  if (d && d->struct_size == int32_t(sizeof(nidreg_desc)) && wants_shards(d)) return create_sharded(d, out);
+  if (d && out && d->struct_size == int32_t(sizeof(nidreg_desc)) && wants_shards(d)) return create_sharded(d, nullptr, nullptr, 0.0, 0, out);
   return create_impl(d, nullptr, nullptr, 0.0, 0, CreateOpts(), out);
 }
 
@@ -1568,6 +1664,9 @@ void nidreg_cloud_destroy(nidreg_cloud* c) {
 
 int nidreg_create_from_cloud(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T_camera_lidar, double min_z, int enable_depth_buffer_culling, nidreg_handle** out) {
   if (!cloud) return fail(NIDREG_ERR_INVALID, "nidreg_create_from_cloud: null cloud");
+  // desc.device_ids / NIDREG_DEVICES: cull + bucket + sort on the cloud's GPU, then every shard takes its column groups
+  // device to device -- the per-outer-iteration `cull -> new NIDCost` stays on the GPUs
+  if (d && out && d->struct_size == int32_t(sizeof(nidreg_desc)) && wants_shards(d)) return create_sharded(d, cloud, T_camera_lidar, min_z, enable_depth_buffer_culling, out);
   return create_impl(d, cloud, T_camera_lidar, min_z, enable_depth_buffer_culling, CreateOpts(), out);
 }
 
@@ -1713,11 +1812,29 @@ int nidreg_eval_iso_multi(nidreg_handle* const* handles, int n, const double* T,
 
 int nidreg_get_hist_fixed(nidreg_handle* h, int64_t* joint, int64_t* inliers, int* frac_bits) {
   if (!h) return fail(NIDREG_ERR_INVALID, "nidreg_get_hist_fixed: null handle");
+  if (h->set) {  // every shard holds its own columns of the pair's histogram
+    const int B = h->bins;
+    std::vector<u64> tmp(size_t(h->hist_words));
+    int64_t inl = 0;
+    if (joint) std::fill(joint, joint + size_t(B) * B, int64_t(0));
+    for (nidreg_handle* sh : h->set->shards) {
+      HIP_TRY(hipSetDevice(sh->device));
+      HIP_TRY(hipStreamSynchronize(sh->stream));
+      HIP_TRY(hipMemcpy(tmp.data(), sh->d_hist, tmp.size() * sizeof(u64), hipMemcpyDeviceToHost));
+      if (joint)
+        for (int c = sh->col_lo; c < sh->col_hi; c++)
+          for (int r = 0; r < B; r++) joint[size_t(r) * B + c] = int64_t(tmp[size_t(c) * B + r]);
+      inl += int64_t(tmp[size_t(B) * B + kTailInliers]);
+    }
+    if (inliers) *inliers = inl;
+    if (frac_bits) *frac_bits = h->frac_bits;
+    return NIDREG_OK;
+  }
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipStreamSynchronize(h->stream));
   const int B = h->bins;
   std::vector<u64> tmp(size_t(h->hist_words));
-  HIP_TRY(hipMemcpy(tmp.data(), hist_source(h), tmp.size() * sizeof(u64), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(tmp.data(), h->d_hist, tmp.size() * sizeof(u64), hipMemcpyDeviceToHost));
   if (joint) {
     // device layout [bin_points][bin_image] -> [bin_image][bin_points]
     for (int c = 0; c < B; c++)

@@ -24,13 +24,11 @@
  *   nidreg_shard_*           (no reference counterpart) split-phase evaluation of one pair whose
  *                            points are sharded over several GPUs, ONE PROCESS PER GPU; the caller
  *                            all-reduces the fixed-point histogram (RCCL) between the phases.
- *   desc.num_devices /       (no reference counterpart) the same sharding inside ONE process: nidreg_create
- *   NIDREG_DEVICES           splits the cloud over the listed GPUs and nidreg_eval* exchange the histogram
- *                            GPU to GPU themselves (the reference's calibrate is a single process,
- *                            src/calibrate.cpp:117-120)
- *   NIDREG_COMBINE=1         (environment, experimental) concurrent nidreg_eval callers on one device at one pose -- the
- *                            reference's OpenMP loop over the pairs of a MultiNIDCost, visual_camera_calibration.cpp:161 --
- *                            are collected and evaluated as ONE grid like nidreg_eval_multi's
+ *   desc.num_devices /       (no reference counterpart) one pair over several GPUs inside ONE process: nidreg_create /
+ *   NIDREG_DEVICES           nidreg_create_from_cloud cut the cloud along the histogram column (every GPU owns a range of
+ *                            column groups and the points that fall into them) and nidreg_eval* exchange inlier counts,
+ *                            entropy partials and marginal sums GPU to GPU themselves (the reference's calibrate is a
+ *                            single process, src/calibrate.cpp:117-120)
  *   nidreg_destroy           ~NIDCost / ~CostCalculatorNID
  *
  * Conventions
@@ -45,6 +43,12 @@
  *   - threading: concurrent calls on DIFFERENT handles from different host threads are safe (the
  *     reference evaluates one NIDCost per OpenMP thread, visual_camera_calibration.cpp:161);
  *     concurrent calls on the same handle are not supported (never happens in the reference).
+ *     Handles sharded over several GPUs are evaluated one after the other on every device they share
+ *     (a per-device lock inside nidreg_eval*: each of them uses all of its GPUs anyway).
+ *   - an evaluation that has its device to itself runs as ONE kernel (histogram -> grid barrier -> entropy ->
+ *     grid barrier -> gradient, csrc/nid_fused.hpp) and with issue priority by progress; evaluations that
+ *     share a device (concurrent callers, other processes) run as three kernels without it.  The cost and the
+ *     histograms are bit-identical on both routes, the gradient equal up to the order of the workgroup partials.
  *   - the caller keeps ownership of every host buffer; nidreg_create copies what it needs.
  */
 #ifndef NIDREG_H
@@ -123,12 +127,15 @@ typedef struct nidreg_desc {
   void* ext_stream;         /* hipStream_t the handle launches on */
   void* ext_hist;           /* device buffer of nidreg_hist_words(bins) 64-bit words */
   void* ext_out;            /* device buffer of NIDREG_OUT_DOUBLES doubles */
-  /* one pair sharded over several GPUs inside the library (single process): num_devices > 1 splits the cloud into
-     contiguous point slices, one per device_ids[k], and nidreg_eval* then run every slice on its GPU with a direct
-     GPU-to-GPU all-reduce of the fixed-point histogram (results are bit-identical to the unsharded handle's cost;
-     the gradient differs by summation order only).  0 = device_id alone, unless the environment variable
-     NIDREG_DEVICES="0,1,..." is set -- which shards every handle built from host arrays, so a caller that knows
-     nothing about GPUs (the reference's `new NIDCost(proj, image, points, bins)`) uses the whole node. */
+  /* one pair spread over several GPUs inside the library (single process): num_devices > 1 cuts the cloud along the
+     pose-independent histogram column -- device_ids[k] owns a contiguous range of column groups, balanced by their point
+     counts, and holds the points that fall into them -- so the GPUs' joint histograms have disjoint support and an
+     evaluation exchanges only inlier counts, entropy partials, row sums and column sums (2 + bins + bins/n words per GPU)
+     directly between the GPUs.  Cost and histograms are bit-identical to the unsharded handle's, the gradient differs by
+     summation order only.  The same device may be listed several times (a 1-GPU box exercising the protocol).
+     0 = device_id alone, unless the environment variable NIDREG_DEVICES="0,1,..." is set -- which shards every handle
+     (nidreg_create and nidreg_create_from_cloud), so a caller that knows nothing about GPUs (the reference's
+     `new NIDCost(proj, image, points, bins)`) uses the whole node. */
   int32_t num_devices;
   int32_t device_ids[NIDREG_MAX_DEVICES];
 } nidreg_desc;
@@ -147,7 +154,9 @@ void nidreg_destroy(nidreg_handle* h);
  * it entirely on the GPU: optional ViewCulling::cull at T_camera_lidar (row-major 4x4; NULL = no culling;
  * min_z / enable_depth_buffer_culling as in nidreg_view_culling), then bucketing, Morton sort and record
  * gather -- the reference's per-outer-iteration `cull -> new NIDCost` (visual_camera_calibration.cpp:
- * 201-206) without a host round trip.  desc->points / intensities / num_points are ignored. */
+ * 201-206) without a host round trip.  desc->points / intensities / num_points are ignored.  desc->num_devices /
+ * NIDREG_DEVICES are honoured: the cull and the sort run on the cloud's GPU, every shard then takes the records of its
+ * column groups device to device. */
 typedef struct nidreg_cloud nidreg_cloud;
 int nidreg_cloud_create(int device_id, const double* points, int64_t point_stride, const double* intensities, int64_t num_points, nidreg_cloud** out);
 void nidreg_cloud_destroy(nidreg_cloud* cloud);
@@ -169,8 +178,9 @@ int nidreg_eval_iso(nidreg_handle* h, const double* T_camera_lidar, double* cost
  * concurrently (every GPU's histogram pass is queued before the rest).  2..16 compatible SPLINE handles on ONE GPU
  * (same camera, image size, bins, precision) are evaluated by ONE grid per pass over the chunks of all pairs -- three
  * launches in all instead of three per pair; each pair keeps its own histogram, fixed-point unit and result block, so
- * the result is bit-identical to evaluating the handles one by one (NIDREG_NO_MULTI_GRID=1 in the environment forces
- * the per-pair launches). */
+ * every pair's cost and histogram are bit-identical to evaluating the handles one by one; the gradient's workgroup
+ * partials follow the group's chunk table, i.e. it is equal up to summation order (NIDREG_NO_MULTI_GRID=1 in the
+ * environment forces the per-pair launches). */
 int nidreg_eval_multi(nidreg_handle* const* handles, int n, const double* init_se3, const double* se3, double* cost, double* grad7);
 
 /* sum_i CostCalculatorNID_i::calculate(T); compatible NEAREST handles on one GPU share one grid per pass like nidreg_eval_multi */
@@ -259,7 +269,8 @@ void nidreg_trim(void);
  * recorded on the handle's stream, i.e. the stream the kernels run on):
  * [0]=whole launch sequence [1]=histogram memset [2]=histogram kernel [3]=entropy kernels
  * [4]=gradient kernel (0 if not run) [5]=gradient finalisation.
- * Only recorded after nidreg_set_timing(h, 1). */
+ * nidreg_set_timing(h, 1): an event after every kernel -- the evaluation then runs as three kernels; (h, 2): only [0], around
+ * whichever route runs (one fused kernel when the handle has its device to itself); (h, 0): off. */
 int nidreg_set_timing(nidreg_handle* h, int enable);
 int nidreg_get_timing(nidreg_handle* h, float* ms6);
 

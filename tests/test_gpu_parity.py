@@ -625,18 +625,19 @@ def test_concurrent_handles_from_host_threads_and_no_leaks():
     assert free0 - free1 < 64 * 1024 * 1024
 
 
-@pytest.mark.parametrize("nshards", [2, 3])
+@pytest.mark.parametrize("nshards", [2, 3, 5])
 def test_in_library_sharding_matches_plain_handle(nshards):
     """desc.num_devices > 1 (here: the same GPU listed several times -- all a 1-GPU box offers; the peer-mapped
-    fine-grained buffers, flag protocol, worker threads and the exchange kernel are the ones a multi-GPU node runs):
-    contiguous point slices, one-shot GPU-to-GPU all-reduce of the fixed-point histogram inside nidreg_eval.  The
-    histogram and the cost are bit-identical to the unsharded handle, the gradient equal up to summation order --
-    SPLINE and NEAREST, 16 and 256 bins, a cloud size that does not divide evenly."""
+    fine-grained flag / gather blocks, the announce in the histogram kernel, k_entropy_owned / k_entropy_gather are the ones
+    a multi-GPU node runs): the points are cut along the histogram column, every shard owns a range of column groups, and
+    only inlier counts, entropy partials, row sums and column sums cross between the shards.  Histogram and cost are
+    bit-identical to the unsharded handle, the gradient equal up to summation order -- SPLINE and NEAREST, 16 and 256 bins,
+    a cloud size that does not divide evenly."""
     s = scene_for("plumb_bob", n=30011)
     proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
     rng = np.random.default_rng(5)
     poses = [s.T_camera_lidar_init] + [synth.random_pose_near(s.T_camera_lidar_true, rng) for _ in range(6)]
-    for bins in (16, 256):
+    for bins in (16, 100, 256):
         plain = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, bins)
         sh = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, bins, devices=[0] * nshards)
         assert sh.num_shards() == nshards and sh.shard_devices() == [0] * nshards and plain.num_shards() == 1
@@ -647,11 +648,21 @@ def test_in_library_sharding_matches_plain_handle(nshards):
             assert ok and ok1 and c1 == c
             assert np.allclose(g1, g, rtol=1e-12, atol=1e-15)
             assert np.array_equal(sh.histogram_fixed()[0], plain.histogram_fixed()[0]) and sh.histogram_fixed()[1] == plain.histogram_fixed()[1]
+            jp, hip_, hpp = plain.histograms()
+            js, his, hps = sh.histograms()
+            assert np.array_equal(js, jp) and np.array_equal(his, hip_) and np.array_equal(hps, hpp)
             ok2, c2, g2 = sh(x, want_grad=False)
             assert ok2 and c2 == c and g2 is None
         ref = oracle_nid(s, bins, poses[1])
         ok1, c1, g1 = sh(poses[1])
         assert abs(c1 - ref["cost"]) <= 1e-10 and np.allclose(g1, ref["grad"], rtol=1e-7, atol=1e-10)
+        # nothing projects: every shard announces zero inliers, the functor returns false like the reference's 0 / 0
+        far = np.array(poses[1], dtype=np.float64).copy()
+        far[4:7] += 1.0e4
+        okf, cf, gf = sh(far)
+        assert not okf and not np.isfinite(cf)
+        okb, cb, gb = sh(poses[2])
+        assert okb and cb == plain(poses[2])[1]
         plain.close()
         sh.close()
     max_fov = oracle_lib.estimate_camera_fov(s.model, s.intrinsics, s.distortion, s.width, s.height)
@@ -662,6 +673,36 @@ def test_in_library_sharding_matches_plain_handle(nshards):
     assert np.array_equal(near_sh.histogram_fixed()[0], near.histogram_fixed()[0])
     near.close()
     near_sh.close()
+
+
+def test_sharding_a_device_resident_cloud_with_culling():
+    """nidreg_create_from_cloud honours desc.device_ids: ViewCulling + bucketing + sort on the cloud's GPU, then every shard
+    takes the records of its column groups device to device -- same bits as the unsharded device-resident handle (BASELINE
+    configs[4]: a map culled on the GPU every outer iteration, visual_camera_calibration.cpp:199-208, on several GPUs)."""
+    s = scene_for("plumb_bob", n=40000)
+    T = se3.to_matrix(s.T_camera_lidar_init)
+    Tinv = np.linalg.inv(T)
+    pc = s.points[:8000, :3] @ T[:3, :3].T + T[:3, 3]
+    extra = np.concatenate([pc * (1.0 + 1.0 / np.linalg.norm(pc, axis=1, keepdims=True)), -pc]) @ Tinv[:3, :3].T + Tinv[:3, 3]
+    pts = np.concatenate([s.points, np.concatenate([extra, np.ones((extra.shape[0], 1))], -1)])
+    ints = np.concatenate([s.intensities, s.intensities[:8000], s.intensities[:8000]])
+    proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
+    min_z = np.cos(oracle_lib.estimate_camera_fov(s.model, s.intrinsics, s.distortion, s.width, s.height))
+    cloud = nid.Cloud(pts, ints)
+    rng = np.random.default_rng(8)
+    poses = [s.T_camera_lidar_init] + [synth.random_pose_near(s.T_camera_lidar_true, rng) for _ in range(3)]
+    for bins in (16, 256):
+        one = nid.NIDCost.from_cloud(proj, s.image_f64, cloud, bins, cull=(T, min_z, True))
+        many = nid.NIDCost.from_cloud(proj, s.image_f64, cloud, bins, cull=(T, min_z, True), devices=[0, 0, 0, 0])
+        assert many.num_shards() == 4 and many.num_points == one.num_points and many.info()["frac_bits"] == one.info()["frac_bits"]
+        for x in poses:
+            ok1, c1, g1 = one(x)
+            okm, cm, gm = many(x)
+            assert ok1 and okm and cm == c1 and np.allclose(gm, g1, rtol=1e-12, atol=1e-15)
+            assert np.array_equal(many.histogram_fixed()[0], one.histogram_fixed()[0])
+        one.close()
+        many.close()
+    cloud.close()
 
 
 def test_nidreg_devices_environment_shards_an_unchanged_caller(monkeypatch):

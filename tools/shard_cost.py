@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
-"""Protocol cost of the in-library sharded evaluation on ONE GPU (the same device listed n times; at most 3: co-located exchange kernels each hold a hardware queue): with a cloud so small
-that the kernels' work is negligible, the time per evaluation beyond the plain handle's is the exchange (two flag round
-trips + slice reduce + delivery), the extra launch and the host-thread hand-off.  Also the 10M-point case for the record
-(there the shards' kernels share the one GPU, so nothing is gained -- it only shows the protocol at full size).
+"""Protocol cost of the in-library sharded evaluation on ONE GPU (the same device listed n times, every shard driven by its
+own host thread on its own hardware queue like shards on different devices): with a cloud so small that the kernels' work
+is negligible, the time per evaluation beyond the plain handle's is the protocol -- the announce at the end of the histogram
+kernel, k_entropy_owned's flag wait and push, k_entropy_gather's flag wait, one more launch, the host-thread hand-off.
+Also the 10M-point case for the record (there the shards' kernels share the one GPU, so nothing is gained -- it only shows
+the protocol at full size).  The plain handle is measured on both routes (one fused kernel / three kernels).
 Usage: shard_cost.py [bins]"""
 import json
 import os
@@ -11,7 +13,8 @@ import time
 
 import numpy as np
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # co-located shards must not share an in-order hardware queue
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")  # co-located shards driven by worker threads must not share an in-order hardware queue
+os.environ["NIDREG_SHARD_COLOCATED_WORKERS"] = "1"
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -25,8 +28,9 @@ for label, n_points in (("tiny", 4096), ("10M", 10_000_000)):
     rng = np.random.default_rng(3)
     poses = np.ascontiguousarray([synth.random_pose_near(s.T_camera_lidar_true, rng) for _ in range(40)])
     row = {}
-    for n in (1, 2, 3):
-        c = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, bins, devices=None if n == 1 else [0] * n)
+    for n in (0, 1, 2, 3, 4, 8):
+        os.environ["NIDREG_FUSED"] = "1" if n == 0 else "0"  # n = 0: the plain handle's one-launch route; 1: its three-kernel route
+        c = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, bins, devices=None if n <= 1 else [0] * n)
         c.eval_batch(poses[:5])
         ts = []
         for _ in range(15):
@@ -38,7 +42,7 @@ for label, n_points in (("tiny", 4096), ("10M", 10_000_000)):
             t0 = time.perf_counter()
             c.eval_batch(poses, want_grad=False)
             ts2.append((time.perf_counter() - t0) / len(poses))
-        row[f"shards_{n}"] = {"us_per_eval_cost_grad": round(1e6 * float(np.median(ts)), 2), "us_per_eval_cost_only": round(1e6 * float(np.median(ts2)), 2), "cost0": float(costs[0])}
+        row["plain_fused" if n == 0 else ("plain_three_kernels" if n == 1 else f"shards_{n}")] = {"us_per_eval_cost_grad": round(1e6 * float(np.median(ts)), 2), "us_per_eval_cost_only": round(1e6 * float(np.median(ts2)), 2), "cost0": float(costs[0])}
         c.close()
     out[label] = row
 print(json.dumps(out))
