@@ -27,6 +27,25 @@
 
 namespace nidreg {
 
+// Everything the kernel needs only AFTER the histogram phase lives in device memory (written once per handle) and is read
+// through `st` where it is used: kernel arguments are all loaded at the kernel's entry and would stay live -- in SGPRs, or
+// spilled to VGPR lanes and restored inside the hot loops -- through the histogram loop (the first version, with
+// everything by value, spilled 81 SGPRs and restored 20 of them per loop iteration).
+struct FusedStatic {
+  u64* hist_buf[2];
+  long long hist_words;
+  long long* part_hj;   // [gridDim.x] fixed-point entropy partials
+  u64* row_part;        // [kFusedMaxSegs][B] row-segment sums
+  double* phi_q;        // [B]  (written by workgroup 0: nidreg_get_hist / tests)
+  double* hist_image;   // [B]
+  double* hist_points;  // [B]
+  EntropyScalars* scal;
+  double* partials;     // [12][gridDim.x]
+  double* out;
+  double* out_host;
+  unsigned int* counters;  // [1] gradient ticket, [4] entropy ticket (cost-only evaluations)
+  double* abort_host;      // host-mapped mirror of the abort flag (nullable)
+};
 struct FusedArgs {
   const void* pts;
   const Chunk* chunks;
@@ -34,26 +53,15 @@ struct FusedArgs {
   int pitch, W, H, B, GW, cshift;
   double dn_scale;  // U/36 as a subnormal double (bspline_scale)
   double inv_unit;  // 1 / U
-  u64* hist;        // this evaluation's histogram, zero on entry
-  u64* zero_buf;    // the other buffer (NULL: none)
-  long long zero_words;
-  long long* part_hj;  // [gridDim.x] fixed-point entropy partials
-  u64* row_part;       // [kFusedMaxSegs][B] row-segment sums
-  double* phi_q;       // [B]  (written by workgroup 0: nidreg_get_hist / tests)
-  double* hist_image;  // [B]
-  double* hist_points;  // [B]
-  EntropyScalars* scal;
-  double* partials;  // [12][gridDim.x]
-  double q[4];
-  double* out;
-  double* out_host;
-  double tag;
-  unsigned int* counters;     // [1] gradient ticket, [4] entropy ticket (cost-only evaluations)
+  u64* hist;        // this evaluation's histogram (= st->hist_buf[cur]), zero on entry
   unsigned int* barrier;      // grid-barrier block (kBarrierWords words, zero at handle creation)
   unsigned int bar_base;      // number of grid barriers this handle has completed before this launch
   unsigned int* abort_flag;   // device word; non-zero = a barrier timed out, the evaluation was abandoned
-  double* abort_host;         // host-mapped mirror (nullable)
   unsigned long long timeout_ticks;  // of the 100 MHz wall clock
+  const FusedStatic* st;
+  double q[4];
+  double tag;
+  int cur;  // index of this evaluation's histogram buffer
   int want_grad;
   int prio;
 };
@@ -140,35 +148,45 @@ __host__ __device__ __forceinline__ FusedSplit fused_split(int nW, int B) {
   return s;
 }
 
-// The three entropies from the partials, by every thread of the workgroup (identical bits in every workgroup: integer sums);
-// fills s_phi[r] = phi(q_r).  `writer`: this workgroup also publishes hist_image / hist_points / phi_q / scal / cost.
+// What the entropy tail needs is split around the second barrier so that as little as possible sits behind it:
+//   fused_pre   (histogram complete): the column marginal's entropy term of column `tid` -- hist_points is final
+//   fused_post  (every workgroup's row-segment sums and entropy partial published): the three entropies -- integer sums,
+//               identical bits in every workgroup -- and phi(q_r) into s_phi.  `writer`: this workgroup also publishes
+//               hist_image / phi_q / scal / cost.
 // s_redk: 3 * (kT / 64) words of LDS.
+__device__ __forceinline__ long long fused_pre(double inv_unit, const u64* hist, const FusedStatic& st, int B, double S, bool writer) {
+  const int tid = threadIdx.x;
+  long long hp_k = 0;
+  if (tid < B) {  // B <= 256 <= threads per workgroup
+    const u64* col_sum = hist + size_t(B) * size_t(B) + kTailWords;
+    const double cnt = rint(double(load_agent(col_sum + tid)) * inv_unit);  // exact inlier count of column c
+    const double p = cnt / S;
+    hp_k = ent_fixed(p * log(p + 1e-6));
+    if (writer) st.hist_points[tid] = cnt;
+  }
+  return hp_k;
+}
 template <int kT>
-__device__ __forceinline__ EntropyScalars fused_scalars(const FusedArgs& a, int B, int nW, double* s_phi, long long* s_redk, bool writer) {
+__device__ __forceinline__ EntropyScalars fused_post(double inv_unit, const FusedStatic& st, int B, int nW, double S, long long hp_k, double* s_phi, long long* s_redk, bool writer) {
   const int tid = threadIdx.x;
   const FusedSplit sp = fused_split(nW, B);
-  const double S = double(load_agent(a.hist + size_t(B) * size_t(B) + kTailInliers));
-  const u64* col_sum = a.hist + size_t(B) * size_t(B) + kTailWords;
-  long long hi_k = 0, hp_k = 0, hj_k = 0;
-  if (tid < B) {  // B <= 256 <= kT
-    u64 t = 0;
-    for (int s = 0; s < sp.segs; s++) t += load_agent(a.row_part + size_t(s) * size_t(B) + tid);
-    const double raw = double(t) * a.inv_unit;  // raw (un-normalised) hist_image[r]
+  long long hi_k = 0, hj_k = 0;
+  u64 t = 0;
+  if (tid < B)
+    for (int s = 0; s < sp.segs; s++) t += load_agent(st.row_part + size_t(s) * size_t(B) + tid);
+  for (int g = tid; g < nW; g += kT) hj_k += load_agent(st.part_hj + g);
+  if (tid < B) {
+    const double raw = double(t) * inv_unit;  // raw (un-normalised) hist_image[r]
     const double qv = raw / S;
     const double lq = log(qv + 1e-6);
     hi_k = ent_fixed(qv * lq);
     const double ph = lq + qv / (qv + 1e-6);
     s_phi[tid] = ph;
-    const double cnt = rint(double(load_agent(col_sum + tid)) * a.inv_unit);  // exact inlier count of column c
-    const double p = cnt / S;
-    hp_k = ent_fixed(p * log(p + 1e-6));
     if (writer) {
-      a.phi_q[tid] = ph;
-      a.hist_image[tid] = raw;
-      a.hist_points[tid] = cnt;
+      st.phi_q[tid] = ph;
+      st.hist_image[tid] = raw;
     }
   }
-  for (int g = tid; g < nW; g += kT) hj_k += load_agent(a.part_hj + g);
   hi_k = wave_sum(hi_k);
   hp_k = wave_sum(hp_k);
   hj_k = wave_sum(hj_k);
@@ -187,17 +205,21 @@ __device__ __forceinline__ EntropyScalars fused_scalars(const FusedArgs& a, int 
   }
   const EntropyScalars e = entropy_scalars(A, Bk, C, S);
   if (writer && tid == 0) {
-    *a.scal = e;
+    *st.scal = e;
     // agent scope: grad_final_body (another workgroup) mirrors these to the host behind the gradient
-    store_agent(&a.out[0], e.nid);
-    store_agent(&a.out[8], e.status);
-    store_agent(&a.out[9], S);
+    store_agent(&st.out[0], e.nid);
+    store_agent(&st.out[8], e.status);
+    store_agent(&st.out[9], S);
   }
   return e;
 }
 
+// 16 waves per CU (two 8-wave or four 4-wave workgroups: the chunk tables are one such round) need <= 128 VGPRs: asked for
+// explicitly where the loops fit (the fisheye / equirectangular gradient loops hold 154-161: those instantiations keep the
+// compiler's choice and nidreg.hip leaves their handles on the three-kernel route)
+constexpr int fused_min_waves(int model) { return (model == MODEL_FISHEYE || model == MODEL_EQUIRECT) ? 1 : 4; }
 template <int MODEL, typename Rec, typename real, bool WIDE>
-__global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_fused(PoseParams<real> pose, CamParams<real> cam, FusedArgs a) {
+__global__ __launch_bounds__(WIDE ? kWideThreads : kThreads, fused_min_waves(MODEL)) void k_fused(PoseParams<real> pose, CamParams<real> cam, FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int kT = WIDE ? kWideThreads : kThreads;
   constexpr int kNW = kT / 64;
@@ -224,17 +246,44 @@ __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_fused(PosePa
   NID_FSTAMP(0);
   spline_hist_body<MODEL, Rec, real, WIDE, kT>(pts, ch, a.img, a.pitch, a.W, a.H, pose, cam, B, GW, cshift, a.dn_scale, a.hist, smem, a.prio != 0);
   NID_FSTAMP(1);
+  // the arguments used from here on are re-read from the kernel-argument segment where they are needed (see FusedStatic)
+  typedef __attribute__((address_space(4))) const unsigned char kernarg_bytes_t;
+  kernarg_bytes_t* ka_base = (kernarg_bytes_t*)__builtin_amdgcn_kernarg_segment_ptr();
+  constexpr size_t ka_off = (sizeof(PoseParams<real>) + sizeof(CamParams<real>) + 7) & ~size_t(7);
+  const __attribute__((address_space(4))) FusedArgs& al = *reinterpret_cast<const __attribute__((address_space(4))) FusedArgs*>(ka_base + ka_off);
+  const FusedStatic& st = *al.st;
   if (!grid_barrier(a.barrier, a.bar_base + 1u, a.abort_flag, a.timeout_ticks, s_flag)) {
-    if (tid == 0 && a.abort_host) *a.abort_host = 1.0;
+    if (tid == 0 && st.abort_host) *st.abort_host = 1.0;
     return;
   }
   NID_FSTAMP(2);
 
-  // ---- phase 2: this workgroup's row segment(s): sum p log(p + eps) (fixed point), row-segment sums
+  // ---- phase 2: this workgroup's row segment(s): sum p log(p + eps) (fixed point), row-segment sums; and everything of
+  // phase 3's prologue that needs only the finished histogram: the column-marginal term, phi(p) of the own column(s)
+  const int want_grad = al.want_grad;
+  const double inv_unit = al.inv_unit;
+  u64* hist = st.hist_buf[al.cur];
+  const double S = double(load_agent(hist + size_t(B) * size_t(B) + kTailInliers));
+  const double scale = inv_unit / S;  // fixed-point word -> probability
+  const int tile_n = GW * B;
+  const u64* own = hist + size_t(ch.group) * size_t(tile_n);
+  const int own_n = min(GW, B - int(ch.group) * GW) * B;
+  double* gtile = reinterpret_cast<double*>(smem);  // the histogram tile's LDS, free since the flush
+  double phi_own = 0.0;  // WIDE: phi(p) of cell tid & 255 of the own column
+  if (want_grad) {
+    if (WIDE) {
+      const double p = double(load_agent(own + (tid & 255))) * scale;
+      phi_own = log(p + 1e-6) + p / (p + 1e-6);
+    } else {
+      for (int k = tid; k < own_n; k += kT) {
+        const double p = double(load_agent(own + k)) * scale;
+        gtile[uint32_t(k) << cshift] = log(p + 1e-6) + p / (p + 1e-6);  // parked in the cell's first copy until coefA / coefB are known
+      }
+    }
+  }
+  const long long hp_k = fused_pre(inv_unit, hist, st, B, S, w == 0);
   {
     const FusedSplit sp = fused_split(nW, B);
-    const double S = double(load_agent(a.hist + size_t(B) * size_t(B) + kTailInliers));
-    const double scale = a.inv_unit / S;  // fixed-point word -> probability
     long long ek = 0;
     int r0, r1, seg;
     if (nW >= B) {
@@ -250,7 +299,7 @@ __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_fused(PosePa
     for (int r = r0; r < r1; r++) {
       u64 row = 0;
       for (int c = c0 + tid; c < c1; c += kT) {
-        const u64 v = load_agent(a.hist + size_t(c) * size_t(B) + size_t(r));
+        const u64 v = load_agent(hist + size_t(c) * size_t(B) + size_t(r));
         if (v) {
           const double p = double(v) * scale;
           ek += ent_fixed(p * log(p + 1e-6));
@@ -264,7 +313,7 @@ __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_fused(PosePa
       if (tid == 0) {
         u64 t = 0;
         for (int k = 0; k < kNW; k++) t += s_row[k];
-        store_agent(a.row_part + size_t(seg) * size_t(B) + size_t(r), t);
+        store_agent(st.row_part + size_t(seg) * size_t(B) + size_t(r), t);
       }
     }
     ek = wave_sum(ek);
@@ -274,57 +323,51 @@ __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_fused(PosePa
     if (tid == 0) {
       long long t = 0;
       for (int k = 0; k < kNW; k++) t += s_redk[k];
-      store_agent(a.part_hj + w, t);
+      store_agent(st.part_hj + w, t);
     }
     // double-buffered histogram: clear the buffer the NEXT evaluation accumulates into
-    if (a.zero_buf)
-      for (long long k = (long long)w * kT + tid; k < a.zero_words; k += (long long)nW * kT) store_agent(a.zero_buf + k, u64(0));
+    u64* zero_buf = st.hist_buf[al.cur ^ 1];
+    const long long zero_words = st.hist_words;
+    for (long long k = (long long)w * kT + tid; k < zero_words; k += (long long)nW * kT) store_agent(zero_buf + k, u64(0));
   }
 
   NID_FSTAMP(3);
-  if (!a.want_grad) {
+  if (!want_grad) {
     // cost only: the last workgroup to get here finalises (every partial above was stored at agent scope)
-    if (last_workgroup_arrives<true>(a.counters + 4, unsigned(nW), s_flag)) {
-      const EntropyScalars e = fused_scalars<kT>(a, B, nW, s_phi, s_redk, true);
-      if (tid == 0 && a.out_host) {
-        a.out_host[0] = e.nid;
-        a.out_host[8] = e.status;
-        a.out_host[9] = e.S;
+    if (last_workgroup_arrives<true>(st.counters + 4, unsigned(nW), s_flag)) {
+      const EntropyScalars e = fused_post<kT>(inv_unit, st, B, nW, S, hp_k, s_phi, s_redk, true);
+      double* out_host = st.out_host;
+      if (tid == 0 && out_host) {
+        out_host[0] = e.nid;
+        out_host[8] = e.status;
+        out_host[9] = e.S;
         __threadfence_system();
-        __hip_atomic_store(&a.out_host[15], a.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&out_host[15], al.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
     return;
   }
-  if (!grid_barrier(a.barrier, a.bar_base + 2u, a.abort_flag, a.timeout_ticks, s_flag)) {
-    if (tid == 0 && a.abort_host) *a.abort_host = 1.0;
+  if (!grid_barrier(al.barrier, al.bar_base + 2u, al.abort_flag, al.timeout_ticks, s_flag)) {
+    if (tid == 0 && st.abort_host) *st.abort_host = 1.0;
     return;
   }
   NID_FSTAMP(4);
 
   // ---- phase 3: entropies -> G tile -> gradient of this chunk
-  const EntropyScalars e = fused_scalars<kT>(a, B, nW, s_phi, s_redk, w == 0);
-  double* gtile = reinterpret_cast<double*>(smem);
+  const EntropyScalars e = fused_post<kT>(inv_unit, st, B, nW, S, hp_k, s_phi, s_redk, w == 0);
   {
-    const double scale = a.inv_unit / e.S;
-    const int tile_n = GW * B;
-    const u64* src = a.hist + size_t(ch.group) * size_t(tile_n);
-    const int ncols = min(GW, B - int(ch.group) * GW);
-    const int n = ncols * B;
+    // G = (coefA phi(p) + coefB phi(q_r)) / 12: the tap loop works with 6 b and 2 db/ds (bspline6 / bspline_deriv2)
     const uint32_t cmask = (1u << cshift) - 1u;
     if (WIDE) {
       // 256 cells x 32 copies at byte address (cell << 8) | (copy << 3): thread t takes cell t & 255, the 16 copies of half t >> 8
       const int cell = tid & 255, half = tid >> 8;
-      const double p = double(load_agent(src + cell)) * scale;
-      const double gval = (e.coefA * (log(p + 1e-6) + p / (p + 1e-6)) + e.coefB * s_phi[cell]) * (1.0 / 12.0);
+      const double gval = (e.coefA * phi_own + e.coefB * s_phi[cell]) * (1.0 / 12.0);
       static_assert(kWideThreads == 512, "the G tile fill assumes two threads per cell");
 #pragma unroll
       for (int j = 0; j < 16; j++) gtile[(cell << kWideShift) + half * 16 + j] = gval;
     } else {
-      for (int k = tid; k < n; k += kT) {
-        const double p = double(load_agent(src + k)) * scale;
-        // times 1/12: the tap loop works with 6 b and 2 db/ds (bspline6 / bspline_deriv2)
-        const double gval = (e.coefA * (log(p + 1e-6) + p / (p + 1e-6)) + e.coefB * s_phi[k % B]) * (1.0 / 12.0);
+      for (int k = tid; k < own_n; k += kT) {
+        const double gval = (e.coefA * gtile[uint32_t(k) << cshift] + e.coefB * s_phi[k % B]) * (1.0 / 12.0);
         for (uint32_t j = 0; j <= cmask; j++) gtile[(uint32_t(k) << cshift) + ((j + uint32_t(k)) & cmask)] = gval;
       }
     }
@@ -338,10 +381,10 @@ __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_fused(PosePa
   spline_grad_loop<MODEL, Rec, real, WIDE ? TAP_WIDE : TAP_COPIES, kT>(pts, ch, a.img, a.pitch, a.W, a.H, pose, cam, B, GW, cshift, gtile, acc, a.prio != 0);
   NID_FSTAMP(6);
   __syncthreads();  // s_red aliases the reduction scratch of fused_scalars
-  grad_reduce_store<kT>(acc, s_red, a.partials, unsigned(w), unsigned(nW));
+  grad_reduce_store<kT>(acc, s_red, st.partials, unsigned(w), unsigned(nW));
   NID_FSTAMP(7);
-  if (last_workgroup_arrives<true>(a.counters + 1, unsigned(nW), s_flag))
-    grad_final_body<kT>(a.partials, nW, a.q[0], a.q[1], a.q[2], a.q[3], a.out, a.out_host, a.tag, s_red);
+  if (last_workgroup_arrives<true>(st.counters + 1, unsigned(nW), s_flag))
+    grad_final_body<kT>(st.partials, nW, al.q[0], al.q[1], al.q[2], al.q[3], st.out, st.out_host, al.tag, s_red);
 }
 
 // dynamic LDS of k_fused: the histogram / G tile + phi table + reduction scratch

@@ -52,18 +52,11 @@ struct PassArgs {
   unsigned int* ann_ticket;
   int prio;  // progress priority (s_setprio) in the spline passes: set when the evaluation has its device to itself
   // the one-launch evaluation (k_fused, nid_fused.hpp); chunks / nchunks = the histogram pass's table
-  unsigned long long* zero_buf;
-  long long zero_words;
-  long long* part_hj;
-  unsigned long long* row_part;
-  double* hist_image;
-  double* hist_points;
-  EntropyScalars* scal_out;
-  unsigned int* counters;
+  const void* fused_static;  // device FusedStatic of the handle
+  int hist_cur;              // index of the histogram buffer this evaluation accumulates into
   unsigned int* barrier;
   unsigned int bar_base;
   unsigned int* abort_flag;
-  double* abort_host;
   unsigned long long timeout_ticks;
   int want_grad;
   size_t lds_fused;

@@ -214,25 +214,14 @@ static FusedArgs make_fused_args(const PassArgs& a) {
   f.dn_scale = a.magic;
   f.inv_unit = a.inv_unit;
   f.hist = a.hist;
-  f.zero_buf = a.zero_buf;
-  f.zero_words = a.zero_words;
-  f.part_hj = a.part_hj;
-  f.row_part = a.row_part;
-  f.phi_q = const_cast<double*>(a.phi_q);
-  f.hist_image = a.hist_image;
-  f.hist_points = a.hist_points;
-  f.scal = a.scal_out;
-  f.partials = a.partials;
-  for (int k = 0; k < 4; k++) f.q[k] = a.q[k];
-  f.out = a.out;
-  f.out_host = a.out_host;
-  f.tag = a.tag;
-  f.counters = a.counters;
   f.barrier = a.barrier;
   f.bar_base = a.bar_base;
   f.abort_flag = a.abort_flag;
-  f.abort_host = a.abort_host;
   f.timeout_ticks = a.timeout_ticks;
+  f.st = static_cast<const FusedStatic*>(a.fused_static);
+  for (int k = 0; k < 4; k++) f.q[k] = a.q[k];
+  f.tag = a.tag;
+  f.cur = a.hist_cur;
   f.want_grad = a.want_grad;
   f.prio = a.prio;
   return f;

@@ -125,6 +125,7 @@ struct nidreg_handle {
   bool fused_off = false;
   bool fused_inflight = false;
   size_t lds_fused = 0;
+  void* d_fused_static = nullptr;     // device FusedStatic (nid_fused.hpp), carved from d_scratch
   unsigned int* d_barrier = nullptr;  // grid-barrier block of k_fused (kBarrierWords words, carved from d_scratch)
   unsigned int bar_base = 0;          // grid barriers completed by this handle's fused launches so far
   unsigned long long fused_timeout_ticks = 500000ull;  // 5 ms of the 100 MHz wall clock
@@ -437,18 +438,11 @@ int eval_launch_fused(nidreg_handle* h, const double* se3, bool want_grad) {
   HIP_TRY(begin_histogram(h));
   a.hist = h->d_hist;
   a.prio = 1;
-  a.zero_buf = h->d_hist_buf[h->hist_cur ^ 1];
-  a.zero_words = h->hist_words;
-  a.part_hj = h->d_part_hj;
-  a.row_part = h->d_row_part;
-  a.hist_image = h->d_hist_image;
-  a.hist_points = h->d_hist_points;
-  a.scal_out = h->d_scal;
-  a.counters = h->d_counters;
+  a.fused_static = h->d_fused_static;
+  a.hist_cur = h->hist_cur;
   a.barrier = h->d_barrier;
   a.bar_base = h->bar_base;
   a.abort_flag = h->d_counters + 5;
-  a.abort_host = h->d_out_host + 11;
   a.timeout_ticks = h->fused_timeout_ticks;
   a.want_grad = want_grad ? 1 : 0;
   a.lds_fused = h->lds_fused;
@@ -928,6 +922,7 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
     const size_t o_partials = carve(size_t(chunks_max) * 12 * sizeof(double));
     const size_t o_counters = carve(8 * sizeof(unsigned int));
     const size_t o_barrier = carve(size_t(kBarrierWords) * sizeof(unsigned int));
+    const size_t o_fstatic = carve(sizeof(FusedStatic));
     CREATE_TRY(hipMalloc(&h->d_scratch, off));
     CREATE_TRY(hipMemset(h->d_scratch, 0, off));
     char* base = static_cast<char*>(h->d_scratch);
@@ -940,6 +935,7 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
     h->d_partials = reinterpret_cast<double*>(base + o_partials);
     h->d_counters = reinterpret_cast<unsigned int*>(base + o_counters);
     h->d_barrier = reinterpret_cast<unsigned int*>(base + o_barrier);
+    h->d_fused_static = base + o_fstatic;
   }
   CREATE_TRY(hipHostMalloc(&h->h_out, NIDREG_OUT_DOUBLES * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
   std::memset(h->h_out, 0, NIDREG_OUT_DOUBLES * sizeof(double));
@@ -954,6 +950,23 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
   // once, which the table's construction aimed at for k_spline_hist -- checked here against k_fused's own occupancy
   // (the fisheye / equirectangular instantiations hold more registers: they keep the three-kernel path)
   if (d->mode == NIDREG_MODE_SPLINE && h->own_hist && h->d_out_host && !opts.shard && h->own_stream) {
+    FusedStatic fs;
+    std::memset(&fs, 0, sizeof(fs));
+    fs.hist_buf[0] = h->d_hist_buf[0];
+    fs.hist_buf[1] = h->d_hist_buf[1];
+    fs.hist_words = h->hist_words;
+    fs.part_hj = h->d_part_hj;
+    fs.row_part = h->d_row_part;
+    fs.phi_q = h->d_phi_q;
+    fs.hist_image = h->d_hist_image;
+    fs.hist_points = h->d_hist_points;
+    fs.scal = h->d_scal;
+    fs.partials = h->d_partials;
+    fs.out = h->d_out;
+    fs.out_host = h->d_out_host;
+    fs.counters = h->d_counters;
+    fs.abort_host = h->d_out_host + 11;
+    CREATE_TRY(hipMemcpy(h->d_fused_static, &fs, sizeof(fs), hipMemcpyHostToDevice));
     const char* env = std::getenv("NIDREG_FUSED");
     const bool enabled = !(env && *env == '0');
     const int table = h->d_chunks_hist ? h->nchunks_hist : h->nchunks;

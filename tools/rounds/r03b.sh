@@ -3,7 +3,7 @@
 # protocol cost).  Everything lands in gpurun_out/r03b/.
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd $REPO
-O=$REPO/gpurun_out/r03b
+O=$REPO/gpurun_out/${RTAG:-r03b}
 mkdir -p $O
 export TMPDIR=/tmp
 timeout 300 python tools/make_scene_cache.py /tmp/scene.npz > $O/make_scene.log 2>&1
