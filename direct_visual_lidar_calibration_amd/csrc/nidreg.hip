@@ -990,8 +990,9 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
 // MultiNIDCost evaluates every pair at the same pose (visual_camera_calibration.cpp:147-173).  Launching three kernels
 // per pair makes k small pairs on one GPU launch- and prologue-bound (8 x 1.25M points: 337 us against 160 us for one
 // 10M-point pair); a group launches THREE kernels in all, whose combined chunk tables give every pair a share of the
-// one round of co-resident workgroups in proportion to its points.  Results are bit-identical to evaluating the handles
-// one by one (each pair keeps its own histogram buffers, fixed-point unit, scratch and result block).
+// one round of co-resident workgroups in proportion to its points.  Every pair's cost and histogram are bit-identical to
+// evaluating the handles one by one (each pair keeps its own histogram buffers, fixed-point unit, scratch and result block);
+// the gradient's workgroup partials follow the group's chunk table: equal up to summation order.
 struct MultiGroup {
   std::vector<nidreg_handle*> hs;
   int device = 0;
@@ -1000,9 +1001,19 @@ struct MultiGroup {
   Chunk* d_chunks = nullptr;       // gradient pass / generic histogram kernels
   Chunk* d_chunks_hist = nullptr;  // WIDE histogram kernel
   int nchunks = 0, nchunks_hist = 0;
+  std::atomic<int> users{0};  // evaluations running on this group (acquire_group / release_group)
+  uint64_t last_use = 0;
 };
+// The cache of groups: keyed by the exact handle list, at most kMaxGroups entries (least recently used first out), plus a
+// short list of handle lists that cannot be grouped (a pair's partial buffer too small for its share of the table) so that
+// the chunk tables are not rebuilt on every call.  A group in use is never freed: acquire_group / release_group count the
+// evaluations running on it, and a handle's destruction waits for them.
+constexpr size_t kMaxGroups = 16, kMaxRejected = 32;
 std::mutex g_groups_mu;
 std::vector<MultiGroup*> g_groups;
+std::vector<std::vector<nidreg_handle*>> g_rejected;
+uint64_t g_group_clock = 0;
+void release_group(MultiGroup* g) { g->users.fetch_sub(1, std::memory_order_acq_rel); }
 
 void free_group(MultiGroup* g) {
   (void)hipSetDevice(g->device);
@@ -1015,14 +1026,28 @@ void free_group(MultiGroup* g) {
 }
 // called by free_handle: a group dies with any of its members
 void drop_groups_of(const nidreg_handle* h) {
-  std::lock_guard<std::mutex> lk(g_groups_mu);
-  for (size_t i = 0; i < g_groups.size();) {
-    if (std::find(g_groups[i]->hs.begin(), g_groups[i]->hs.end(), h) != g_groups[i]->hs.end()) {
-      free_group(g_groups[i]);
-      g_groups.erase(g_groups.begin() + long(i));
-    } else {
-      i++;
+  std::vector<MultiGroup*> dead;
+  {
+    std::lock_guard<std::mutex> lk(g_groups_mu);
+    for (size_t i = 0; i < g_groups.size();) {
+      if (std::find(g_groups[i]->hs.begin(), g_groups[i]->hs.end(), h) != g_groups[i]->hs.end()) {
+        dead.push_back(g_groups[i]);
+        g_groups.erase(g_groups.begin() + long(i));
+      } else {
+        i++;
+      }
     }
+    for (size_t i = 0; i < g_rejected.size();) {
+      if (std::find(g_rejected[i].begin(), g_rejected[i].end(), h) != g_rejected[i].end()) {
+        g_rejected.erase(g_rejected.begin() + long(i));
+      } else {
+        i++;
+      }
+    }
+  }
+  for (MultiGroup* g : dead) {
+    while (g->users.load(std::memory_order_acquire) > 0) std::this_thread::yield();  // an evaluation of another thread still runs on it
+    free_group(g);
   }
 }
 
@@ -1054,10 +1079,17 @@ void pair_chunks(const nidreg_handle* h, int pair, int64_t target, int threads, 
   }
 }
 
+// returns the group with its use count raised (release_group when the evaluation is over), or nullptr
 MultiGroup* find_or_make_group(nidreg_handle* const* handles, int n) {
   std::lock_guard<std::mutex> lk(g_groups_mu);
   for (MultiGroup* g : g_groups)
-    if (int(g->hs.size()) == n && std::equal(g->hs.begin(), g->hs.end(), handles)) return g;
+    if (int(g->hs.size()) == n && std::equal(g->hs.begin(), g->hs.end(), handles)) {
+      g->users.fetch_add(1, std::memory_order_acq_rel);
+      g->last_use = ++g_group_clock;
+      return g;
+    }
+  for (const auto& r : g_rejected)
+    if (int(r.size()) == n && std::equal(r.begin(), r.end(), handles)) return nullptr;
   MultiGroup* g = new MultiGroup();
   g->hs.assign(handles, handles + n);
   g->device = handles[0]->device;
@@ -1095,8 +1127,10 @@ MultiGroup* find_or_make_group(nidreg_handle* const* handles, int n) {
     e.zero_words = h->hist_words;
     e.chunk_base = base;
     e.nchunks = int(chunks.size()) - base;
-    if (e.nchunks > std::max(h->nchunks, 1)) {  // the pair's partial buffer holds 12 doubles per chunk of ITS OWN table
+    if (e.nchunks > std::max(std::max(h->nchunks, h->nchunks_hist), 1)) {  // the pair's partial buffer holds 12 doubles per chunk of ITS OWN table
       delete g;
+      if (g_rejected.size() >= kMaxRejected) g_rejected.erase(g_rejected.begin());
+      g_rejected.emplace_back(handles, handles + n);
       return nullptr;
     }
   }
@@ -1116,6 +1150,17 @@ MultiGroup* find_or_make_group(nidreg_handle* const* handles, int n) {
   }
   g->nchunks = int(chunks.size());
   g->nchunks_hist = int(wide_chunks.size());
+  // least recently used out (never one that is being evaluated)
+  while (g_groups.size() >= kMaxGroups) {
+    size_t victim = g_groups.size();
+    for (size_t i = 0; i < g_groups.size(); i++)
+      if (g_groups[i]->users.load(std::memory_order_acquire) == 0 && (victim == g_groups.size() || g_groups[i]->last_use < g_groups[victim]->last_use)) victim = i;
+    if (victim == g_groups.size()) break;
+    free_group(g_groups[victim]);
+    g_groups.erase(g_groups.begin() + long(victim));
+  }
+  g->users.store(1, std::memory_order_release);
+  g->last_use = ++g_group_clock;
   g_groups.push_back(g);
   return g;
 }
@@ -1739,6 +1784,7 @@ int nidreg_eval_multi(nidreg_handle* const* handles, int n, const double* init_s
         double costs[kMaxMulti], grads[kMaxMulti * 7];
         bool all_ok = true;
         const int rc = group_eval(g, se3, grad7 != nullptr, costs, grad7 ? grads : nullptr, &all_ok);
+        release_group(g);
         if (rc < 0) return rc;
         double csum = 0.0, gsum[7] = {0, 0, 0, 0, 0, 0, 0};
         for (int i = 0; i < n; i++) {
@@ -1799,6 +1845,7 @@ int nidreg_eval_iso_multi(nidreg_handle* const* handles, int n, const double* T,
     if (g) {
       double costs[kMaxMulti];
       const int rc = group_eval_iso(g, T, costs);
+      release_group(g);
       if (rc < 0) return rc;
       double csum = 0.0;
       for (int i = 0; i < n; i++) csum += costs[i];

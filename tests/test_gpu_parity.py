@@ -729,6 +729,48 @@ def test_nidreg_devices_environment_shards_an_unchanged_caller(monkeypatch):
     sh.close()
 
 
+def test_points_on_knot_and_border_boundaries():
+    """The SPLINE kernels divide by v_rcp_f64 + ONE Newton step (csrc/nid_device.hpp fast_rcp: <= 2^-46 relative, i.e.
+    3e-11 px on a 2000-px coordinate) where the reference divides exactly.  Knot decisions near integer pixel coordinates
+    cannot matter -- the cubic B-spline weights are continuous across knots (at s -> 1 the weights of knot k equal those of
+    knot k + 1 at s = 0) -- and the in-image decision can only differ inside that band around the image border.  Points
+    placed +-1e-12 .. 1e-9 px around knots, and >= 1e-9 px inside / outside the borders: same inlier count, histogram, cost
+    and gradient as the oracle."""
+    s = scene_for("plumb_bob", n=2000)
+    W, H = s.width, s.height
+    fx, fy, cx, cy = s.intrinsics[:4]
+    dist = [0.0] * 5  # invertible in closed form
+    rng = np.random.default_rng(12)
+    n = 6000
+    ku = rng.integers(2, W - 2, n).astype(np.float64)
+    kv = rng.integers(2, H - 2, n).astype(np.float64)
+    deltas = np.array([0.0, 1e-12, -1e-12, 1e-10, -1e-10, 1e-9, -1e-9])
+    u = ku + deltas[rng.integers(0, len(deltas), n)]
+    v = kv + deltas[rng.integers(0, len(deltas), n)]
+    # borders: well-resolved distances only (>= 1e-9 px from the edge, on both sides)
+    nb = 400
+    edge = np.array([1e-9, -1e-9, 1e-6, -1e-6])
+    ub = np.where(rng.random(nb) < 0.5, 0.0, float(W)) + edge[rng.integers(0, 4, nb)]
+    vb = rng.uniform(5, H - 5, nb)
+    u = np.concatenate([u, ub, rng.uniform(5, W - 5, nb)])
+    v = np.concatenate([v, vb, np.where(rng.random(nb) < 0.5, 0.0, float(H)) + edge[rng.integers(0, 4, nb)]])
+    z = rng.uniform(2.0, 30.0, u.shape[0])
+    pts = np.stack([(u - cx) / fx * z, (v - cy) / fy * z, z, np.ones_like(z)], -1)
+    ints = (np.floor(rng.random(u.shape[0]) * 256) / 256).astype(np.float64)
+    x = np.array([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0])  # p_cam = p: the placement survives the transform
+    proj = nid.create_camera("plumb_bob", list(s.intrinsics[:4]), dist)
+    for bins in (16, 256):
+        cost = nid.NIDCost(proj, s.image_f64, pts, ints, bins)
+        assert cost.info()["float32_records"] == 0  # these coordinates do not round-trip through float: double records
+        ref = oracle_lib.nid_cost("plumb_bob", list(s.intrinsics[:4]), dist, s.image_f64, pts, ints, bins, x, want_hist=True)
+        ok, c, g = cost(x)
+        joint, hi, hp = cost.histograms()
+        assert ok and ref["ok"] and np.array_equal(hp, ref["hist_points"])  # same inlier decisions
+        assert np.abs(joint - ref["hist"]).max() <= 1e-9 and abs(c - ref["cost"]) <= 1e-10
+        assert np.allclose(g, ref["grad"], rtol=1e-7, atol=1e-10)
+        cost.close()
+
+
 def test_input_order_flag_and_strided_points():
     """NIDREG_FLAG_INPUT_ORDER (stable sort on the column-group bits only) and a point stride > 32 bytes: same bits."""
     from direct_visual_lidar_calibration_amd import _lib

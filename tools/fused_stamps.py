@@ -48,4 +48,16 @@ for j, nm in enumerate(names):
     last = np.mean([r[:, j].max() for r in rows])
     dur = np.mean([(r[:, j] - r[:, j - 1]).mean() for r in rows]) if j else 0.0
     print(f"{nm:<26}{first:9.2f}{mean:9.2f}{last:9.2f}   {dur:9.2f}")
+# where the spread comes from: mean duration of the two streaming phases by dispatch slot (first / second workgroup of a
+# CU: the grid is dispatched in index order, 256 CUs), by XCD (index mod 8) and by column pair
+for name, j in (("hist phase", 1), ("gradient loop", 6)):
+    dur = np.mean([r[:, j] - r[:, j - 1] for r in rows], axis=0)
+    n = dur.shape[0]
+    half = n // 2
+    print(f"{name}: mean {dur.mean():.2f} us, std {dur.std():.2f}; first half of the grid {dur[:half].mean():.2f}, second half {dur[half:].mean():.2f}; by index mod 8: " +
+          " ".join(f"{dur[k::8].mean():.2f}" for k in range(8)))
+    # the two workgroups of a column are neighbours in the chunk table: how much of the spread is between columns?
+    pair = dur[: n - n % 2].reshape(-1, 2)
+    print(f"    std of column means {pair.mean(axis=1).std():.2f}, mean |difference| within a column {np.abs(pair[:, 0] - pair[:, 1]).mean():.2f}; run-to-run std of one workgroup's duration "
+          f"{np.std([r[:, j] - r[:, j - 1] for r in rows], axis=0).mean():.2f}")
 cost.close()
