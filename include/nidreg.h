@@ -45,10 +45,12 @@
  *     concurrent calls on the same handle are not supported (never happens in the reference).
  *     Handles sharded over several GPUs are evaluated one after the other on every device they share
  *     (a per-device lock inside nidreg_eval*: each of them uses all of its GPUs anyway).
- *   - an evaluation that has its device to itself runs as ONE kernel (histogram -> grid barrier -> entropy ->
- *     grid barrier -> gradient, csrc/nid_fused.hpp) and with issue priority by progress; evaluations that
- *     share a device (concurrent callers, other processes) run as three kernels without it.  The cost and the
- *     histograms are bit-identical on both routes, the gradient equal up to the order of the workgroup partials.
+ *   - an evaluation that has its device to itself runs with issue priority by progress in the two streaming kernels;
+ *     evaluations that share a device (concurrent callers) run without it.  NIDREG_FUSED=1 in the environment at handle
+ *     creation (opt-in; measured equal to the default route on the headline workload and slower at 50M points) runs such
+ *     an evaluation as ONE kernel: histogram -> grid barrier -> entropy -> grid barrier -> gradient (csrc/nid_fused.hpp).
+ *     The cost and the histograms are bit-identical on both routes (fixed-point histogram, fixed-point entropy sums), the
+ *     gradient equal up to the order of the workgroup partials.
  *   - the caller keeps ownership of every host buffer; nidreg_create copies what it needs.
  */
 #ifndef NIDREG_H
@@ -277,7 +279,7 @@ int nidreg_get_timing(nidreg_handle* h, float* ms6);
 /* layout facts for DESIGN.md / bench: [0]=record bytes per point on device, [1]=number of chunks,
  * [2]=columns per group, [3]=fixed-point fraction bits, [4]=LDS bytes per workgroup,
  * [5]=padded image pitch, [6]=points stored, [7]=bit0: float32 records, bit1: nidreg_eval runs as ONE fused kernel when the
- * handle has its device to itself (csrc/nid_fused.hpp; NIDREG_FUSED=0 in the environment at creation keeps three kernels),
+ * handle has its device to itself (csrc/nid_fused.hpp; opt-in: NIDREG_FUSED=1 in the environment at creation),
  * bits 8..: LDS copies per histogram cell */
 int nidreg_get_info(nidreg_handle* h, int64_t* info8);
 

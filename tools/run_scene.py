@@ -42,7 +42,7 @@ for _ in range(5):
     cost.eval_batch(block)
     wb.append((time.perf_counter() - t0) * 1e3 / len(block))
 wall_batch_ms = float(np.median(wb))
-# the whole evaluation between two HIP events, whichever route runs it (one fused kernel unless NIDREG_FUSED=0)
+# the whole evaluation between two HIP events, whichever route runs it (one fused kernel with NIDREG_FUSED=1)
 cost.set_timing(2)
 whole = []
 for k in range(max(steps, 10)):
