@@ -829,56 +829,28 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
   {
     int num_cus = 256;
     if (hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || num_cus <= 0) num_cus = 256;
-    // Dispatch-slot weights.  The grid is one round of co-resident workgroups dispatched in index order: indices [0, CUs) are
-    // the first workgroup of their CU, [CUs, 2 CUs) the second, ...  The first-dispatched workgroup of a CU runs faster than
-    // the later ones, systematically (stamped timeline of the headline workload, profiles/r03d_workgroup_spread.txt: equal
-    // chunks finish after 50.1 us in the first half of the table and 54.5 us in the second, run-to-run std 0.4 us), and a
-    // pass is as long as its slowest workgroup.  A column group's parts are therefore emitted PART-MAJOR (part j of every
-    // group in the j-th stretch of the table, i.e. in dispatch slot j) and sized by the slot's weight.  Static, so the
-    // gradient's workgroup partials -- hence its bits -- stay reproducible from run to run.
-    auto slot_weights = [&](const char* env_name, int nslots, const double* dflt) {
-      std::vector<double> w(dflt, dflt + nslots);
-      if (const char* e = std::getenv(env_name)) {
-        const char* p = e;
-        for (int k = 0; k < nslots && *p; k++) {
-          char* end = nullptr;
-          const double v = std::strtod(p, &end);
-          if (end == p) break;
-          if (v > 0.1 && v < 10.0) w[size_t(k)] = v;
-          p = (*end == ',') ? end + 1 : end;
-        }
-      }
-      return w;
-    };
-    auto build_chunks = [&](int target, int threads, const std::vector<double>& weights, std::vector<Chunk>& chunks) {
+    // (Tried and dropped: emitting a group's parts part-major -- part j of every group in dispatch slot j of the CUs -- and
+    // sizing them by slot weights.  The first-dispatched workgroup of a CU does run ~8 % faster than the second, systematically
+    // (profiles/r03d_workgroup_spread.txt), but the workgroups of one CU share its issue capacity: what ends a pass is the
+    // slowest CU, not the slowest workgroup, and no weighting moved the kernel times (profiles/r03e_slot_weights_no_gain.txt;
+    // the part-major order itself cost 3 us in the gradient pass).)
+    auto build_chunks = [&](int target, int threads, std::vector<Chunk>& chunks) {
       int64_t CH = (N + target - 1) / std::max(target, 1);
       CH = std::max<int64_t>(threads, ((CH + threads - 1) / threads) * threads);
-      std::vector<std::vector<Chunk>> by_part;
       for (int g = 0; g < h->NG; g++) {
         const int64_t cnt = gcount[g + 1] - gcount[g];
         if (cnt <= 0) continue;
         const int64_t parts = (cnt + CH - 1) / CH;
-        double wsum = 0.0;
-        for (int64_t p = 0; p < parts; p++) wsum += weights[size_t(std::min<int64_t>(p, int64_t(weights.size()) - 1))];
-        int64_t s = gcount[g];
-        double acc = 0.0;
-        for (int64_t p = 0; p < parts && s < gcount[g + 1]; p++) {
-          acc += weights[size_t(std::min<int64_t>(p, int64_t(weights.size()) - 1))];
-          // boundaries at multiples of 64 records (1 KB): chunk starts stay aligned
-          int64_t e = p + 1 == parts ? gcount[g + 1] : gcount[g] + ((int64_t(double(cnt) * acc / wsum) + 63) / 64) * 64;
-          e = std::min(e, gcount[g + 1]);
-          if (e <= s) continue;
+        const int64_t size = (((cnt + parts - 1) / parts + 63) / 64) * 64;  // 64 records = 1 KB: chunk starts stay aligned
+        for (int64_t s = gcount[g]; s < gcount[g + 1]; s += size) {
           Chunk c;
           c.start = uint32_t(s);
-          c.count = uint32_t(e - s);
+          c.count = uint32_t(std::min<int64_t>(size, gcount[g + 1] - s));
           c.group = uint32_t(g);
           c.pad = 0;
-          if (by_part.size() <= size_t(p)) by_part.resize(size_t(p) + 1);
-          by_part[size_t(p)].push_back(c);
-          s = e;
+          chunks.push_back(c);
         }
       }
-      for (const auto& part : by_part) chunks.insert(chunks.end(), part.begin(), part.end());
     };
     // workgroups per CU that are really co-resident for THIS kernel instantiation: 4 for the pinhole family, 3 for the
     // fisheye / equirectangular gradient kernels (154-161 VGPRs) -- 1024 chunks there meant 1.33 rounds
@@ -895,18 +867,14 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
     h->num_cus = num_cus;
     h->per_cu_grad = h->wide ? per_cu_grad : std::min(per_cu_grad, per_cu_hist);
     h->per_cu_hist = per_cu_hist;
-    // slot weights measured on the headline workload (profiles/r03e_slot_weights.txt); NIDREG_SLOT_WEIGHTS_{HIST,GRAD}=a,b,c,d re-tune
-    const double w_two[4] = {1.0, 1.0, 1.0, 1.0}, w_four[4] = {1.0, 1.0, 1.0, 1.0};
-    const std::vector<double> wg = slot_weights("NIDREG_SLOT_WEIGHTS_GRAD", 4, w_four);
-    const std::vector<double> wh = h->wide ? slot_weights("NIDREG_SLOT_WEIGHTS_HIST", 4, w_two) : wg;
     std::vector<Chunk> chunks;
-    build_chunks(d->target_blocks > 0 ? d->target_blocks : (h->wide ? per_cu_grad : std::min(per_cu_grad, per_cu_hist)) * num_cus, kThreads, wg, chunks);
+    build_chunks(d->target_blocks > 0 ? d->target_blocks : (h->wide ? per_cu_grad : std::min(per_cu_grad, per_cu_hist)) * num_cus, kThreads, chunks);
     h->nchunks = int(chunks.size());
     CREATE_TRY(hipMalloc(&h->d_chunks, std::max<size_t>(chunks.size(), 1) * sizeof(Chunk)));
     if (!chunks.empty()) CREATE_TRY(hipMemcpy(h->d_chunks, chunks.data(), chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice));
     if (h->wide) {
       std::vector<Chunk> wide_chunks;
-      build_chunks(d->target_blocks > 0 ? d->target_blocks : per_cu_hist * num_cus, kWideThreads, wh, wide_chunks);
+      build_chunks(d->target_blocks > 0 ? d->target_blocks : per_cu_hist * num_cus, kWideThreads, wide_chunks);
       h->nchunks_hist = int(wide_chunks.size());
       CREATE_TRY(hipMalloc(&h->d_chunks_hist, std::max<size_t>(wide_chunks.size(), 1) * sizeof(Chunk)));
       if (!wide_chunks.empty()) CREATE_TRY(hipMemcpy(h->d_chunks_hist, wide_chunks.data(), wide_chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice));

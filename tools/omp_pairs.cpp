@@ -52,7 +52,9 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < img.size(); i++) img[i] = double(simg[i]) * (1.0 / 255.0);
   }
   std::printf("{\"data\": \"%s\", \"multi_grid\": \"%s\"", scene_n ? "scene" : "uniform random", std::getenv("NIDREG_NO_MULTI_GRID") ? "off (per-pair launches)" : "on");
-  for (int k : {1, 2, 4, 8}) {
+  std::vector<int> ks = {1, 2, 4, 8};
+  if (argc > 4) ks.assign(1, std::atoi(argv[4]));  // one pair count only (kernel traces)
+  for (int k : ks) {
     const long n = (scene_n ? std::min(total, scene_n) : total) / k;
     std::vector<nidreg_handle*> hs;
     for (int p = 0; p < k; p++) {
