@@ -458,10 +458,11 @@ __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_spline_hist(
   constexpr int kT = WIDE ? kWideThreads : kThreads;
   const Chunk ch = chunks[blockIdx.x];
   if constexpr (MULTI) {  // one grid over several pairs: this chunk's pair brings its own records, bin image, histogram and unit
-    const MultiEntry& e = multi[ch.pad];
+    const uint32_t pair = ch.pad & 0xffu;  // Chunk::pad = pair | (index of the chunk among its pair's chunks) << 8
+    const MultiEntry& e = multi[pair];
     pts = static_cast<const Rec*>(e.pts);
     img = e.img;
-    hist = e.hist_buf[dyn.cur[ch.pad]];
+    hist = e.hist_buf[dyn.cur[pair]];
     dn_scale = e.k16;
   }
   spline_hist_body<MODEL, Rec, real, WIDE, kT>(pts, ch, img, pitch, W, H, pose, cam, B, GW, cshift, dn_scale, hist, smem, prio != 0);
@@ -490,10 +491,11 @@ __global__ __launch_bounds__(kThreads) void k_nearest_hist(
   const int tid = threadIdx.x;
   const Chunk ch = chunks[blockIdx.x];
   if constexpr (MULTI) {  // one grid over several pairs (see k_spline_hist)
-    const MultiEntry& e = multi[ch.pad];
+    const uint32_t pair = ch.pad & 0xffu;  // Chunk::pad = pair | (index of the chunk among its pair's chunks) << 8
+    const MultiEntry& e = multi[pair];
     pts = static_cast<const Rec*>(e.pts);
     img = e.img;
-    hist = e.hist_buf[dyn.cur[ch.pad]];
+    hist = e.hist_buf[dyn.cur[pair]];
   }
   for (int k = tid; k < tile_w; k += kThreads) tile[k] = 0;
   if (tid == 0) *s_inl = 0;
@@ -1020,19 +1022,20 @@ __global__ __launch_bounds__(kThreads, NID_GRAD_MIN_WAVES) void k_spline_grad(
   const Chunk ch = chunks[blockIdx.x];
   unsigned int my_block = blockIdx.x, my_blocks = gridDim.x;  // this workgroup's slot among its pair's partials
   if constexpr (MULTI) {
-    const MultiEntry& e = multi[ch.pad];
+    const uint32_t pair = ch.pad & 0xffu;  // Chunk::pad = pair | (index of the chunk among its pair's chunks) << 8
+    const MultiEntry& e = multi[pair];
     pts = static_cast<const Rec*>(e.pts);
     img = e.img;
-    hist = e.hist_buf[dyn.cur[ch.pad]];
+    hist = e.hist_buf[dyn.cur[pair]];
     inv_unit = e.inv_unit;
     phi_q = e.phi_q;
     scal = e.scal;
     partials = e.partials;
     out = e.out;
     out_host = e.out_host;
-    tag = dyn.tag[ch.pad];
+    tag = dyn.tag[pair];
     counter = e.counters + 1;
-    my_block = blockIdx.x - unsigned(e.chunk_base);
+    my_block = ch.pad >> 8;
     my_blocks = unsigned(e.nchunks);
   }
   {

@@ -10,7 +10,8 @@ typedef unsigned long long u64;
 struct EntropyScalars;
 
 // MultiNIDCost on one GPU (visual_camera_calibration.cpp:141-178: the same pose for every pair): ONE grid per pass over
-// the chunks of ALL pairs instead of three launches per pair.  Chunk::pad carries the pair's index into this table (device
+// the chunks of ALL pairs instead of three launches per pair.  Chunk::pad carries the pair's index into this table (low 8
+// bits; above them the chunk's index among its pair's chunks: its slot in the pair's gradient partials) (device
 // memory, built once per set of handles); what changes per evaluation -- which of the two histogram buffers is current,
 // the completion tag -- travels by value (MultiDyn).  multi == nullptr: the single-pair launch, unchanged.
 constexpr int kMaxMulti = 16;
@@ -31,8 +32,8 @@ struct MultiEntry {
   double* out_host;
   unsigned int* counters;  // [0] entropy ticket, [1] gradient ticket
   long long zero_words;
-  int chunk_base;  // first chunk of this pair in the combined gradient-pass table
-  int nchunks;
+  int reserved0;
+  int nchunks;  // chunks of this pair in the combined gradient-pass table (their indices: Chunk::pad >> 8)
 };
 struct NoMultiDyn {};  // what the single-pair instantiations take in its place (no kernel-argument bytes, no branch)
 struct MultiDyn {

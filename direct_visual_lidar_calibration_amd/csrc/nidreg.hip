@@ -1082,10 +1082,47 @@ void pair_chunks(const nidreg_handle* h, int pair, int64_t target, int threads, 
       c.start = uint32_t(st);
       c.count = uint32_t(std::min<int64_t>(size, hi - st));
       c.group = uint32_t(g);
-      c.pad = uint32_t(pair);
+      c.pad = uint32_t(pair) | (uint32_t(chunks.size()) << 8);  // pair, and the chunk's index among the pair's chunks
       chunks.push_back(c);
     }
   }
+}
+
+// Order of a group's combined chunk table.  Workgroup b of a grid runs on XCD b mod 8 (MI355X_MICROARCH.md, "observed, for
+// speed only"), and every XCD has its own 4 MB L2.  With the pairs' chunks simply concatenated, the workgroups of ALL pairs
+// are co-resident on every XCD and n bin images (2 MB each at 1080p) compete for each L2: traced at 2 x 5M points, the
+// histogram kernel took 85 us instead of 51 and the gradient kernel 100 instead of 74 (profiles/r03f_group_kernel_stats.txt).
+// Here XCD x works on pair floor(x n / 8) (n <= 8; beyond that pair p goes to XCD p mod 8, pair after pair), so an L2 sees
+// one image at a time; a queue that runs dry takes from the fullest one, so the grid stays one round whatever the sizes.
+std::vector<Chunk> interleave_by_xcd(const std::vector<std::vector<Chunk>>& per_pair) {
+  const int n = int(per_pair.size());
+  std::vector<std::vector<Chunk>> queue(8);
+  std::vector<std::vector<int>> xcds_of(static_cast<size_t>(n));
+  if (n <= 8) {
+    for (int x = 0; x < 8; x++) xcds_of[size_t(x * n / 8)].push_back(x);
+  } else {
+    for (int p = 0; p < n; p++) xcds_of[size_t(p)].push_back(p % 8);
+  }
+  for (int p = 0; p < n; p++) {
+    const std::vector<int>& xs = xcds_of[size_t(p)];
+    for (size_t k = 0; k < per_pair[size_t(p)].size(); k++) queue[size_t(xs[k % xs.size()])].push_back(per_pair[size_t(p)][k]);
+  }
+  size_t total = 0;
+  for (const auto& q : queue) total += q.size();
+  std::vector<size_t> head(8, 0);
+  std::vector<Chunk> out;
+  out.reserve(total);
+  for (size_t i = 0; i < total; i++) {
+    size_t x = i % 8;
+    if (head[x] >= queue[x].size()) {  // dry: take from the queue with the most left
+      size_t best = 8, left = 0;
+      for (size_t y = 0; y < 8; y++)
+        if (queue[y].size() - head[y] > left) left = queue[y].size() - head[y], best = y;
+      x = best;
+    }
+    out.push_back(queue[x][head[x]++]);
+  }
+  return out;
 }
 
 // returns the group with its use count raised (release_group when the evaluation is over), or nullptr
@@ -1104,17 +1141,16 @@ MultiGroup* find_or_make_group(nidreg_handle* const* handles, int n) {
   g->device = handles[0]->device;
   int64_t total = 0;
   for (int i = 0; i < n; i++) total += std::max<int64_t>(handles[i]->num_points, 1);
-  std::vector<Chunk> chunks, wide_chunks;
+  std::vector<std::vector<Chunk>> pair_grad(static_cast<size_t>(n)), pair_hist(static_cast<size_t>(n));
   std::vector<MultiEntry> table(static_cast<size_t>(n));
   const nidreg_handle* h0 = handles[0];
   for (int i = 0; i < n; i++) {
     nidreg_handle* h = handles[i];
     const int64_t share_grad = std::max<int64_t>(1, int64_t(h0->per_cu_grad) * h0->num_cus * std::max<int64_t>(h->num_points, 1) / total);
-    const int base = int(chunks.size());
-    pair_chunks(h, i, share_grad, kThreads, chunks);
+    pair_chunks(h, i, share_grad, kThreads, pair_grad[size_t(i)]);
     if (h0->wide) {
       const int64_t share_hist = std::max<int64_t>(1, int64_t(h0->per_cu_hist) * h0->num_cus * std::max<int64_t>(h->num_points, 1) / total);
-      pair_chunks(h, i, share_hist, kWideThreads, wide_chunks);
+      pair_chunks(h, i, share_hist, kWideThreads, pair_hist[size_t(i)]);
     }
     MultiEntry& e = table[size_t(i)];
     e.pts = h->d_pts;
@@ -1134,14 +1170,23 @@ MultiGroup* find_or_make_group(nidreg_handle* const* handles, int n) {
     e.out_host = h->d_out_host;
     e.counters = h->d_counters;
     e.zero_words = h->hist_words;
-    e.chunk_base = base;
-    e.nchunks = int(chunks.size()) - base;
+    e.reserved0 = 0;
+    e.nchunks = int(pair_grad[size_t(i)].size());
     if (e.nchunks > std::max(std::max(h->nchunks, h->nchunks_hist), 1)) {  // the pair's partial buffer holds 12 doubles per chunk of ITS OWN table
       delete g;
       if (g_rejected.size() >= kMaxRejected) g_rejected.erase(g_rejected.begin());
       g_rejected.emplace_back(handles, handles + n);
       return nullptr;
     }
+  }
+  const bool flat = std::getenv("NIDREG_GROUP_FLAT_ORDER") != nullptr;  // measurement knob: the pairs' chunks simply concatenated
+  std::vector<Chunk> chunks, wide_chunks;
+  if (flat) {
+    for (int i = 0; i < n; i++) chunks.insert(chunks.end(), pair_grad[size_t(i)].begin(), pair_grad[size_t(i)].end());
+    for (int i = 0; i < n; i++) wide_chunks.insert(wide_chunks.end(), pair_hist[size_t(i)].begin(), pair_hist[size_t(i)].end());
+  } else {
+    chunks = interleave_by_xcd(pair_grad);
+    wide_chunks = interleave_by_xcd(pair_hist);
   }
   hipError_t err = hipSetDevice(g->device);
   if (err == hipSuccess) err = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
