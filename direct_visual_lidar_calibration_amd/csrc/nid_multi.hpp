@@ -38,7 +38,10 @@ struct MultiEntry {
 struct NoMultiDyn {};  // what the single-pair instantiations take in its place (no kernel-argument bytes, no branch)
 struct MultiDyn {
   double tag[kMaxMulti];
-  unsigned char cur[kMaxMulti];  // index of the histogram buffer this evaluation accumulates into
+  // index of the histogram buffer this evaluation accumulates into.  32-bit on purpose: with a byte array the compiler
+  // folded `&dyn + pair` into a common base for cur[pair] and tag[pair] and read the tag with a scalar load at base + 7 pair
+  // -- scalar loads ignore the two low address bits, so pair 1 got the bytes at offset 4 (found on hardware, round 3)
+  int cur[kMaxMulti];
   int want_grad;
   int neb;  // entropy workgroups per pair
 };

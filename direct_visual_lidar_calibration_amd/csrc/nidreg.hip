@@ -1238,7 +1238,7 @@ int group_eval(MultiGroup* g, const double* se3, bool want_grad, double* costs, 
     nidreg_handle* h = g->hs[size_t(i)];
     bump_seq(h);
     HIP_TRY(begin_histogram(h, g->stream));
-    a.dyn.cur[i] = static_cast<unsigned char>(h->hist_cur);
+    a.dyn.cur[i] = h->hist_cur;
     a.dyn.tag[i] = h->seq;
     for (int k = 0; k < 4; k++) h->last_q[k] = se3[k];
     std::memcpy(h->last_R, a.R, sizeof(a.R));
@@ -1281,6 +1281,18 @@ int group_eval(MultiGroup* g, const double* se3, bool want_grad, double* costs, 
   *all_ok = true;
   for (int i = 0; i < n; i++) {
     const int rc = eval_finish_on(g->hs[size_t(i)], g->stream, costs + i, grads ? grads + 7 * i : nullptr);
+    if (rc < 0 && std::getenv("NIDREG_DEBUG_GROUP")) {
+      (void)hipStreamSynchronize(g->stream);
+      for (int j = 0; j < n; j++) {
+        nidreg_handle* hj = g->hs[size_t(j)];
+        unsigned int c[8];
+        (void)hipMemcpy(c, hj->d_counters, sizeof(c), hipMemcpyDeviceToHost);
+        std::vector<MultiEntry> tab(static_cast<size_t>(n));
+        (void)hipMemcpy(tab.data(), g->d_table, tab.size() * sizeof(MultiEntry), hipMemcpyDeviceToHost);
+        std::fprintf(stderr, "group debug: pair %d seq %.0f tag %.0f cost %.6f counters %u %u %u %u nchunks(table) %d group nchunks %d/%d\n", j, hj->seq, hj->h_out[15], hj->h_out[0], c[0], c[1], c[2], c[3],
+                     tab[size_t(j)].nchunks, g->nchunks, g->nchunks_hist);
+      }
+    }
     if (rc < 0) return rc;
     if (rc == NIDREG_FALSE) *all_ok = false;
     if (rcs) rcs[i] = rc;
@@ -1304,7 +1316,7 @@ int group_eval_iso(MultiGroup* g, const double* T, double* costs) {
     nidreg_handle* h = g->hs[size_t(i)];
     bump_seq(h);
     HIP_TRY(begin_histogram(h, g->stream));
-    a.dyn.cur[i] = static_cast<unsigned char>(h->hist_cur);
+    a.dyn.cur[i] = h->hist_cur;
     a.dyn.tag[i] = h->seq;
     h->ev_grad = false;
   }
