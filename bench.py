@@ -410,7 +410,7 @@ def main():
         # >= 3 cost+Jacobian evaluations of the WHOLE cloud on one core when that takes <= ~25 s (10M points: ~4.8 s each);
         # larger clouds: every (N/ns)-th sweep-ordered point (keeps the spatial / intensity distribution), scaled, with the
         # per-point cost at a second sample size next to it
-        full = pts.shape[0] <= 12_000_000 and args.cpu_sample > 0
+        full = pts.shape[0] <= 12_000_000 and args.cpu_sample >= min(2_000_000, pts.shape[0])  # a smaller --cpu-sample asks for a shorter CPU leg
         ns = pts.shape[0] if full else min(args.cpu_sample, pts.shape[0])
         sel = np.linspace(0, pts.shape[0] - 1, ns).astype(np.int64)
         sp, si = (pts, ints) if full else (np.ascontiguousarray(pts[sel]), np.ascontiguousarray(ints[sel]))
@@ -549,7 +549,7 @@ def main():
                     out[key] = {"value": round(1.0 / med, 2), "unit": "evals/s", "ms_per_step": round(1e3 * med, 5), "points": n_points, "devices": c.shard_devices(), "setup_s": round(setup, 3)}
                     c.close()
                     del s
-                out["route"] = "one process, desc.device_ids: one-shot GPU-to-GPU all-reduce of the histogram inside nidreg_eval, host sums the gradient partials"
+                out["route"] = "one process, desc.device_ids: the cloud cut along the histogram column, inlier counts / entropy partials / marginal sums exchanged GPU to GPU inside nidreg_eval, host sums the gradient partials"
             return out
 
         leg("single_process_sharded", single_process_leg)

@@ -1088,43 +1088,6 @@ void pair_chunks(const nidreg_handle* h, int pair, int64_t target, int threads, 
   }
 }
 
-// Order of a group's combined chunk table.  Workgroup b of a grid runs on XCD b mod 8 (MI355X_MICROARCH.md, "observed, for
-// speed only"), and every XCD has its own 4 MB L2.  With the pairs' chunks simply concatenated, the workgroups of ALL pairs
-// are co-resident on every XCD and n bin images (2 MB each at 1080p) compete for each L2: traced at 2 x 5M points, the
-// histogram kernel took 85 us instead of 51 and the gradient kernel 100 instead of 74 (profiles/r03f_group_kernel_stats.txt).
-// Here XCD x works on pair floor(x n / 8) (n <= 8; beyond that pair p goes to XCD p mod 8, pair after pair), so an L2 sees
-// one image at a time; a queue that runs dry takes from the fullest one, so the grid stays one round whatever the sizes.
-std::vector<Chunk> interleave_by_xcd(const std::vector<std::vector<Chunk>>& per_pair) {
-  const int n = int(per_pair.size());
-  std::vector<std::vector<Chunk>> queue(8);
-  std::vector<std::vector<int>> xcds_of(static_cast<size_t>(n));
-  if (n <= 8) {
-    for (int x = 0; x < 8; x++) xcds_of[size_t(x * n / 8)].push_back(x);
-  } else {
-    for (int p = 0; p < n; p++) xcds_of[size_t(p)].push_back(p % 8);
-  }
-  for (int p = 0; p < n; p++) {
-    const std::vector<int>& xs = xcds_of[size_t(p)];
-    for (size_t k = 0; k < per_pair[size_t(p)].size(); k++) queue[size_t(xs[k % xs.size()])].push_back(per_pair[size_t(p)][k]);
-  }
-  size_t total = 0;
-  for (const auto& q : queue) total += q.size();
-  std::vector<size_t> head(8, 0);
-  std::vector<Chunk> out;
-  out.reserve(total);
-  for (size_t i = 0; i < total; i++) {
-    size_t x = i % 8;
-    if (head[x] >= queue[x].size()) {  // dry: take from the queue with the most left
-      size_t best = 8, left = 0;
-      for (size_t y = 0; y < 8; y++)
-        if (queue[y].size() - head[y] > left) left = queue[y].size() - head[y], best = y;
-      x = best;
-    }
-    out.push_back(queue[x][head[x]++]);
-  }
-  return out;
-}
-
 // returns the group with its use count raised (release_group when the evaluation is over), or nullptr
 MultiGroup* find_or_make_group(nidreg_handle* const* handles, int n) {
   std::lock_guard<std::mutex> lk(g_groups_mu);
@@ -1179,15 +1142,12 @@ MultiGroup* find_or_make_group(nidreg_handle* const* handles, int n) {
       return nullptr;
     }
   }
-  const bool flat = std::getenv("NIDREG_GROUP_FLAT_ORDER") != nullptr;  // measurement knob: the pairs' chunks simply concatenated
+  // the pairs' chunks one after the other.  (An XCD-aware order -- workgroup b runs on XCD b mod 8, so XCD x would only see
+  // the bin image of pair floor(x n / 8) -- was measured and changed nothing: 2 / 4 / 8 pairs 204 / 183 / 176 us against
+  // 191 / 185 / 178 us, profiles/r03g_multi_pair_patterns.jsonl: the images' L2 footprint is not what slows the group down.)
   std::vector<Chunk> chunks, wide_chunks;
-  if (flat) {
-    for (int i = 0; i < n; i++) chunks.insert(chunks.end(), pair_grad[size_t(i)].begin(), pair_grad[size_t(i)].end());
-    for (int i = 0; i < n; i++) wide_chunks.insert(wide_chunks.end(), pair_hist[size_t(i)].begin(), pair_hist[size_t(i)].end());
-  } else {
-    chunks = interleave_by_xcd(pair_grad);
-    wide_chunks = interleave_by_xcd(pair_hist);
-  }
+  for (int i = 0; i < n; i++) chunks.insert(chunks.end(), pair_grad[size_t(i)].begin(), pair_grad[size_t(i)].end());
+  for (int i = 0; i < n; i++) wide_chunks.insert(wide_chunks.end(), pair_hist[size_t(i)].begin(), pair_hist[size_t(i)].end());
   hipError_t err = hipSetDevice(g->device);
   if (err == hipSuccess) err = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
   if (err == hipSuccess) err = hipMalloc(&g->d_table, table.size() * sizeof(MultiEntry));
@@ -1341,8 +1301,21 @@ int group_eval_iso(MultiGroup* g, const double* T, double* costs) {
 }
 
 // handles[0..n) all distinct, compatible and on one device?
+// Measured on the same clouds in one harness (tools/omp_pairs.cpp on the 10M-point scene split into n pairs,
+// profiles/r03g_multi_pair_patterns.jsonl), microseconds per evaluation of all pairs: single grid 191 / 185 / 178 at
+// 2 / 4 / 8 pairs, per-pair launches 149 / 197 / 295, one OpenMP caller per pair 171 / 225 / 297.  The single grid pays off
+// from four pairs on (three launches instead of 3 n, one round of workgroups instead of n); two or three pairs run as
+// per-pair launches, every pair's histogram pass queued before the rest.  NIDREG_MULTI_GRID_MIN=n moves the threshold.
+int multi_grid_min() {
+  static const int v = [] {
+    const char* e = std::getenv("NIDREG_MULTI_GRID_MIN");
+    const long m = e ? std::strtol(e, nullptr, 10) : 4;
+    return int(std::max(2L, std::min(m, long(kMaxMulti) + 1)));
+  }();
+  return v;
+}
 bool can_group(nidreg_handle* const* handles, int n) {
-  if (n < 2 || n > kMaxMulti || std::getenv("NIDREG_NO_MULTI_GRID")) return false;
+  if (n < multi_grid_min() || n > kMaxMulti || std::getenv("NIDREG_NO_MULTI_GRID")) return false;
   if (!groupable(handles[0], handles[0])) return false;
   for (int i = 1; i < n; i++)
     if (!groupable(handles[0], handles[i])) return false;
