@@ -28,8 +28,9 @@ def test_fused_matches_three_kernel_path_and_oracle(monkeypatch, model, bins):
     s = scene_for(model)
     proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
     three, fused = _pair(monkeypatch, proj, s, bins)
-    # the fisheye / equirectangular instantiations hold too many registers for one co-resident round: they stay on three kernels
-    assert three.info()["fused"] == 0 and fused.info()["fused"] == (0 if model in ("fisheye", "equirectangular") else 1)
+    # eligible whenever the histogram pass's chunk table is one co-resident round of k_fused as well (nidreg.hip checks the
+    # kernel's own occupancy); the pinhole family always is
+    assert three.info()["fused"] == 0 and (fused.info()["fused"] == 1 or model in ("fisheye", "equirectangular"))
     rng = np.random.default_rng(3)
     poses = [s.T_camera_lidar_init, s.T_camera_lidar_true] + [synth.random_pose_near(s.T_camera_lidar_true, rng) for _ in range(4)]
     for k, x in enumerate(poses):  # back to back: both histogram buffers, the barrier counter's running base
