@@ -20,6 +20,8 @@
 
 #include <type_traits>
 
+#include "nid_atan_table.hpp"
+
 namespace nidreg {
 
 typedef unsigned long long u64;
@@ -203,43 +205,32 @@ NID_HD double fast_rsq(double z) {
 }
 NID_HD float fast_rsq(float z) { return 1.0f / sqrtf(z); }
 
-// atan2 for the SPLINE kernels' fisheye / equirectangular projections: octant reduction to t in [0,1]
-// with one fast reciprocal, then atan(t) = t P(t^2) with a 20-term polynomial (Chebyshev interpolant of
-// atan(sqrt s)/sqrt s on [0,1], tools/gen_atan_poly.py; max abs error 2.3e-16 in the double Horner
-// form), ~40 instructions against ~110 for the library routine with its IEEE division.
-// atan2(0, 0) = 0 like libm (equirectangular.hpp:21 relies on it for points on the vertical axis).
+// atan2 for the SPLINE kernels' fisheye / equirectangular projections.  Octant reduction to t in [0,1] with one fast
+// reciprocal, then a 257-entry table: atan(t) = atan(t0) + atan(d), t0 = round(256 t) / 256, d = (t - t0) / (1 + t t0),
+// |d| <= 1/512, atan(d) = d (1 - d^2/3 + d^4/5) (next term d^7/7 < 2e-20).  The table (nid_atan_table.hpp: correctly
+// rounded) is 2 KB and read through the vector L1, where it stays resident.  Against the 20-term polynomial of rounds
+// 1-2 (its coefficients had to be re-materialised with v_mov pairs inside the Horner chain, and the fisheye /
+// equirectangular gradient kernels held 154-161 VGPRs) this is ~7 fp64 and ~10 other VALU operations less per call and two
+// constants instead of twenty.  Max abs error 1.1e-16 with exact divisions (tools/gen_atan_table.py), ~1e-15 with the
+// one-Newton-step reciprocals (test_device_math).  atan2(0, 0) = 0 like libm (equirectangular.hpp:21 relies on it for
+// points on the vertical axis).
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ const double g_atan_tab[kAtanTableN + 1] = {NID_ATAN_TABLE_VALUES};
+#else
+static const double g_atan_tab[kAtanTableN + 1] = {NID_ATAN_TABLE_VALUES};
+#endif
 NID_HD double fast_atan2(double y, double x) {
-  const double kC[20] = {
-    1.00000000000000000e+00,
-    -3.33333333333307003e-01,
-    1.99999999996479605e-01,
-    -1.42857142669267329e-01,
-    1.11111105780020827e-01,
-    -9.09089979321734132e-02,
-    7.69219899745829383e-02,
-    -6.66576491068972266e-02,
-    5.87682811448727235e-02,
-    -5.23742347191881660e-02,
-    4.66874530484852890e-02,
-    -4.08112475031788546e-02,
-    3.38712670270067476e-02,
-    -2.55686236443717387e-02,
-    1.67195960635073901e-02,
-    -8.99108054265826059e-03,
-    3.75113848396514118e-03,
-    -1.12525443022346450e-03,
-    2.14238107386039464e-04,
-    -1.93423475928923002e-05,
-  };
   const double ax = fabs(x), ay = fabs(y);
   const bool swap = ay > ax;
   const double mx = swap ? ay : ax, mn = swap ? ax : ay;  // NaN operands propagate (no maxNum semantics)
   const double t = mn * fast_rcp(mx < 1e-30 ? 1e-30 : mx);  // 0/0 -> 0; a NaN mx stays NaN
-  const double s = t * t;
-  double p = kC[19];
-#pragma unroll
-  for (int k = 18; k >= 0; k--) p = fma(p, s, kC[k]);
-  double a = t * p;
+  const double ti = rint(t * double(kAtanTableN));
+  int i = int(ti);  // NaN -> 0 (v_cvt_i32_f64) / INT_MIN (x86): clamped below, the result is NaN through d either way
+  i = i < 0 ? 0 : (i > kAtanTableN ? kAtanTableN : i);
+  const double t0 = ti * (1.0 / double(kAtanTableN));
+  const double d = (t - t0) * fast_rcp(fma(t, t0, 1.0));
+  const double d2 = d * d;
+  double a = fma(d, fma(d2, fma(d2, 0.2, -1.0 / 3.0), 1.0), g_atan_tab[i]);
   a = swap ? 1.57079632679489661923 - a : a;
   a = x < 0.0 ? 3.14159265358979323846 - a : a;
   return copysign(a, y);
