@@ -713,15 +713,18 @@ __global__ __launch_bounds__(kEntropyThreads) void k_entropy(
   acc = wave_sum(acc);
   if ((tid & 63) == 0) s_red[tid >> 6] = acc;
   __syncthreads();
-  if (q == 0 && r < B) row_part[size_t(j) * size_t(B) + r] = row + s_row[0][r] + s_row[1][r] + s_row[2][r];
+  // the partials the last workgroup reads are stored write-through at agent scope and every storing wave drains its
+  // stores before the ticket: no release fence (a buffer_wbl2 costs ~1.7 us on this kernel's critical path)
+  if (q == 0 && r < B) __hip_atomic_store(&row_part[size_t(j) * size_t(B) + r], row + s_row[0][r] + s_row[1][r] + s_row[2][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (tid < 64) {  // the sixteen wave partials, summed by one wave instead of a serial loop of LDS reads
     const long long t = wave_sum(tid < kEntropyWaves ? s_red[tid] : 0ll);
-    if (tid == 0) part_hj[j] = t;
+    if (tid == 0) __hip_atomic_store(&part_hj[j], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const u64* col_sum = hist + size_t(B) * size_t(B) + kTailWords;  // accumulated by the histogram kernels' flush
   // the tail's loops stride by kThreads = 256 over B <= 256 items: threads beyond 255 find nothing to do but take part
   // in its barriers and (with zeros) in its wave reductions -- s_red holds 3 slots for each of the 16 waves
-  if (last_workgroup_arrives<false>(counter, unsigned(nblocks), &s_flag))
+  if (last_workgroup_arrives<true>(counter, unsigned(nblocks), &s_flag))
     entropy_final_body(S, B, nblocks, inv_unit, part_hj, row_part, col_sum, phi_q, hist_image_out, hist_points_out, scal, out, out_host, tag, s_red);
 }
 
