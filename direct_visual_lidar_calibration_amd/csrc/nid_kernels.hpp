@@ -655,8 +655,8 @@ constexpr int kEntropyWaves = kEntropyThreads / 64;
 template <bool MULTI>
 __global__ __launch_bounds__(kEntropyThreads) void k_entropy(
   const u64* __restrict__ hist, int B, int CB, double inv_unit, long long* part_hj, u64* row_part, double* phi_q, double* hist_image_out, double* hist_points_out,
-  EntropyScalars* scal, double* out, double* out_host, double tag, unsigned int* counter, u64* __restrict__ zero_buf, long long zero_words, const MultiEntry* __restrict__ multi,
-  typename multi_dyn_of<MULTI>::type dyn) {
+  EntropyScalars* scal, double* out, double* out_host, double tag, unsigned int* counter, u64* __restrict__ zero_buf, long long zero_words, int tail,
+  const MultiEntry* __restrict__ multi, typename multi_dyn_of<MULTI>::type dyn) {
   __shared__ long long s_red[3 * kEntropyWaves];
   __shared__ u64 s_row[3][256];
   __shared__ int s_flag;
@@ -682,6 +682,7 @@ __global__ __launch_bounds__(kEntropyThreads) void k_entropy(
     out_host = e.out_host;
     counter = e.counters;
     tag = dyn.want_grad ? 0.0 : dyn.tag[pair];
+    tail = (!dyn.want_grad || e.nchunks == 0) ? 1 : 0;  // a pair without points has no gradient workgroup to run the tail
   }
   // double-buffered histogram: clear the buffer the NEXT evaluation accumulates into (nidreg.hip,
   // begin_histogram) -- ~0.5 MB of stores that replace a memset launch per evaluation
@@ -720,6 +721,10 @@ __global__ __launch_bounds__(kEntropyThreads) void k_entropy(
     const long long t = wave_sum(tid < kEntropyWaves ? s_red[tid] : 0ll);
     if (tid == 0) __hip_atomic_store(&part_hj[j], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  // cost + Jacobian: the tail (three entropies -> NID, coefficients, phi(q_r)) is run by every workgroup of k_spline_grad in
+  // its prologue, in parallel on all CUs, from the partials stored above (grad_scalars_from_partials) -- the ticket, the
+  // acquire and one workgroup's serial tail (~6.8 us of this kernel, profiles/r02g_variants_prio.txt) leave the critical path
+  if (!tail) return;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const u64* col_sum = hist + size_t(B) * size_t(B) + kTailWords;  // accumulated by the histogram kernels' flush
   // the tail's loops stride by kThreads = 256 over B <= 256 items: threads beyond 255 find nothing to do but take part
@@ -1007,11 +1012,80 @@ __device__ __forceinline__ void grad_reduce_store(const double* acc, double* s_r
   }
 }
 
+// what the gradient kernel needs to run the entropy tail itself (k_entropy launched with tail = 0)
+struct GradTail {
+  const long long* part_hj;  // [neb] fixed-point entropy partials of k_entropy's column blocks
+  const u64* row_part;       // [neb][B]
+  double* phi_q;             // outputs, written by the pair's first workgroup (nidreg_get_hist, the cost's way to the host)
+  double* hist_image;
+  double* hist_points;
+  EntropyScalars* scal;
+  int neb;
+  int from_partials;         // 0: read scal / phi_q as k_entropy's tail (or k_entropy_gather) left them
+};
+
+// The entropy tail in the gradient kernel's prologue: every workgroup computes the three entropies from k_entropy's
+// partials (integer sums: identical bits everywhere), NID, coefA / coefB, and phi(q_r) into s_phi.  `writer` (one
+// workgroup per pair) publishes hist_image / hist_points / phi_q / scal and -- at agent scope, read by grad_final_body in
+// another workgroup -- cost, status and inlier count.  s_redk: 3 * (kT / 64) words of LDS.
+template <int kT>
+__device__ __forceinline__ EntropyScalars grad_scalars_from_partials(const u64* hist, int B, double inv_unit, const GradTail& gt, double* s_phi, long long* s_redk, bool writer, double* out) {
+  const int tid = threadIdx.x;
+  const double S = double(hist[size_t(B) * size_t(B) + kTailInliers]);
+  const u64* col_sum = hist + size_t(B) * size_t(B) + kTailWords;
+  long long hi_k = 0, hp_k = 0, hj_k = 0;
+  for (int r = tid; r < B; r += kT) {
+    u64 t = 0;
+    for (int g = 0; g < gt.neb; g++) t += gt.row_part[size_t(g) * size_t(B) + r];
+    const double raw = double(t) * inv_unit;  // raw (un-normalised) hist_image[r]
+    const double qv = raw / S;
+    const double lq = log(qv + 1e-6);
+    hi_k += ent_fixed(qv * lq);
+    const double ph = lq + qv / (qv + 1e-6);
+    s_phi[r] = ph;
+    const double cnt = rint(double(col_sum[r]) * inv_unit);  // exact inlier count of column r
+    const double p = cnt / S;
+    hp_k += ent_fixed(p * log(p + 1e-6));
+    if (writer) {
+      gt.phi_q[r] = ph;
+      gt.hist_image[r] = raw;
+      gt.hist_points[r] = cnt;
+    }
+  }
+  for (int g = tid; g < gt.neb; g += kT) hj_k += gt.part_hj[g];
+  hi_k = wave_sum(hi_k);
+  hp_k = wave_sum(hp_k);
+  hj_k = wave_sum(hj_k);
+  if ((tid & 63) == 0) {
+    s_redk[(tid >> 6) * 3 + 0] = hi_k;
+    s_redk[(tid >> 6) * 3 + 1] = hp_k;
+    s_redk[(tid >> 6) * 3 + 2] = hj_k;
+  }
+  __syncthreads();
+  long long A = 0, Bk = 0, C = 0;
+  for (int w = 0; w < kT / 64; w++) {
+    A += s_redk[w * 3 + 0];
+    Bk += s_redk[w * 3 + 1];
+    C += s_redk[w * 3 + 2];
+  }
+  const EntropyScalars e = entropy_scalars(A, Bk, C, S);
+  if (writer && tid == 0) {
+    *gt.scal = e;
+    __hip_atomic_store(&out[0], e.nid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&out[8], e.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&out[9], S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return e;
+}
+
+// the `atan` model keeps the generic Dual3 forward mode and sits at the edge of three waves per SIMD (164-170 VGPRs; the
+// allocation granule is 8): ask for three explicitly
+constexpr int grad_min_waves(int model) { return model == MODEL_ATAN ? 3 : NID_GRAD_MIN_WAVES; }
 template <int MODEL, typename Rec, typename real, bool GW1, bool MULTI>
-__global__ __launch_bounds__(kThreads, NID_GRAD_MIN_WAVES) void k_spline_grad(
+__global__ __launch_bounds__(kThreads, grad_min_waves(MODEL)) void k_spline_grad(
   const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint8_t* __restrict__ img, int pitch, int W, int H, PoseParams<real> pose, CamParams<real> cam, int B,
-  int GW, int cshift, double inv_unit, const u64* __restrict__ hist, const double* __restrict__ phi_q, const EntropyScalars* __restrict__ scal, double* partials, double qx,
-  double qy, double qz, double qw, double* out, double* out_host, double tag, unsigned int* counter, int prio, const MultiEntry* __restrict__ multi,
+  int GW, int cshift, double inv_unit, const u64* __restrict__ hist, const double* __restrict__ phi_q, const EntropyScalars* __restrict__ scal, GradTail gt, double* partials,
+  double qx, double qy, double qz, double qw, double* out, double* out_host, double tag, unsigned int* counter, int prio, const MultiEntry* __restrict__ multi,
   typename multi_dyn_of<MULTI>::type dyn) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* gtile = reinterpret_cast<double*>(smem);
@@ -1019,7 +1093,8 @@ __global__ __launch_bounds__(kThreads, NID_GRAD_MIN_WAVES) void k_spline_grad(
   if (GW1) cshift = 0;
   const uint32_t cmask = (1u << cshift) - 1u;  // G is replicated like the histogram tile: lane-private copies, conflict-free ds_read_b64
   double* s_red = gtile + (tile_n << cshift);
-  int* s_flag = reinterpret_cast<int*>(s_red + kWaves * 12);
+  double* s_phi = s_red + kWaves * 12;  // [256] phi(q_r) when this kernel runs the entropy tail itself
+  int* s_flag = reinterpret_cast<int*>(s_phi + 256);
 
   const int tid = threadIdx.x;
   const Chunk ch = chunks[blockIdx.x];
@@ -1040,10 +1115,24 @@ __global__ __launch_bounds__(kThreads, NID_GRAD_MIN_WAVES) void k_spline_grad(
     counter = e.counters + 1;
     my_block = ch.pad >> 8;
     my_blocks = unsigned(e.nchunks);
+    gt.part_hj = e.part_hj;
+    gt.row_part = e.row_part;
+    gt.phi_q = e.phi_q;
+    gt.hist_image = e.hist_image;
+    gt.hist_points = e.hist_points;
+    gt.scal = e.scal;
+    gt.neb = dyn.neb;
   }
   {
-    const double coefA = scal->coefA, coefB = scal->coefB;
-    const double scale = inv_unit / scal->S;
+    double coefA, coefB, S;
+    if (gt.from_partials) {
+      const EntropyScalars es = grad_scalars_from_partials<kThreads>(hist, B, inv_unit, gt, s_phi, reinterpret_cast<long long*>(s_red), my_block == 0, out);
+      coefA = es.coefA, coefB = es.coefB, S = es.S;
+      phi_q = s_phi;  // LDS through a generic pointer: B reads per workgroup
+    } else {
+      coefA = scal->coefA, coefB = scal->coefB, S = scal->S;
+    }
+    const double scale = inv_unit / S;
     const u64* src = hist + size_t(ch.group) * size_t(tile_n);
     const int ncols = min(GW, B - int(ch.group) * GW);
     const int n = ncols * B;

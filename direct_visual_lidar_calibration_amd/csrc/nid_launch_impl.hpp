@@ -96,19 +96,28 @@ template <typename real, typename Rec>
 static hipError_t launch_spline_grad_rec(const PassArgs& a) {
   const PoseParams<real> pose = make_pose<real>(a);
   const CamParams<real> cam = make_cam<real>(a.intr, a.dist);
+  GradTail gt;
+  gt.part_hj = a.gt_part_hj;
+  gt.row_part = a.gt_row_part;
+  gt.phi_q = a.gt_phi_q;
+  gt.hist_image = a.gt_hist_image;
+  gt.hist_points = a.gt_hist_points;
+  gt.scal = a.gt_scal;
+  gt.neb = a.gt_neb;
+  gt.from_partials = a.gt_from_partials;
 #define NID_LAUNCH_G(M, GW1)                                                                                                                           \
   if (a.multi) {                                                                                                                                       \
     auto k = k_spline_grad<M, Rec, real, GW1, true>;                                                                                                   \
     hipError_t e = ensure_lds(k, a.lds_grad);                                                                                                          \
     if (e != hipSuccess) return e;                                                                                                                     \
     hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(kThreads), a.lds_grad, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, pose, cam, \
-                       a.B, a.GW, a.cshift, a.inv_unit, a.hist, a.phi_q, a.scal, a.partials, a.q[0], a.q[1], a.q[2], a.q[3], a.out, a.out_host, a.tag, a.counter, a.prio, a.multi, a.dyn); \
+                       a.B, a.GW, a.cshift, a.inv_unit, a.hist, a.phi_q, a.scal, gt, a.partials, a.q[0], a.q[1], a.q[2], a.q[3], a.out, a.out_host, a.tag, a.counter, a.prio, a.multi, a.dyn); \
   } else {                                                                                                                                             \
     auto k = k_spline_grad<M, Rec, real, GW1, false>;                                                                                                  \
     hipError_t e = ensure_lds(k, a.lds_grad);                                                                                                          \
     if (e != hipSuccess) return e;                                                                                                                     \
     hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(kThreads), a.lds_grad, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, pose, cam, \
-                       a.B, a.GW, a.cshift, a.inv_unit, a.hist, a.phi_q, a.scal, a.partials, a.q[0], a.q[1], a.q[2], a.q[3], a.out, a.out_host, a.tag, a.counter, a.prio, a.multi, \
+                       a.B, a.GW, a.cshift, a.inv_unit, a.hist, a.phi_q, a.scal, gt, a.partials, a.q[0], a.q[1], a.q[2], a.q[3], a.out, a.out_host, a.tag, a.counter, a.prio, a.multi, \
                        NoMultiDyn());                                                                                                                  \
   }
   if (a.GW == 1) {

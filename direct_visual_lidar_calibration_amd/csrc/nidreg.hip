@@ -245,6 +245,13 @@ void fill_pass_args(const nidreg_handle* h, PassArgs& a) {
   a.out_host = h->d_out_host;
   a.tag = h->seq;
   a.counter = h->d_counters + 1;
+  a.gt_part_hj = h->d_part_hj;
+  a.gt_row_part = h->d_row_part;
+  a.gt_phi_q = h->d_phi_q;
+  a.gt_hist_image = h->d_hist_image;
+  a.gt_hist_points = h->d_hist_points;
+  a.gt_scal = h->d_scal;
+  a.gt_neb = h->NEB;
   a.stream = h->stream;
   a.lds_hist = h->lds_hist;
   a.lds_grad = h->lds_grad;
@@ -357,21 +364,24 @@ int launch_hist_nearest(nidreg_handle* h, const double* T, u64 ann_seq = 0) {
   return NIDREG_OK;
 }
 
-int launch_entropy(nidreg_handle* h, double tag) {
+// tail = false: partials only -- the gradient kernel that follows runs the entropy tail in its prologue (launch_grad with
+// from_partials); tail = true: the last workgroup finalises (cost-only evaluations, the split-phase ABI, empty clouds)
+int launch_entropy(nidreg_handle* h, double tag, bool tail = true) {
   const double inv_unit = 1.0 / fixed_unit(h);
   hipLaunchKernelGGL(
     k_entropy<false>, dim3(h->NEB), dim3(kEntropyThreads), 0, h->stream, h->d_hist, h->bins, kEntropyCols, inv_unit, h->d_part_hj, h->d_row_part, h->d_phi_q, h->d_hist_image,
-    h->d_hist_points, h->d_scal, h->d_out, h->d_out_host, tag, h->d_counters, h->own_hist ? h->d_hist_buf[h->hist_cur ^ 1] : nullptr, h->hist_words, static_cast<const MultiEntry*>(nullptr),
-    NoMultiDyn());
+    h->d_hist_points, h->d_scal, h->d_out, h->d_out_host, tag, h->d_counters, h->own_hist ? h->d_hist_buf[h->hist_cur ^ 1] : nullptr, h->hist_words, tail ? 1 : 0,
+    static_cast<const MultiEntry*>(nullptr), NoMultiDyn());
   HIP_TRY(hipGetLastError());
   if (h->own_hist) h->hist_zeroed[h->hist_cur ^ 1] = true;  // zeroed by this k_entropy for the next evaluation
   return NIDREG_OK;
 }
 
-int launch_grad(nidreg_handle* h, bool alone = false) {
+int launch_grad(nidreg_handle* h, bool alone = false, bool from_partials = false) {
   PassArgs a;
   fill_pass_args(h, a);
   a.prio = alone ? 1 : 0;
+  a.gt_from_partials = from_partials ? 1 : 0;
   a.hist = h->d_hist;  // the finished histogram (for a shard: its own columns)
   // same pose as the histogram pass of this evaluation
   std::memcpy(a.R, h->last_R, sizeof(a.R));
@@ -404,12 +414,14 @@ int eval_launch_first(nidreg_handle* h, const double* se3, bool alone = false) {
 }
 int eval_launch_rest(nidreg_handle* h, bool want_grad, bool alone = false) {
   HIP_TRY(hipSetDevice(h->device));
-  int rc = launch_entropy(h, want_grad ? 0.0 : h->seq);
+  // cost + Jacobian on a non-empty cloud: k_entropy stores its partials and ends; every gradient workgroup runs the tail
+  const bool grad_runs_tail = want_grad && h->nchunks > 0;
+  int rc = launch_entropy(h, want_grad ? 0.0 : h->seq, !grad_runs_tail);
   if (rc) return rc;
   if (h->timing == 1) HIP_TRY(hipEventRecord(h->ev[3], h->stream));
   h->ev_grad = want_grad;
   if (want_grad) {
-    rc = launch_grad(h, alone);
+    rc = launch_grad(h, alone, grad_runs_tail);
     if (rc) return rc;
   } else if (h->timing == 1) {
     HIP_TRY(hipEventRecord(h->ev[4], h->stream));
@@ -705,7 +717,7 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
   h->NEB = (B + kEntropyCols - 1) / kEntropyCols;
   h->lds_hist = (size_t(GW) * B * 8 << cshift) + size_t(GW) * 8 + 16;
   // gradient pass: a single-column workgroup (GW = 1) keeps ONE copy of its G column (k_spline_grad<.., GW1>)
-  h->lds_grad = (GW == 1 ? size_t(B) * 8 : (size_t(GW) * B * 8 << cshift)) + size_t(kWaves) * 12 * 8 + 16;
+  h->lds_grad = (GW == 1 ? size_t(B) * 8 : (size_t(GW) * B * 8 << cshift)) + size_t(kWaves) * 12 * 8 + 256 * 8 + 16;  // G tile, reduction scratch, phi(q_r), flag
   h->lds_entropy = size_t(B) * 8 + size_t(GW) * 8 + size_t(kWaves) * 8;
 
   // ---- fixed point: sum over a bin <= N * 2^frac must stay below 2^63
@@ -1218,13 +1230,14 @@ int group_eval(MultiGroup* g, const double* se3, bool want_grad, double* costs, 
   hipLaunchKernelGGL(
     k_entropy<true>, dim3(h0->NEB * n), dim3(kEntropyThreads), 0, g->stream, static_cast<const u64*>(nullptr), h0->bins, kEntropyCols, 0.0, static_cast<long long*>(nullptr),
     static_cast<u64*>(nullptr), static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<EntropyScalars*>(nullptr), static_cast<double*>(nullptr),
-    static_cast<double*>(nullptr), 0.0, static_cast<unsigned int*>(nullptr), static_cast<u64*>(nullptr), 0ll, static_cast<const MultiEntry*>(g->d_table), a.dyn);
+    static_cast<double*>(nullptr), 0.0, static_cast<unsigned int*>(nullptr), static_cast<u64*>(nullptr), 0ll, 1, static_cast<const MultiEntry*>(g->d_table), a.dyn);
   HIP_TRY(hipGetLastError());
   for (int i = 0; i < n; i++) g->hs[size_t(i)]->hist_zeroed[g->hs[size_t(i)]->hist_cur ^ 1] = true;
-  // pass B
+  // pass B (k_entropy<true> ran without its tail for every pair that has gradient workgroups: they run it)
   if (want_grad) {
     a.chunks = g->d_chunks;
     a.nchunks = g->nchunks;
+    a.gt_from_partials = 1;
     if (h0->precision == NIDREG_PREC_FP32) {
       HIP_TRY(launch_spline_grad<float>(a));
     } else {
@@ -1290,7 +1303,7 @@ int group_eval_iso(MultiGroup* g, const double* T, double* costs) {
   hipLaunchKernelGGL(
     k_entropy<true>, dim3(h0->NEB * n), dim3(kEntropyThreads), 0, g->stream, static_cast<const u64*>(nullptr), h0->bins, kEntropyCols, 0.0, static_cast<long long*>(nullptr),
     static_cast<u64*>(nullptr), static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<EntropyScalars*>(nullptr), static_cast<double*>(nullptr),
-    static_cast<double*>(nullptr), 0.0, static_cast<unsigned int*>(nullptr), static_cast<u64*>(nullptr), 0ll, static_cast<const MultiEntry*>(g->d_table), a.dyn);
+    static_cast<double*>(nullptr), 0.0, static_cast<unsigned int*>(nullptr), static_cast<u64*>(nullptr), 0ll, 1, static_cast<const MultiEntry*>(g->d_table), a.dyn);
   HIP_TRY(hipGetLastError());
   for (int i = 0; i < n; i++) g->hs[size_t(i)]->hist_zeroed[g->hs[size_t(i)]->hist_cur ^ 1] = true;
   for (int i = 0; i < n; i++) {
