@@ -28,7 +28,10 @@ constexpr int kUnroll = NID_UNROLL;  // point records in flight per thread
 
 // tail words behind the B*B joint histogram
 constexpr int kTailInliers = 0;  // number of inlier points (plain count)
-constexpr int kTailWords = 8;     // followed by B column sums (sum_r h[c][r], fixed point) written by the flush
+constexpr int kTailHj = 1;       // sum over all cells of p log(p + eps), fixed point (ent_fixed), accumulated by k_entropy
+constexpr int kTailWords = 8;     // followed by B column sums (sum_r h[c][r], fixed point) written by the flush,
+                                  // then (from the next multiple of 8) B row sums (sum_c h[c][r]) accumulated by k_entropy
+__host__ __device__ __forceinline__ size_t hist_row_sums_at(int B) { return size_t(B) * size_t(B) + kTailWords + size_t((B + 7) & ~7); }
 
 // scalars written by k_entropy_final for k_spline_grad / the host
 struct EntropyScalars {
@@ -654,7 +657,7 @@ constexpr int kEntropyThreads = 1024;
 constexpr int kEntropyWaves = kEntropyThreads / 64;
 template <bool MULTI>
 __global__ __launch_bounds__(kEntropyThreads) void k_entropy(
-  const u64* __restrict__ hist, int B, int CB, double inv_unit, long long* part_hj, u64* row_part, double* phi_q, double* hist_image_out, double* hist_points_out,
+  u64* __restrict__ hist, int B, int CB, double inv_unit, long long* part_hj, u64* row_part, double* phi_q, double* hist_image_out, double* hist_points_out,
   EntropyScalars* scal, double* out, double* out_host, double tag, unsigned int* counter, u64* __restrict__ zero_buf, long long zero_words, int tail,
   const MultiEntry* __restrict__ multi, typename multi_dyn_of<MULTI>::type dyn) {
   __shared__ long long s_red[3 * kEntropyWaves];
@@ -714,23 +717,31 @@ __global__ __launch_bounds__(kEntropyThreads) void k_entropy(
   acc = wave_sum(acc);
   if ((tid & 63) == 0) s_red[tid >> 6] = acc;
   __syncthreads();
-  // the partials the last workgroup reads are stored write-through at agent scope and every storing wave drains its
-  // stores before the ticket: no release fence (a buffer_wbl2 costs ~1.7 us on this kernel's critical path)
-  if (q == 0 && r < B) __hip_atomic_store(&row_part[size_t(j) * size_t(B) + r], row + s_row[0][r] + s_row[1][r] + s_row[2][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // this block's row sums and entropy partial are ADDED (device-scope atomics) to the B row-sum words and the Hj word behind
+  // the histogram -- zero on entry like the histogram itself: they are part of the buffer the previous evaluation cleared.
+  // Whoever runs the tail (this kernel's last workgroup, or every workgroup of k_spline_grad) reads B + 1 finished words
+  // instead of summing NEB x B partials (the gradient prologue read 32 KB per workgroup, 32 MB over the grid, before).
+  if (q == 0 && r < B) {
+    const u64 t = row + s_row[0][r] + s_row[1][r] + s_row[2][r];
+    if (t) atomicAdd(&hist[hist_row_sums_at(B) + size_t(r)], t);
+  }
   if (tid < 64) {  // the sixteen wave partials, summed by one wave instead of a serial loop of LDS reads
     const long long t = wave_sum(tid < kEntropyWaves ? s_red[tid] : 0ll);
-    if (tid == 0) __hip_atomic_store(&part_hj[j], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0 && t) atomicAdd(&hist[size_t(B) * size_t(B) + kTailHj], u64(t));
   }
+  (void)part_hj;
+  (void)row_part;
   // cost + Jacobian: the tail (three entropies -> NID, coefficients, phi(q_r)) is run by every workgroup of k_spline_grad in
   // its prologue, in parallel on all CUs, from the partials stored above (grad_scalars_from_partials) -- the ticket, the
   // acquire and one workgroup's serial tail (~6.8 us of this kernel, profiles/r02g_variants_prio.txt) leave the critical path
   if (!tail) return;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's atomics have been performed
   const u64* col_sum = hist + size_t(B) * size_t(B) + kTailWords;  // accumulated by the histogram kernels' flush
   // the tail's loops stride by kThreads = 256 over B <= 256 items: threads beyond 255 find nothing to do but take part
   // in its barriers and (with zeros) in its wave reductions -- s_red holds 3 slots for each of the 16 waves
   if (last_workgroup_arrives<true>(counter, unsigned(nblocks), &s_flag))
-    entropy_final_body(S, B, nblocks, inv_unit, part_hj, row_part, col_sum, phi_q, hist_image_out, hist_points_out, scal, out, out_host, tag, s_red);
+    entropy_final_body(S, B, 1, inv_unit, reinterpret_cast<const long long*>(hist + size_t(B) * size_t(B) + kTailHj), hist + hist_row_sums_at(B), col_sum, phi_q, hist_image_out,
+                       hist_points_out, scal, out, out_host, tag, s_red);
 }
 
 #endif  // NID_COMMON_KERNELS
@@ -1014,18 +1025,16 @@ __device__ __forceinline__ void grad_reduce_store(const double* acc, double* s_r
 
 // what the gradient kernel needs to run the entropy tail itself (k_entropy launched with tail = 0)
 struct GradTail {
-  const long long* part_hj;  // [neb] fixed-point entropy partials of k_entropy's column blocks
-  const u64* row_part;       // [neb][B]
   double* phi_q;             // outputs, written by the pair's first workgroup (nidreg_get_hist, the cost's way to the host)
   double* hist_image;
   double* hist_points;
   EntropyScalars* scal;
-  int neb;
-  int from_partials;         // 0: read scal / phi_q as k_entropy's tail (or k_entropy_gather) left them
+  int from_partials;         // 1: run the tail on the row sums / Hj k_entropy left behind the histogram; 0: read scal / phi_q
+                             // as k_entropy's own tail (or k_entropy_gather) wrote them
 };
 
-// The entropy tail in the gradient kernel's prologue: every workgroup computes the three entropies from k_entropy's
-// partials (integer sums: identical bits everywhere), NID, coefA / coefB, and phi(q_r) into s_phi.  `writer` (one
+// The entropy tail in the gradient kernel's prologue: every workgroup computes the three entropies from the sums k_entropy
+// left behind the histogram (integers: identical bits everywhere), NID, coefA / coefB, and phi(q_r) into s_phi.  `writer` (one
 // workgroup per pair) publishes hist_image / hist_points / phi_q / scal and -- at agent scope, read by grad_final_body in
 // another workgroup -- cost, status and inlier count.  s_redk: 3 * (kT / 64) words of LDS.
 template <int kT>
@@ -1033,11 +1042,11 @@ __device__ __forceinline__ EntropyScalars grad_scalars_from_partials(const u64* 
   const int tid = threadIdx.x;
   const double S = double(hist[size_t(B) * size_t(B) + kTailInliers]);
   const u64* col_sum = hist + size_t(B) * size_t(B) + kTailWords;
-  long long hi_k = 0, hp_k = 0, hj_k = 0;
+  const u64* row_sum = hist + hist_row_sums_at(B);
+  long long hi_k = 0, hp_k = 0;
+  const long long hj_all = (long long)hist[size_t(B) * size_t(B) + kTailHj];
   for (int r = tid; r < B; r += kT) {
-    u64 t = 0;
-    for (int g = 0; g < gt.neb; g++) t += gt.row_part[size_t(g) * size_t(B) + r];
-    const double raw = double(t) * inv_unit;  // raw (un-normalised) hist_image[r]
+    const double raw = double(row_sum[r]) * inv_unit;  // raw (un-normalised) hist_image[r]
     const double qv = raw / S;
     const double lq = log(qv + 1e-6);
     hi_k += ent_fixed(qv * lq);
@@ -1052,23 +1061,19 @@ __device__ __forceinline__ EntropyScalars grad_scalars_from_partials(const u64* 
       gt.hist_points[r] = cnt;
     }
   }
-  for (int g = tid; g < gt.neb; g += kT) hj_k += gt.part_hj[g];
   hi_k = wave_sum(hi_k);
   hp_k = wave_sum(hp_k);
-  hj_k = wave_sum(hj_k);
   if ((tid & 63) == 0) {
-    s_redk[(tid >> 6) * 3 + 0] = hi_k;
-    s_redk[(tid >> 6) * 3 + 1] = hp_k;
-    s_redk[(tid >> 6) * 3 + 2] = hj_k;
+    s_redk[(tid >> 6) * 2 + 0] = hi_k;
+    s_redk[(tid >> 6) * 2 + 1] = hp_k;
   }
   __syncthreads();
-  long long A = 0, Bk = 0, C = 0;
+  long long A = 0, Bk = 0;
   for (int w = 0; w < kT / 64; w++) {
-    A += s_redk[w * 3 + 0];
-    Bk += s_redk[w * 3 + 1];
-    C += s_redk[w * 3 + 2];
+    A += s_redk[w * 2 + 0];
+    Bk += s_redk[w * 2 + 1];
   }
-  const EntropyScalars e = entropy_scalars(A, Bk, C, S);
+  const EntropyScalars e = entropy_scalars(A, Bk, hj_all, S);
   if (writer && tid == 0) {
     *gt.scal = e;
     __hip_atomic_store(&out[0], e.nid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1115,13 +1120,10 @@ __global__ __launch_bounds__(kThreads, grad_min_waves(MODEL)) void k_spline_grad
     counter = e.counters + 1;
     my_block = ch.pad >> 8;
     my_blocks = unsigned(e.nchunks);
-    gt.part_hj = e.part_hj;
-    gt.row_part = e.row_part;
     gt.phi_q = e.phi_q;
     gt.hist_image = e.hist_image;
     gt.hist_points = e.hist_points;
     gt.scal = e.scal;
-    gt.neb = dyn.neb;
   }
   {
     double coefA, coefB, S;

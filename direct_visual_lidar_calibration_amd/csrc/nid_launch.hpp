@@ -51,13 +51,10 @@ struct PassArgs {
   unsigned long long ann_seq;
   unsigned int* ann_ticket;
   // the gradient kernel runs the entropy tail itself (k_entropy launched with tail = 0): nid_kernels.hpp GradTail
-  const long long* gt_part_hj;
-  const unsigned long long* gt_row_part;
   double* gt_phi_q;
   double* gt_hist_image;
   double* gt_hist_points;
   EntropyScalars* gt_scal;
-  int gt_neb;
   int gt_from_partials;
   int prio;  // progress priority (s_setprio) in the spline passes: set when the evaluation has its device to itself
   // the one-launch evaluation (k_fused, nid_fused.hpp); chunks / nchunks = the histogram pass's table

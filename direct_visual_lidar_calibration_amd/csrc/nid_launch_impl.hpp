@@ -97,13 +97,10 @@ static hipError_t launch_spline_grad_rec(const PassArgs& a) {
   const PoseParams<real> pose = make_pose<real>(a);
   const CamParams<real> cam = make_cam<real>(a.intr, a.dist);
   GradTail gt;
-  gt.part_hj = a.gt_part_hj;
-  gt.row_part = a.gt_row_part;
   gt.phi_q = a.gt_phi_q;
   gt.hist_image = a.gt_hist_image;
   gt.hist_points = a.gt_hist_points;
   gt.scal = a.gt_scal;
-  gt.neb = a.gt_neb;
   gt.from_partials = a.gt_from_partials;
 #define NID_LAUNCH_G(M, GW1)                                                                                                                           \
   if (a.multi) {                                                                                                                                       \

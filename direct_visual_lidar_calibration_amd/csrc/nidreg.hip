@@ -245,13 +245,10 @@ void fill_pass_args(const nidreg_handle* h, PassArgs& a) {
   a.out_host = h->d_out_host;
   a.tag = h->seq;
   a.counter = h->d_counters + 1;
-  a.gt_part_hj = h->d_part_hj;
-  a.gt_row_part = h->d_row_part;
   a.gt_phi_q = h->d_phi_q;
   a.gt_hist_image = h->d_hist_image;
   a.gt_hist_points = h->d_hist_points;
   a.gt_scal = h->d_scal;
-  a.gt_neb = h->NEB;
   a.stream = h->stream;
   a.lds_hist = h->lds_hist;
   a.lds_grad = h->lds_grad;
@@ -629,7 +626,7 @@ int nidreg_device_count(void) {
 
 int64_t nidreg_hist_words(int bins) {
   // room for a partially filled last column group plus the tail words
-  return int64_t(bins) * bins + kTailWords + ((bins + 7) & ~7);  // joint histogram, tail, column sums
+  return int64_t(bins) * bins + kTailWords + 2 * ((bins + 7) & ~7);  // joint histogram, tail, column sums, row sums
 }
 
 }  // extern "C"
@@ -1228,7 +1225,7 @@ int group_eval(MultiGroup* g, const double* se3, bool want_grad, double* costs, 
   }
   // entropy: NEB workgroups per pair
   hipLaunchKernelGGL(
-    k_entropy<true>, dim3(h0->NEB * n), dim3(kEntropyThreads), 0, g->stream, static_cast<const u64*>(nullptr), h0->bins, kEntropyCols, 0.0, static_cast<long long*>(nullptr),
+    k_entropy<true>, dim3(h0->NEB * n), dim3(kEntropyThreads), 0, g->stream, static_cast<u64*>(nullptr), h0->bins, kEntropyCols, 0.0, static_cast<long long*>(nullptr),
     static_cast<u64*>(nullptr), static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<EntropyScalars*>(nullptr), static_cast<double*>(nullptr),
     static_cast<double*>(nullptr), 0.0, static_cast<unsigned int*>(nullptr), static_cast<u64*>(nullptr), 0ll, 1, static_cast<const MultiEntry*>(g->d_table), a.dyn);
   HIP_TRY(hipGetLastError());
@@ -1301,7 +1298,7 @@ int group_eval_iso(MultiGroup* g, const double* T, double* costs) {
     HIP_TRY(launch_nearest_hist<double>(a));
   }
   hipLaunchKernelGGL(
-    k_entropy<true>, dim3(h0->NEB * n), dim3(kEntropyThreads), 0, g->stream, static_cast<const u64*>(nullptr), h0->bins, kEntropyCols, 0.0, static_cast<long long*>(nullptr),
+    k_entropy<true>, dim3(h0->NEB * n), dim3(kEntropyThreads), 0, g->stream, static_cast<u64*>(nullptr), h0->bins, kEntropyCols, 0.0, static_cast<long long*>(nullptr),
     static_cast<u64*>(nullptr), static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<EntropyScalars*>(nullptr), static_cast<double*>(nullptr),
     static_cast<double*>(nullptr), 0.0, static_cast<unsigned int*>(nullptr), static_cast<u64*>(nullptr), 0ll, 1, static_cast<const MultiEntry*>(g->d_table), a.dyn);
   HIP_TRY(hipGetLastError());
