@@ -600,7 +600,7 @@ bool trust_gate_ok(const double* init, const double* se3) {
 extern "C" {
 
 const char* nidreg_last_error(void) { return g_last_error.c_str(); }
-const char* nidreg_version(void) { return "nidreg 0.2 (gfx950, hand-written HIP)"; }
+const char* nidreg_version(void) { return "nidreg 0.3 (gfx950, hand-written HIP)"; }
 
 int nidreg_model_from_name(const char* name, int* num_intrinsics, int* num_distortion) {
   if (!name) return -1;
@@ -2107,6 +2107,16 @@ int nidreg_shard_devices(nidreg_handle* h, int* device_ids, int capacity) {
   const int n = int(h->set->shards.size());
   for (int g = 0; g < n && g < capacity; g++) device_ids[g] = h->set->shards[size_t(g)]->device;
   return n;
+}
+
+/* test hook (tests/test_host_logic.py; not part of the drop-in surface): the column-group partition a pair spread over n
+ * GPUs uses -- gcount[NG + 1] record offsets of the column groups -> cut[n + 1] group boundaries */
+int nidreg_debug_partition_groups(const int64_t* gcount, int NG, int n, int* cut_out) {
+  if (!gcount || !cut_out || NG < 1 || n < 1) return NIDREG_ERR_INVALID;
+  const std::vector<int64_t> g(gcount, gcount + NG + 1);
+  const std::vector<int> cut = partition_groups(g, NG, n);
+  for (int k = 0; k <= n; k++) cut_out[k] = cut[size_t(k)];
+  return NIDREG_OK;
 }
 
 void nidreg_trim(void) {

@@ -108,3 +108,39 @@ def test_bench_helpers_algorithmic_bytes_labels_and_committed_traffic():
     assert got == t["kernels"]["k_spline_grad"]["hbm_bytes_corrected"]
     assert 0.95 < got / bench.algorithmic_bytes(10_000_000, 1920, 1080, 256) < 1.15  # no over-fetch
     assert bench.pmc_traffic("k_spline_grad", 7, 1, 1, 16, "fp64") is None
+
+
+def test_column_group_partition_of_a_sharded_pair():
+    """The cut of a pair's column groups over n GPUs (csrc/nidreg.hip partition_groups, through a test hook of the library --
+    host arithmetic, no GPU): contiguous, exhaustive, balanced to within one group, well defined for empty clouds and more
+    GPUs than groups."""
+    import ctypes
+
+    from direct_visual_lidar_calibration_amd import _lib
+
+    lib = _lib.load()
+    lib.nidreg_debug_partition_groups.argtypes = [ctypes.POINTER(ctypes.c_int64), ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+
+    def cut(counts, n):
+        g = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        out = (ctypes.c_int * (n + 1))()
+        assert lib.nidreg_debug_partition_groups(g.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), len(counts), n, out) == 0
+        return list(out), g
+
+    rng = np.random.default_rng(3)
+    for ng, n in ((256, 8), (256, 3), (16, 8), (16, 5), (7, 2), (4, 8), (1, 2)):
+        for trial in range(5):
+            counts = rng.integers(0, 2000, ng) if trial else np.full(ng, 39062)
+            if trial == 4:
+                counts[rng.integers(0, ng, ng // 2)] = 0  # culled-away columns
+            c, g = cut(counts, n)
+            assert c[0] == 0 and c[-1] == ng and all(a <= b for a, b in zip(c, c[1:]))  # contiguous, exhaustive, ordered
+            total = int(g[-1])
+            biggest = int(counts.max()) if len(counts) else 0
+            for k in range(n):
+                share = int(g[c[k + 1]] - g[c[k]])
+                assert abs(share - total / n) <= biggest + 1, (ng, n, trial, c)  # balanced to within one group
+    c, g = cut(np.zeros(256, dtype=np.int64), 8)  # nothing to balance: equal column ranges
+    assert c == [0, 32, 64, 96, 128, 160, 192, 224, 256]
+    c, g = cut(np.full(256, 39062), 8)
+    assert c == [0, 32, 64, 96, 128, 160, 192, 224, 256]
