@@ -463,9 +463,9 @@ __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_spline_hist(
   if constexpr (MULTI) {  // one grid over several pairs: this chunk's pair brings its own records, bin image, histogram and unit
     const uint32_t pair = ch.pad & 0xffu;  // Chunk::pad = pair | (index of the chunk among its pair's chunks) << 8
     const MultiEntry& e = multi[pair];
-    pts = static_cast<const Rec*>(e.pts);
-    img = e.img;
-    hist = e.hist_buf[dyn.cur[pair]];
+    pts = as_global(static_cast<const Rec*>(e.pts));
+    img = as_global(e.img);
+    hist = as_global(e.hist_buf[dyn.cur[pair]]);
     dn_scale = e.k16;
   }
   spline_hist_body<MODEL, Rec, real, WIDE, kT>(pts, ch, img, pitch, W, H, pose, cam, B, GW, cshift, dn_scale, hist, smem, prio != 0);
@@ -496,9 +496,9 @@ __global__ __launch_bounds__(kThreads) void k_nearest_hist(
   if constexpr (MULTI) {  // one grid over several pairs (see k_spline_hist)
     const uint32_t pair = ch.pad & 0xffu;  // Chunk::pad = pair | (index of the chunk among its pair's chunks) << 8
     const MultiEntry& e = multi[pair];
-    pts = static_cast<const Rec*>(e.pts);
-    img = e.img;
-    hist = e.hist_buf[dyn.cur[pair]];
+    pts = as_global(static_cast<const Rec*>(e.pts));
+    img = as_global(e.img);
+    hist = as_global(e.hist_buf[dyn.cur[pair]]);
   }
   for (int k = tid; k < tile_w; k += kThreads) tile[k] = 0;
   if (tid == 0) *s_inl = 0;
@@ -671,19 +671,19 @@ __global__ __launch_bounds__(kEntropyThreads) void k_entropy(
     j = int(blockIdx.x) % dyn.neb;
     nblocks = dyn.neb;
     const MultiEntry& e = multi[pair];
-    hist = e.hist_buf[dyn.cur[pair]];
-    zero_buf = e.hist_buf[dyn.cur[pair] ^ 1];
+    hist = as_global(e.hist_buf[dyn.cur[pair]]);
+    zero_buf = as_global(e.hist_buf[dyn.cur[pair] ^ 1]);
     zero_words = e.zero_words;
     inv_unit = e.inv_unit;
-    part_hj = e.part_hj;
-    row_part = e.row_part;
-    phi_q = e.phi_q;
-    hist_image_out = e.hist_image;
-    hist_points_out = e.hist_points;
-    scal = e.scal;
-    out = e.out;
-    out_host = e.out_host;
-    counter = e.counters;
+    part_hj = as_global(e.part_hj);
+    row_part = as_global(e.row_part);
+    phi_q = as_global(e.phi_q);
+    hist_image_out = as_global(e.hist_image);
+    hist_points_out = as_global(e.hist_points);
+    scal = as_global(e.scal);
+    out = as_global(e.out);
+    out_host = as_global(e.out_host);
+    counter = as_global(e.counters);
     tag = dyn.want_grad ? 0.0 : dyn.tag[pair];
     tail = (!dyn.want_grad || e.nchunks == 0) ? 1 : 0;  // a pair without points has no gradient workgroup to run the tail
   }
@@ -1107,23 +1107,23 @@ __global__ __launch_bounds__(kThreads, grad_min_waves(MODEL)) void k_spline_grad
   if constexpr (MULTI) {
     const uint32_t pair = ch.pad & 0xffu;  // Chunk::pad = pair | (index of the chunk among its pair's chunks) << 8
     const MultiEntry& e = multi[pair];
-    pts = static_cast<const Rec*>(e.pts);
-    img = e.img;
-    hist = e.hist_buf[dyn.cur[pair]];
+    pts = as_global(static_cast<const Rec*>(e.pts));
+    img = as_global(e.img);
+    hist = as_global(e.hist_buf[dyn.cur[pair]]);
     inv_unit = e.inv_unit;
-    phi_q = e.phi_q;
-    scal = e.scal;
-    partials = e.partials;
-    out = e.out;
-    out_host = e.out_host;
+    phi_q = as_global(e.phi_q);
+    scal = as_global(e.scal);
+    partials = as_global(e.partials);
+    out = as_global(e.out);
+    out_host = as_global(e.out_host);
     tag = dyn.tag[pair];
-    counter = e.counters + 1;
+    counter = as_global(e.counters) + 1;
     my_block = ch.pad >> 8;
     my_blocks = unsigned(e.nchunks);
-    gt.phi_q = e.phi_q;
-    gt.hist_image = e.hist_image;
-    gt.hist_points = e.hist_points;
-    gt.scal = e.scal;
+    gt.phi_q = as_global(e.phi_q);
+    gt.hist_image = as_global(e.hist_image);
+    gt.hist_points = as_global(e.hist_points);
+    gt.scal = as_global(e.scal);
   }
   {
     double coefA, coefB, S;

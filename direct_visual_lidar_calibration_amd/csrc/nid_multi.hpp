@@ -47,6 +47,21 @@ struct MultiDyn {
 };
 
 
+// A pointer READ FROM DEVICE MEMORY (this table) is a generic pointer to the compiler: every access through it becomes a
+// FLAT instruction -- 64-bit per-lane addresses instead of an SGPR base + 32-bit lane offset, and, worse, FLAT loads count
+// on lgkmcnt as well as vmcnt, so each wait for an LDS atomic of the tap loop also waited for the record prefetch: the
+// multi-pair kernels ran 1.35-1.65x slower than the single-pair kernels on the same points (round 3, 85 + 100 us against
+// 51 + 74 us).  Kernel-argument pointers are known to be global; these are told to be.
+#if defined(__HIPCC__)
+template <typename T>
+__device__ __forceinline__ T* as_global(T* p) {
+  // through an integer: a plain generic -> global -> generic cast pair is folded away again before the address-space
+  // inference runs (and an assume(!is_shared && !is_private) did not reach it either; both checked in the ISA)
+  typedef __attribute__((address_space(1))) T global_t;
+  return (T*)(global_t*)(unsigned long long)p;
+}
+#endif
+
 template <bool MULTI>
 struct multi_dyn_of {
   typedef typename std::conditional<MULTI, MultiDyn, NoMultiDyn>::type type;

@@ -641,6 +641,66 @@ struct nidreg_cloud {
 
 namespace {
 
+// ---- chunk tables: each chunk = one workgroup, points of ONE column group only.  A pass should be ONE round of co-resident
+// workgroups (`target` of them; measured on cfg 2: the per-workgroup prologue / flush is amortised over more points and no
+// partial last round is left -- 2048 chunks +4 %, 4096 +12 %).  Every group is split EVENLY into ceil(count / CH) chunks,
+// CH = N / target rounded up to whole workgroup sweeps -- and CH GROWS until the table fits the round.  Without that step a
+// cloud whose column populations are not uniform (a pair of a multi-pair set, any view-culled cloud: the rank equalisation
+// of preprocess.cpp:464-473 makes the columns of the WHOLE cloud equal, not those of a subset) got a few workgroups more
+// than the round holds, and a pass took a round plus one lone chunk: two pairs x 5M points had 519 / 1031 chunks for 512 /
+// 1024 slots and their kernels ran 85 + 100 us instead of 51 + 74 us (round 3's open question about the two-pair single
+// grid; found with the column counts of the bench scene, tools/chunk_rounds.py).  A group is never merged with another
+// one (a workgroup owns its columns), so a cloud with more non-empty groups than `target` gets one chunk per group.
+// pair < 0: a single-pair table (pad = 0); otherwise Chunk::pad = pair | (index among the pair's chunks) << 8.
+void split_groups(const int64_t* gcount, int NG, int64_t target, int threads, int pair, std::vector<Chunk>& chunks) {
+  const int64_t N = gcount[NG] - gcount[0];
+  target = std::max<int64_t>(target, 1);
+  int64_t nonempty = 0, biggest = 0;
+  for (int g = 0; g < NG; g++) {
+    const int64_t cnt = gcount[g + 1] - gcount[g];
+    if (cnt > 0) nonempty++;
+    biggest = std::max(biggest, cnt);
+  }
+  auto round_up = [threads](int64_t v) { return std::max<int64_t>(threads, ((v + threads - 1) / threads) * threads); };
+  auto count_for = [&](int64_t ch) {
+    int64_t n = 0;
+    for (int g = 0; g < NG; g++) {
+      const int64_t cnt = gcount[g + 1] - gcount[g];
+      if (cnt > 0) n += (cnt + ch - 1) / ch;
+    }
+    return n;
+  };
+  int64_t CH = round_up((N + target - 1) / target);
+  const int64_t limit = std::max(target, nonempty);
+  if (count_for(CH) > limit) {  // smallest CH (in whole sweeps) whose table fits: count_for is non-increasing in CH
+    int64_t lo = CH / threads, hi = round_up(biggest) / threads;  // count_for(lo * threads) > limit >= nonempty = count_for(hi * threads)
+    while (hi - lo > 1) {
+      const int64_t mid = lo + (hi - lo) / 2;
+      if (count_for(mid * threads) > limit) {
+        lo = mid;
+      } else {
+        hi = mid;
+      }
+    }
+    CH = hi * threads;
+  }
+  const size_t first = chunks.size();
+  for (int g = 0; g < NG; g++) {
+    const int64_t lo = gcount[g], hi = gcount[g + 1];
+    if (hi <= lo) continue;
+    const int64_t parts = (hi - lo + CH - 1) / CH;
+    const int64_t size = (((hi - lo + parts - 1) / parts + 63) / 64) * 64;  // 64 records = 1 KB: chunk starts stay aligned
+    for (int64_t st = lo; st < hi; st += size) {
+      Chunk c;
+      c.start = uint32_t(st);
+      c.count = uint32_t(std::min<int64_t>(size, hi - st));
+      c.group = uint32_t(g);
+      c.pad = pair < 0 ? 0u : (uint32_t(pair) | (uint32_t(chunks.size() - first) << 8));
+      chunks.push_back(c);
+    }
+  }
+}
+
 struct CreateOpts {
   // one shard of a ShardSet: built from the column groups [group_lo, group_hi) of `master` (a complete handle of the pair
   // on the owner device) -- its bin image and that slice of its bucketed records are copied device to device
@@ -830,11 +890,8 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
     CREATE_TRY(hipStreamSynchronize(nullptr));  // the bin-image kernel, before the arena is handed to the next construction
   }
 
-  // ---- chunk tables: each chunk = one workgroup, points of one column group only.  By default a pass
-  // gets ONE round of co-resident workgroups (measured on cfg 2: the per-workgroup prologue / flush is
-  // amortised over more points and no partial last round is left -- 2048 chunks +4 %, 4096 +12 %):
-  // 4 workgroups per CU for the 256-thread kernels, 2 per CU for the WIDE histogram kernel (64 KB LDS
-  // each), which therefore has its own table.  A column group is split EVENLY into its chunks.
+  // ---- chunk tables (split_groups): by default 4 workgroups per CU for the 256-thread kernels, 2 per CU for the WIDE
+  // histogram kernel (64 KB LDS each), which therefore has its own table
   {
     int num_cus = 256;
     if (hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || num_cus <= 0) num_cus = 256;
@@ -843,24 +900,7 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
     // (profiles/r03d_workgroup_spread.txt), but the workgroups of one CU share its issue capacity: what ends a pass is the
     // slowest CU, not the slowest workgroup, and no weighting moved the kernel times (profiles/r03e_slot_weights_no_gain.txt;
     // the part-major order itself cost 3 us in the gradient pass).)
-    auto build_chunks = [&](int target, int threads, std::vector<Chunk>& chunks) {
-      int64_t CH = (N + target - 1) / std::max(target, 1);
-      CH = std::max<int64_t>(threads, ((CH + threads - 1) / threads) * threads);
-      for (int g = 0; g < h->NG; g++) {
-        const int64_t cnt = gcount[g + 1] - gcount[g];
-        if (cnt <= 0) continue;
-        const int64_t parts = (cnt + CH - 1) / CH;
-        const int64_t size = (((cnt + parts - 1) / parts + 63) / 64) * 64;  // 64 records = 1 KB: chunk starts stay aligned
-        for (int64_t s = gcount[g]; s < gcount[g + 1]; s += size) {
-          Chunk c;
-          c.start = uint32_t(s);
-          c.count = uint32_t(std::min<int64_t>(size, gcount[g + 1] - s));
-          c.group = uint32_t(g);
-          c.pad = 0;
-          chunks.push_back(c);
-        }
-      }
-    };
+    auto build_chunks = [&](int target, int threads, std::vector<Chunk>& chunks) { split_groups(gcount.data(), h->NG, target, threads, -1, chunks); };
     // workgroups per CU that are really co-resident for THIS kernel instantiation: 4 for the pinhole family, 3 for the
     // fisheye / equirectangular gradient kernels (154-161 VGPRs) -- 1024 chunks there meant 1.33 rounds
     int per_cu_grad = 4, per_cu_hist = h->wide ? 2 : 4;
@@ -1076,25 +1116,9 @@ bool groupable(const nidreg_handle* a, const nidreg_handle* b) {
          !a->set && !b->set && !a->is_shard && !b->is_shard && !a->timing && !b->timing;
 }
 
-// chunks of one pair for a share `target` of the round (same rule as create_impl: a column group is split evenly)
+// chunks of one pair for a share `target` of the round (same rule as create_impl's tables: split_groups)
 void pair_chunks(const nidreg_handle* h, int pair, int64_t target, int threads, std::vector<Chunk>& chunks) {
-  const int64_t N = h->num_points;
-  int64_t CH = (N + target - 1) / std::max<int64_t>(target, 1);
-  CH = std::max<int64_t>(threads, ((CH + threads - 1) / threads) * threads);
-  for (int g = 0; g < h->NG; g++) {
-    const int64_t lo = h->gcount[size_t(g)], hi = h->gcount[size_t(g) + 1];
-    if (hi <= lo) continue;
-    const int64_t parts = (hi - lo + CH - 1) / CH;
-    const int64_t size = (((hi - lo + parts - 1) / parts + 63) / 64) * 64;
-    for (int64_t st = lo; st < hi; st += size) {
-      Chunk c;
-      c.start = uint32_t(st);
-      c.count = uint32_t(std::min<int64_t>(size, hi - st));
-      c.group = uint32_t(g);
-      c.pad = uint32_t(pair) | (uint32_t(chunks.size()) << 8);  // pair, and the chunk's index among the pair's chunks
-      chunks.push_back(c);
-    }
-  }
+  split_groups(h->gcount.data(), h->NG, target, threads, pair, chunks);
 }
 
 // returns the group with its use count raised (release_group when the evaluation is over), or nullptr
@@ -1312,14 +1336,15 @@ int group_eval_iso(MultiGroup* g, const double* T, double* costs) {
 
 // handles[0..n) all distinct, compatible and on one device?
 // Measured on the same clouds in one harness (tools/omp_pairs.cpp on the 10M-point scene split into n pairs,
-// profiles/r03g_multi_pair_patterns.jsonl), microseconds per evaluation of all pairs: single grid 191 / 185 / 178 at
-// 2 / 4 / 8 pairs, per-pair launches 149 / 197 / 295, one OpenMP caller per pair 171 / 225 / 297.  The single grid pays off
-// from four pairs on (three launches instead of 3 n, one round of workgroups instead of n); two or three pairs run as
-// per-pair launches, every pair's histogram pass queued before the rest.  NIDREG_MULTI_GRID_MIN=n moves the threshold.
+// profiles/r03q_omp_pairs.jsonl), microseconds per evaluation of all pairs: single grid 152 / 149 / 172 at 2 / 4 / 8
+// pairs, per-pair launches 154 / 198 / 274, one OpenMP caller per pair 173 / 215 / 282.  (Until the chunk tables were made
+// to fit one round -- split_groups -- the single grid took 191 / 185 / 178 and two or three pairs ran as per-pair launches.)
+// The single grid (three launches instead of 3 n) is therefore used from two pairs on; NIDREG_MULTI_GRID_MIN=n moves the
+// threshold, NIDREG_NO_MULTI_GRID=1 keeps per-pair launches (every pair's histogram pass queued before the rest).
 int multi_grid_min() {
   static const int v = [] {
     const char* e = std::getenv("NIDREG_MULTI_GRID_MIN");
-    const long m = e ? std::strtol(e, nullptr, 10) : 4;
+    const long m = e ? std::strtol(e, nullptr, 10) : 2;
     return int(std::max(2L, std::min(m, long(kMaxMulti) + 1)));
   }();
   return v;
@@ -2117,6 +2142,19 @@ int nidreg_debug_partition_groups(const int64_t* gcount, int NG, int n, int* cut
   const std::vector<int> cut = partition_groups(g, NG, n);
   for (int k = 0; k <= n; k++) cut_out[k] = cut[size_t(k)];
   return NIDREG_OK;
+}
+
+/* test hook (tests/test_host_logic.py; not part of the drop-in surface): the chunk table split_groups builds for a share
+ * `target` of a round -- gcount[NG + 1] record offsets of the column groups -> up to cap rows {start, count, group, pad};
+ * returns the number of chunks (also when it exceeds cap) */
+int nidreg_debug_chunk_table(const int64_t* gcount, int NG, int target, int threads, int pair, uint32_t* rows_out, int cap) {
+  if (!gcount || NG < 1 || threads < 1) return NIDREG_ERR_INVALID;
+  std::vector<Chunk> chunks;
+  split_groups(gcount, NG, target, threads, pair, chunks);
+  for (size_t k = 0; k < chunks.size() && int(k) < cap && rows_out; k++) {
+    rows_out[4 * k] = chunks[k].start, rows_out[4 * k + 1] = chunks[k].count, rows_out[4 * k + 2] = chunks[k].group, rows_out[4 * k + 3] = chunks[k].pad;
+  }
+  return int(chunks.size());
 }
 
 void nidreg_trim(void) {

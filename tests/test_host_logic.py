@@ -144,3 +144,53 @@ def test_column_group_partition_of_a_sharded_pair():
     assert c == [0, 32, 64, 96, 128, 160, 192, 224, 256]
     c, g = cut(np.full(256, 39062), 8)
     assert c == [0, 32, 64, 96, 128, 160, 192, 224, 256]
+
+
+def test_chunk_tables_fit_one_round_of_workgroups():
+    """The chunk table of a pass (csrc/nidreg.hip split_groups, through a test hook -- host arithmetic, no GPU): every record in
+    exactly one chunk, a chunk inside one column group, and never more chunks than the round holds when the groups allow it
+    -- also for column populations that are not uniform (a pair of a multi-pair set, a view-culled cloud): the rule without
+    the last step gave two pairs x 5M points 519 / 1031 workgroups for 512 / 1024 slots, and every pass a round plus one lone
+    chunk (round 3)."""
+    import ctypes
+
+    from direct_visual_lidar_calibration_amd import _lib
+
+    lib = _lib.load()
+    lib.nidreg_debug_chunk_table.argtypes = [ctypes.POINTER(ctypes.c_int64), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32), ctypes.c_int]
+
+    def table(counts, target, threads, pair=-1):
+        g = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        cap = 4 * (len(counts) + target) + 16
+        rows = (ctypes.c_uint32 * (4 * cap))()
+        n = lib.nidreg_debug_chunk_table(g.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), len(counts), target, threads, pair, rows, cap)
+        assert 0 <= n <= cap
+        return np.array(rows[: 4 * n], dtype=np.int64).reshape(n, 4), g
+
+    rng = np.random.default_rng(11)
+    cases = [(np.full(256, 39062), 1024, 256), (np.full(256, 39062), 512, 512)]  # cfg 2: exactly one round, as before
+    cases += [(rng.binomial(40000, 0.5, 256) + rng.integers(-600, 600, 256), t, th) for t, th in ((512, 256), (256, 512), (1024, 256))]  # a pair of a multi-pair set
+    culled = rng.integers(0, 60000, 256)
+    culled[rng.integers(0, 256, 100)] = 0
+    cases += [(culled, 1024, 256), (culled, 512, 512), (culled, 64, 256), (np.array([5]), 1024, 256), (np.zeros(16, dtype=np.int64), 1024, 256), (rng.integers(0, 300, 16), 1024, 256)]
+    for counts, target, threads in cases:
+        for pair in (-1, 3):
+            rows, g = table(counts, target, threads, pair)
+            nonempty = int(np.count_nonzero(counts))
+            assert len(rows) <= max(target, nonempty), (len(rows), target, nonempty)
+            assert len(rows) >= nonempty
+            covered = np.zeros(int(g[-1]), dtype=np.int32)
+            for k, (start, count, group, pad) in enumerate(rows):
+                assert count > 0 and g[group] <= start and start + count <= g[group + 1]
+                assert (start - g[group]) % 64 == 0
+                covered[start : start + count] += 1
+                assert pad == (0 if pair < 0 else (pair | (k << 8)))
+            assert np.all(covered == 1)
+            if len(rows):
+                # even split: the chunks of one group differ by less than one 64-record step (the last takes the remainder)
+                for grp in np.unique(rows[:, 2]):
+                    c = rows[rows[:, 2] == grp, 1]
+                    assert c.max() - c.min() < 64 * len(c) + 64
+    # the uniform cloud keeps the table it always had
+    rows, _ = table(np.full(256, 39062), 1024, 256)
+    assert len(rows) == 1024 and rows[:, 1].max() <= 9792
