@@ -672,7 +672,8 @@ void split_groups(const int64_t* gcount, int NG, int64_t target, int threads, in
   };
   int64_t CH = round_up((N + target - 1) / target);
   const int64_t limit = std::max(target, nonempty);
-  if (count_for(CH) > limit) {  // smallest CH (in whole sweeps) whose table fits: count_for is non-increasing in CH
+  // NIDREG_CHUNKS_NO_FIT=1: the rule of rounds 1-3 (no growth step), for A/B measurements (tools/culled_cloud_ab.py)
+  if (count_for(CH) > limit && !std::getenv("NIDREG_CHUNKS_NO_FIT")) {  // smallest CH (in whole sweeps) whose table fits: count_for is non-increasing in CH
     int64_t lo = CH / threads, hi = round_up(biggest) / threads;  // count_for(lo * threads) > limit >= nonempty = count_for(hi * threads)
     while (hi - lo > 1) {
       const int64_t mid = lo + (hi - lo) / 2;
