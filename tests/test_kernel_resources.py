@@ -82,3 +82,26 @@ def test_wide_histogram_kernel_keeps_the_tile_at_lds_address_zero(kernel_metadat
     _, meta = kernel_metadata
     for name, m in _find(meta, "k_spline_histILi0ENS_5Rec32EdLb1E").items():
         assert m["lds_static"] == 0, (name, m)
+
+
+def test_spline_kernels_use_global_not_flat_memory_instructions(kernel_metadata):
+    """Round 3: the multi-pair kernels read their pointers from a device table; a pointer loaded from memory is a generic
+    pointer, and every record load, image gather and histogram flush through it became a FLAT instruction (64-bit lane
+    addresses, counted on lgkmcnt as well as vmcnt: the waits for the LDS atomics also waited for the record prefetch).
+    as_global() (nid_multi.hpp) restores the single-pair kernels' forms.  The one FLAT load the gradient kernels may keep is
+    phi(q_r), read from LDS or global memory through one pointer in the prologue; k_fused is not covered."""
+    text, meta = kernel_metadata
+    checked = 0
+    for name in {**_find(meta, "k_spline_hist"), **_find(meta, "k_spline_grad")}:
+        start = text.index("\n" + name + ":")
+        body = text[start:text.index(".Lfunc_end", start)]
+        flat = re.findall(r"^\s+(flat_\w+)", body, flags=re.M)
+        # allowed: the system-scope stores of shard_announce / the host mirror (peer and host pointers come from tables too,
+        # a handful per workgroup) and the phi(q_r) load; not allowed: record loads (dwordx3 / dwordx4) and the flush's atomics
+        hot = [f for f in flat if f in ("flat_load_dwordx3", "flat_load_dwordx4") or f.startswith("flat_atomic_add_x2")]
+        assert not hot, (name, hot)
+        if "Lb1EEEv" in name and "k_spline_hist" in name:  # the multi-pair histogram kernel: nothing FLAT at all
+            assert not flat, (name, flat)
+        assert re.search(r"^\s+global_load_dwordx4\s+v\[\d+:\d+\], v\d+, s\[\d+:\d+\]", body, flags=re.M), name  # SGPR base + 32-bit lane offset
+        checked += 1
+    assert checked >= 96  # 6 models x 2 record types x (WIDE / GW1) x (single / multi) x 2 passes
