@@ -22,3 +22,23 @@ def pytest_configure(config):
 import os  # noqa: E402
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Margins the kernels delivered against the oracle over this session (tests/parity.py): written when any check ran."""
+    import json
+
+    import parity
+
+    s = parity.summary()
+    if not s:
+        return
+    out = os.environ.get("NIDREG_MARGINS_OUT", os.path.join(ROOT, "gpurun_out", "parity_margins.json"))
+    try:
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        s["exitstatus"] = int(exitstatus)
+        s["bars"] = {"cost_atol": parity.COST_ATOL, "grad_rtol": parity.GRAD_RTOL, "grad_atol": parity.GRAD_ATOL, "hist_atol": parity.HIST_ATOL}
+        with open(out, "w") as f:
+            json.dump(s, f, indent=1)
+    except OSError:
+        pass

@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 import oracle_lib
+import parity
 from direct_visual_lidar_calibration_amd import nid, se3, synth
 
 pytestmark = pytest.mark.gpu
@@ -61,11 +62,11 @@ def test_spline_value_gradient_histogram(model, bins):
         ref = oracle_nid(s, bins, x, want_hist=True)
         ok, c, g = cost(x)
         assert ok and ref["ok"]
-        assert abs(c - ref["cost"]) <= 1e-10
-        assert np.allclose(g, ref["grad"], rtol=1e-7, atol=1e-10)
+        parity.check_cost(c, ref["cost"])
+        parity.check_grad(g, ref["grad"])
         joint, hi, hp = cost.histograms()
-        assert np.abs(joint - ref["hist"]).max() <= 1e-9
-        assert np.abs(hi - ref["hist_image"]).max() <= 1e-8
+        parity.check_hist(joint, ref["hist"])
+        parity.check_hist(hi, ref["hist_image"], kind="hist_image")
         assert np.array_equal(hp, ref["hist_points"])  # integer inlier counts per column
         # cost-only instantiation (T = double) gives the same value
         ok2, c2, g2 = cost(x, want_grad=False)
@@ -118,7 +119,8 @@ def test_single_column_specialisations_match_generic_kernels():
             assert np.allclose(g0, g1, rtol=1e-11, atol=1e-14)
         if prec == "fp64":
             ref = oracle_lib.nid_cost(s.model, s.intrinsics, s.distortion, s.image_f64, pts, s.intensities, 256, x)
-            assert abs(c0 - ref["cost"]) <= 1e-10 and np.allclose(g0, ref["grad"], rtol=1e-7, atol=1e-10)
+            parity.check_cost(c0, ref["cost"])
+            parity.check_grad(g0, ref["grad"])
         for c in (wide, generic, multi):
             c.close()
 
@@ -133,8 +135,9 @@ def test_spline_double_records_when_not_float_representable():
     x = s.T_camera_lidar_init
     ref = oracle_lib.nid_cost(s.model, s.intrinsics, s.distortion, s.image_f64, pts, s.intensities, 16, x)
     ok, c, g = cost(x)
-    assert ok and abs(c - ref["cost"]) <= 1e-10
-    assert np.allclose(g, ref["grad"], rtol=1e-7, atol=1e-10)
+    assert ok
+    parity.check_cost(c, ref["cost"])
+    parity.check_grad(g, ref["grad"])
     cost.close()
 
 
@@ -178,7 +181,8 @@ def test_spline_edge_cases():
     c2 = nid.NIDCost(proj, s.image_f64, pts, ints, 16)
     ref = oracle_lib.nid_cost(s.model, s.intrinsics, s.distortion, s.image_f64, pts, ints, 16, s.T_camera_lidar_true, want_hist=True)
     ok, c, g = c2(s.T_camera_lidar_true)
-    assert ok == ref["ok"] and abs(c - ref["cost"]) <= 1e-10
+    assert ok == ref["ok"]
+    parity.check_cost(c, ref["cost"])
     joint, hi, hp = c2.histograms()
     assert np.array_equal(hp, ref["hist_points"])
     c2.close()
@@ -187,8 +191,9 @@ def test_spline_edge_cases():
     xq[:4] *= 1.01
     ref = oracle_nid(s, 16, xq)
     ok, c, g = cost(xq)
-    assert ok == ref["ok"] and abs(c - ref["cost"]) <= 1e-10
-    assert np.allclose(g, ref["grad"], rtol=1e-7, atol=1e-10)
+    assert ok == ref["ok"]
+    parity.check_cost(c, ref["cost"])
+    parity.check_grad(g, ref["grad"])
     cost.close()
 
 
@@ -217,11 +222,12 @@ def test_border_points_contribute_clamped_taps():
     cost = nid.NIDCost(proj, s.image_f64, pts, ints, 64)
     ref = oracle_lib.nid_cost(model, intr, dist, s.image_f64, pts, ints, 64, s.T_camera_lidar_true, want_hist=True)
     ok, c, g = cost(s.T_camera_lidar_true)
-    assert ok and abs(c - ref["cost"]) <= 1e-10
+    assert ok
+    parity.check_cost(c, ref["cost"])
     joint, _, hp = cost.histograms()
-    assert np.abs(joint - ref["hist"]).max() <= 1e-9
+    parity.check_hist(joint, ref["hist"])
     assert np.array_equal(hp, ref["hist_points"])
-    assert np.allclose(g, ref["grad"], rtol=1e-7, atol=1e-10)
+    parity.check_grad(g, ref["grad"])
     cost.close()
 
 
@@ -267,7 +273,9 @@ def test_multi_nid_cost_sum_and_trust_gate():
     x = se3.plus(init, np.array([0.01, -0.02, 0.015, 0.004, -0.003, 0.002]))
     ok, c, g = multi(x)
     rok, rc, rg = oracle_lib.multi_nid_cost(s1.model, s1.intrinsics, s1.distortion, pairs, 16, init, x)
-    assert ok and rok and abs(c - rc) <= 2e-10 and np.allclose(g, rg, rtol=1e-7, atol=1e-10)
+    assert ok and rok
+    parity.check_cost(c, rc, atol=2e-10)
+    parity.check_grad(g, rg)
     # outside the 0.2 m / 2 deg gate -> false without evaluating
     for delta in ([0.25, 0, 0, 0, 0, 0], [0, 0, 0, 0, np.radians(2.5), 0]):
         xg = se3.plus(init, np.array(delta, dtype=float))
@@ -423,10 +431,12 @@ def test_spline_and_nearest_odd_bin_counts(bins):
     cost = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, bins)
     ref = oracle_nid(s, bins, x, want_hist=True)
     ok, c, g = cost(x)
-    assert ok == ref["ok"] and abs(c - ref["cost"]) <= 1e-10
-    assert np.allclose(g, ref["grad"], rtol=1e-7, atol=1e-10)
+    assert ok == ref["ok"]
+    parity.check_cost(c, ref["cost"])
+    parity.check_grad(g, ref["grad"])
     joint, hi, hp = cost.histograms()
-    assert np.abs(joint - ref["hist"]).max() <= 1e-9 and np.array_equal(hp, ref["hist_points"])
+    assert np.array_equal(hp, ref["hist_points"])
+    parity.check_hist(joint, ref["hist"])
     cost.close()
     max_fov = oracle_lib.estimate_camera_fov(s.model, s.intrinsics, s.distortion, s.width, s.height)
     calc = nid.CostCalculatorNID(proj, s.image_u8, s.points, s.intensities, nid.NIDCostParams(bins), max_fov=max_fov)
@@ -449,10 +459,12 @@ def test_baseline_config_cameras_at_scale(camera, n):
     cost = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, 256)
     ref = oracle_nid(s, 256, x, want_hist=True)
     ok, c, g = cost(x)
-    assert ok and ref["ok"] and abs(c - ref["cost"]) <= 1e-10
-    assert np.allclose(g, ref["grad"], rtol=1e-7, atol=1e-10)
+    assert ok and ref["ok"]
+    parity.check_cost(c, ref["cost"])
+    parity.check_grad(g, ref["grad"])
     joint, hi, hp = cost.histograms()
-    assert np.abs(joint - ref["hist"]).max() <= 1e-9 and np.array_equal(hp, ref["hist_points"])
+    assert np.array_equal(hp, ref["hist_points"])
+    parity.check_hist(joint, ref["hist"])
     cost.close()
     max_fov = oracle_lib.estimate_camera_fov(s.model, s.intrinsics, s.distortion, s.width, s.height)
     calc = nid.CostCalculatorNID(proj, s.image_u8, s.points, s.intensities, nid.NIDCostParams(256), max_fov=max_fov)
@@ -479,11 +491,13 @@ def test_headline_workload_10m_points_matches_oracle():
     x = synth.random_pose_near(s.T_camera_lidar_true, rng)
     ref = oracle_nid(s, 256, x, want_hist=True, threads=oracle_lib.num_threads())
     ok, c, g = cost(x)
-    assert ok and ref["ok"] and abs(c - ref["cost"]) <= 1e-10
-    assert np.allclose(g, ref["grad"], rtol=1e-7, atol=1e-10)
+    assert ok and ref["ok"]
+    parity.check_cost(c, ref["cost"])
+    parity.check_grad(g, ref["grad"])
     joint, hi, hp = cost.histograms()
     # 2^-38 per tap, <= ~2500 taps in the fullest bin; the oracle's own double sums round at ~1e-12 there
-    assert np.abs(joint - ref["hist"]).max() <= 1e-8 and np.array_equal(hp, ref["hist_points"])
+    assert np.array_equal(hp, ref["hist_points"])
+    parity.check_hist(joint, ref["hist"], atol=1e-8, what="10M points")
     assert hp.sum() == ref["hist_points"].sum()
     cost.close()
 
@@ -522,11 +536,13 @@ def test_dense_map_50m_points_4k_image_matches_oracle():
     x = synth.random_pose_near(s.T_camera_lidar_true, rng)
     ref = oracle_nid(s, 256, x, want_hist=True, threads=oracle_lib.num_threads())
     ok, c, g = cost(x)
-    assert ok and ref["ok"] and abs(c - ref["cost"]) <= 1e-10
-    assert np.allclose(g, ref["grad"], rtol=1e-7, atol=1e-10)
+    assert ok and ref["ok"]
+    parity.check_cost(c, ref["cost"])
+    parity.check_grad(g, ref["grad"])
     joint, hi, hp = cost.histograms()
     # 2^-36 per tap, <= ~12 000 taps in the fullest bin
-    assert np.abs(joint - ref["hist"]).max() <= 1e-7 and np.array_equal(hp, ref["hist_points"])
+    assert np.array_equal(hp, ref["hist_points"])
+    parity.check_hist(joint, ref["hist"], atol=1e-7, what="50M points")
     assert hp.sum() == ref["hist_points"].sum()
     ok2, c2, g2 = cost(x, want_grad=False)
     assert ok2 and c2 == c
@@ -655,7 +671,8 @@ def test_in_library_sharding_matches_plain_handle(nshards):
             assert ok2 and c2 == c and g2 is None
         ref = oracle_nid(s, bins, poses[1])
         ok1, c1, g1 = sh(poses[1])
-        assert abs(c1 - ref["cost"]) <= 1e-10 and np.allclose(g1, ref["grad"], rtol=1e-7, atol=1e-10)
+        parity.check_cost(c1, ref["cost"])
+        parity.check_grad(g1, ref["grad"])
         # nothing projects: every shard announces zero inliers, the functor returns false like the reference's 0 / 0
         far = np.array(poses[1], dtype=np.float64).copy()
         far[4:7] += 1.0e4
@@ -766,8 +783,9 @@ def test_points_on_knot_and_border_boundaries():
         ok, c, g = cost(x)
         joint, hi, hp = cost.histograms()
         assert ok and ref["ok"] and np.array_equal(hp, ref["hist_points"])  # same inlier decisions
-        assert np.abs(joint - ref["hist"]).max() <= 1e-9 and abs(c - ref["cost"]) <= 1e-10
-        assert np.allclose(g, ref["grad"], rtol=1e-7, atol=1e-10)
+        parity.check_hist(joint, ref["hist"])
+        parity.check_cost(c, ref["cost"])
+        parity.check_grad(g, ref["grad"])
         cost.close()
 
 

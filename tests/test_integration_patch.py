@@ -12,6 +12,8 @@ import subprocess
 import numpy as np
 import pytest
 
+import parity
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
 CSRC = os.path.join(ROOT, "direct_visual_lidar_calibration_amd", "csrc")
@@ -167,8 +169,9 @@ def test_reference_cameras_feed_the_gpu_cost(tmp_path):
             f.write(np.ascontiguousarray(s.intensities, dtype=np.float64).tobytes())
         vals = np.array([float(v) for v in subprocess.check_output([EXE, str(path)]).decode().split()])
         ref = oracle_lib.nid_cost(s.model, s.intrinsics, s.distortion, s.image_f64, s.points, s.intensities, bins, x)
-        assert abs(vals[0] - ref["cost"]) <= 1e-10 and abs(vals[8] - ref["cost"]) <= 1e-10
-        assert np.allclose(vals[1:8], ref["grad"], rtol=1e-7, atol=1e-10)
+        parity.check_cost(vals[0], ref["cost"])
+        parity.check_cost(vals[8], ref["cost"])
+        parity.check_grad(vals[1:8], ref["grad"])
 
 
 @pytest.mark.gpu

@@ -7,13 +7,15 @@ ARGS="$@"
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/pmc_$TAG
 mkdir -p $OUT
-python $REPO/tools/make_scene_cache.py /tmp/scene.npz > $OUT/make_scene.log 2>&1
+[ -f /tmp/scene.npz ] || python $REPO/tools/make_scene_cache.py /tmp/scene.npz > $OUT/make_scene.log 2>&1
+DRIVER=${PMC_DRIVER:-run_scene.py}   # PMC_DRIVER=run_scene_nearest.py: the NEAREST twin
+export RUN_SCENE_QUICK=1
 cd /tmp && export TMPDIR=/tmp
 PASSES=${PMC_PASSES:-fetch write sq1 sq2 sq3 tcc tcp}  # PMC_PASSES="fetch write sq1": only what traffic_from_pmc.py / bench.py read
 run() { # name, counters...
   NAME=$1; shift
   case " $PASSES " in *" $NAME "*) ;; *) return;; esac
-  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$NAME -- python $REPO/tools/run_scene.py /tmp/scene.npz 6 $ARGS > $OUT/$NAME.log 2>&1
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$NAME -- python $REPO/tools/$DRIVER /tmp/scene.npz 6 $ARGS > $OUT/$NAME.log 2>&1
   echo "$NAME rc=$?"
 }
 run fetch FETCH_SIZE

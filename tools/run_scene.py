@@ -30,17 +30,17 @@ poses = [se3.plus(z["T_true"], np.random.default_rng(7).uniform(-1, 1, 6) * np.a
 for x in poses[:3]:
     cost(x)
 t0 = time.perf_counter()
-NW = 200
+NW = 8 if os.environ.get("RUN_SCENE_QUICK") else 200  # RUN_SCENE_QUICK=1: counter passes (every kernel serialised) need launches, not statistics
 for k in range(NW):
     cost(poses[k & 7])
 wall_ms = (time.perf_counter() - t0) * 1e3 / NW
 # the same through nidreg_eval_batch (no Python between the evaluations: what bench.py times), median of 5 blocks
 block = np.ascontiguousarray([poses[k & 7] for k in range(50)])
 wb = []
-for _ in range(5):
+for _ in range(1 if os.environ.get("RUN_SCENE_QUICK") else 5):
     t0 = time.perf_counter()
-    cost.eval_batch(block)
-    wb.append((time.perf_counter() - t0) * 1e3 / len(block))
+    cost.eval_batch(block[:8] if os.environ.get("RUN_SCENE_QUICK") else block)
+    wb.append((time.perf_counter() - t0) * 1e3 / (8 if os.environ.get("RUN_SCENE_QUICK") else len(block)))
 wall_batch_ms = float(np.median(wb))
 # the whole evaluation between two HIP events, whichever route runs it (one fused kernel with NIDREG_FUSED=1)
 cost.set_timing(2)
