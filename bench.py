@@ -285,9 +285,8 @@ def main():
             cost(poses[k % len(poses)])
         python_call_rate = args.steps / (time.perf_counter() - t1)
         reps = max(10, min(args.steps, 30))
-        # (a) the evaluation as it runs in the timed region -- ONE kernel (k_fused) when the handle has the GPU to itself --
-        # between two events; (b) the three-kernel route (k_spline_hist / k_entropy / k_spline_grad) with an event after
-        # every kernel (it is what runs when several callers share the GPU, and the per-pass breakdown)
+        # (a) the whole evaluation between two events; (b) the same with an event after every kernel (k_spline_hist /
+        # k_entropy / k_spline_grad): the per-pass breakdown
         inner.set_timing(2)
         whole = []
         for k in range(reps):
@@ -304,27 +303,21 @@ def main():
         kt = {key: float(np.mean(v)) for key, v in acc.items()}
         whole_ms = float(np.mean(whole))
         n_local = pts.shape[0]
-        fused = bool(inner.info().get("fused"))
         build = _lib.kernel_source_hash()
         kstats = _matching_kernel_stats(n_local, scene.width, scene.height, args.bins, args.precision, build)
         ks = {k_: v["avg_ns"] * 1e-6 for k_, v in kstats["kernels"].items()} if kstats else {}
         eval_bytes = algorithmic_bytes(n_local, scene.width, scene.height, args.bins)
         eval_achieved = eval_bytes / (ms_per_step * 1e-3) / 1e9
-        if fused:
-            # one launch = one evaluation: it moves the evaluation's algorithmic bytes (the point records are streamed twice
-            # inside it -- histogram phase and gradient phase -- and counted once)
-            dom, dom_ms_events, launch_bytes = "k_fused", whole_ms, eval_bytes
-        else:
-            dom = "k_spline_hist" if kt["hist"] >= kt["grad"] else "k_spline_grad"
-            dom_ms_events = max(kt["hist"], kt["grad"])
-            # algorithmic bytes ONE launch of a streaming pass moves: 16 B/point + the 8-bit image + the B x B 64-bit histogram
-            launch_bytes = 16 * n_local + scene.width * scene.height + 8 * args.bins * args.bins
+        dom = "k_spline_hist" if kt["hist"] >= kt["grad"] else "k_spline_grad"
+        dom_ms_events = max(kt["hist"], kt["grad"])
+        # algorithmic bytes ONE launch of a streaming pass moves: 16 B/point + the 8-bit image + the B x B 64-bit histogram
+        launch_bytes = 16 * n_local + scene.width * scene.height + 8 * args.bins * args.bins
         dom_ms = ks.get(dom, dom_ms_events)  # rocprof average of this kernel build when committed, else the event-timed one
         kernel_achieved = launch_bytes / (dom_ms * 1e-3) / 1e9
         pmc = _matching_pmc(n_local, scene.width, scene.height, args.bins, args.precision, build)
         pk = pmc.get("kernels", {}) if pmc else {}
         traffic = pk[dom]["hbm_bytes_corrected"] if dom in pk else None
-        route = ["k_fused"] if fused else ["k_spline_hist", "k_entropy", "k_spline_grad"]
+        route = ["k_spline_hist", "k_entropy", "k_spline_grad"]
         eval_traffic = sum(pk[k_]["hbm_bytes_corrected"] for k_ in route) if all(k_ in pk for k_ in route) else None
         # VALU issue roof: wave-instructions the evaluation's kernels issue (PMC SQ_INSTS_VALU of this kernel build)
         # at one quad-cycle (4 clocks) each on 1024 SIMDs -- the roof that actually binds
@@ -356,7 +349,7 @@ def main():
             "kernel_ms_source": (kstats["_file"] + " (rocprofv3 --kernel-trace --stats average, same kernel build)") if dom in ks else "HIP events around the launch, this run (a few us of event markers included)",
             "launch_bytes": launch_bytes,
             "eval_bytes": eval_bytes,
-            "route": "one fused kernel per evaluation" if fused else "three kernels per evaluation",
+            "route": "three kernels per evaluation",
             "kernel_ms_events": {"whole_evaluation": round(whole_ms, 4), "three_kernel_route": {k_: round(v, 4) for k_, v in kt.items()}},
             "kernel_ms_rocprof": {k_: round(v, 4) for k_, v in ks.items()} or None,
             "kernel_build": build,

@@ -134,7 +134,7 @@ __device__ __forceinline__ long long wave_sum(long long v) {
 // Entropy terms t = p log(p + 1e-6) (|t| < 0.37; sum over a distribution <= log(bins^2) < 12) are accumulated as 64-bit
 // FIXED POINT with 50 fractional bits: t + 6 lies in [4, 8), where a double's ulp is 2^-50, so bits(t + 6) - bits(6) is
 // round(t 2^50) -- one fp64 add and one 64-bit integer subtract.  Integer sums do not depend on their order, so every
-// decomposition of the entropy work (k_entropy's column blocks, k_fused's row segments, the shards of a pair spread over
+// decomposition of the entropy work (k_entropy's column blocks, the shards of a pair spread over
 // several GPUs, a multi-pair group) gives the SAME three entropies bit for bit, hence the same NID.  Quantisation: <= 2^-51
 // per term, 65 536 terms -> |dH| < 3e-11 worst case (1e-13 typical) on H ~ 5-10, far inside the 1e-10 parity bar.
 __device__ __forceinline__ long long ent_fixed(double t) { return __double_as_longlong(t + 6.0) - __double_as_longlong(6.0); }
@@ -216,8 +216,9 @@ __device__ __forceinline__ void grad_final_body(const double* partials, int nblo
     for (int k = 0; k < 7; k++) out[1 + k] = g[k];
     if (out_host) {
       for (int k = 0; k < 7; k++) out_host[1 + k] = g[k];
-      // cost / status / inlier count: k_entropy has mirrored them already; in the one-launch evaluation (k_fused) another
-      // workgroup of THIS kernel wrote them to `out` (agent scope, before its ticket) and this is their way to the host --
+      // cost / status / inlier count: k_entropy's own tail has mirrored them already; when the gradient kernel runs the tail
+      // (grad_scalars_from_partials) another workgroup of THIS kernel wrote them to `out` (agent scope, before its ticket)
+      // and this is their way to the host --
       // every host-visible word of an evaluation is then written by one thread, in order, ahead of the tag
       out_host[0] = __hip_atomic_load(&out[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       out_host[8] = __hip_atomic_load(&out[8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -311,12 +312,38 @@ __device__ __forceinline__ void shard_announce(const ShardTable* tab, u64 seq, u
 #endif
 constexpr int kWideThreads = NID_WIDE_THREADS;
 constexpr int kWideShift = 5;
-// The pass as a device function: k_spline_hist runs it as a kernel of its own, k_fused (nid_fused.hpp) as the first phase
-// of the one-launch evaluation.  `smem` = the workgroup's dynamic LDS (tile at its start); kT = threads per workgroup.
-template <int MODEL, typename Rec, typename real, bool WIDE, int kT>
+// Chunks and segments.  A chunk is one workgroup's slice [start, start + count) of the bucketed records; `group` is the
+// column group its first record belongs to.  Since round 4 the chunks of a table are EQUAL slices of the whole record array
+// (nidreg.hip split_even), so a chunk may run across column-group boundaries: the workgroup then works through it segment
+// by segment -- the records of one group each --, flushing (and re-zeroing) its histogram tile, or rebuilding its G tile,
+// at every boundary.  gend[g] = index one past the last record of group g (the groups' end offsets; empty groups repeat the
+// previous value and are skipped).  Everything about a segment is wave-uniform (scalar loads, scalar branches).
+// The segment loop costs registers (the hot loops sit at the 128-VGPR edge of four waves per SIMD) and ~3 VALU instructions
+// per point of re-materialised constants, so every point kernel exists twice: SEG = false is the straight-line kernel of
+// rounds 1-3 for tables whose chunks all lie inside one group (any cloud with equally full columns: the headline), SEG =
+// true the loop; the host picks per table (nidreg.hip).  A chunk holds at most kMaxSegs segments (the gradient kernel
+// stages the G columns of all of them in LDS up front).
+constexpr int kMaxSegs = 4;
+struct Segments {
+  const uint32_t* __restrict__ gend;
+  uint32_t pos, end, g;
+  __device__ __forceinline__ Segments(const uint32_t* __restrict__ gend_, const Chunk& ch) : gend(gend_), pos(ch.start), end(ch.start + ch.count), g(ch.group) {}
+  // records of the current segment: [pos, seg_end())
+  __device__ __forceinline__ uint32_t seg_end() const { return min(end, gend[g]); }
+  // moves to the next segment; false when the chunk is finished
+  __device__ __forceinline__ bool advance(uint32_t seg_end_) {
+    pos = seg_end_;
+    if (pos >= end) return false;
+    do { g++; } while (gend[g] <= pos);  // skip empty groups
+    return true;
+  }
+};
+
+// The pass as a device function.  `smem` = the workgroup's dynamic LDS (tile at its start); kT = threads per workgroup.
+template <int MODEL, typename Rec, typename real, bool WIDE, bool SEG, int kT>
 __device__ __forceinline__ void spline_hist_body(
-  const Rec* __restrict__ pts, const Chunk ch, const uint8_t* __restrict__ img, int pitch, int W, int H, const PoseParams<real>& pose, const CamParams<real>& cam, int B, int GW,
-  int cshift, double dn_scale, u64* __restrict__ hist, unsigned char* smem, bool prio) {
+  const Rec* __restrict__ pts, const Chunk ch, const uint32_t* __restrict__ gend, const uint8_t* __restrict__ img, int pitch, int W, int H, const PoseParams<real>& pose,
+  const CamParams<real>& cam, int B, int GW, int cshift, double dn_scale, u64* __restrict__ hist, unsigned char* smem, bool prio) {
   u64* tile = reinterpret_cast<u64*>(smem);
   if (WIDE) {  // the specialisation's tiling is fixed: compile-time constants instead of three SGPRs
     B = 256;
@@ -341,110 +368,124 @@ __device__ __forceinline__ void spline_hist_body(
   __syncthreads();
 
   const real fW = real(W), fH = real(H);
-  const uint32_t col0 = ch.group * uint32_t(GW);
   const uint32_t lane_copy = uint32_t(tid) & cmask;
   unsigned int inl = 0;
   const BsplineScale KU = bspline_scale(dn_scale);  // uniform: the x-weight polynomial's constants in fixed-point units
-  // record stream: uniform base (SGPR pair) + 32-bit byte offsets per lane
-  const char* rec_base = reinterpret_cast<const char*>(pts + ch.start);
 
-  // One point: floor knot, cubic B-spline weights per axis (x-weights already in fixed-point units), the 4x4 tap
-  // patch of the strip-tiled bin image as two 16-byte loads, 16 ds_add_u64 into the lane-private copy.
-  // K is the uniform constant set when every lane of the wave holds an inlier (the common case after view
-  // culling), a per-lane set zeroed for outliers / padding slots otherwise: the same arithmetic either way, so
-  // the bits a point contributes do not depend on its wave neighbours (tiling independence).
-  auto taps = [&](real uc, real vc, uint32_t bin, const BsplineScale& K) {
-    const int kx = int(uc), ky = int(vc);  // uc, vc >= 0: truncation is the floor knot (nid_cost.hpp:52)
-    double bxs[4];
-    real by[4];
-    // |.|: a projected coordinate of exactly -0.0 passes `>= 0`, and a -0.0 fraction would put a sign bit into a
-    // weight (to_fixed_dn reads bit patterns); the modifier folds into the consuming instructions
-    bspline_scaled(double(m_abs(m_fract(uc))), K, bxs);
-    bspline6<real>(m_abs(m_fract(vc)), by);
-    u64* col = tile + ((((bin - col0) * uint32_t(B)) << cshift) + lane_copy);
-    // padded bin image: tap (a,b) of knot (kx,ky) is padded pixel (kx + a, ky + b) (edge-replicated,
-    // which is the reference's clamp of knots_x / knots_y, nid_cost.hpp:70-73)
-    uint32_t cols[4];  // the two strip loads are issued before the first LDS atomic
-    load_patch(img, pitch, kx, ky, cols);
+  Segments seg(gend, ch);
+  for (;;) {
+    const uint32_t seg_end = SEG ? seg.seg_end() : seg.end;
+    const uint32_t cnt = seg_end - seg.pos;  // >= 1
+    const uint32_t col0 = seg.g * uint32_t(GW);
+    // record stream: uniform base (SGPR pair) + 32-bit byte offsets per lane
+    const char* rec_base = reinterpret_cast<const char*>(pts + seg.pos);
+
+    // One point: floor knot, cubic B-spline weights per axis (x-weights already in fixed-point units), the 4x4 tap
+    // patch of the strip-tiled bin image as two 16-byte loads, 16 ds_add_u64 into the lane-private copy.
+    // K is the uniform constant set when every lane of the wave holds an inlier (the common case after view
+    // culling), a per-lane set zeroed for outliers / padding slots otherwise: the same arithmetic either way, so
+    // the bits a point contributes do not depend on its wave neighbours (tiling independence).
+    auto taps = [&](real uc, real vc, uint32_t bin, const BsplineScale& K) {
+      const int kx = int(uc), ky = int(vc);  // uc, vc >= 0: truncation is the floor knot (nid_cost.hpp:52)
+      double bxs[4];
+      real by[4];
+      // |.|: a projected coordinate of exactly -0.0 passes `>= 0`, and a -0.0 fraction would put a sign bit into a
+      // weight (to_fixed_dn reads bit patterns); the modifier folds into the consuming instructions
+      bspline_scaled(double(m_abs(m_fract(uc))), K, bxs);
+      bspline6<real>(m_abs(m_fract(vc)), by);
+      u64* col = tile + ((((bin - col0) * uint32_t(B)) << cshift) + lane_copy);
+      // padded bin image: tap (a,b) of knot (kx,ky) is padded pixel (kx + a, ky + b) (edge-replicated,
+      // which is the reference's clamp of knots_x / knots_y, nid_cost.hpp:70-73)
+      uint32_t cols[4];  // the two strip loads are issued before the first LDS atomic
+      load_patch(img, pitch, kx, ky, cols);
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
+      for (int b = 0; b < 4; b++) {
 #pragma unroll
-      for (int a = 0; a < 4; a++) {
-        if (WIDE) {
-          typedef __attribute__((address_space(3))) u64 lds_u64_t;
-          const uint32_t addr = __builtin_amdgcn_perm(cols[a], lane_copy << 3, 0x0c0c0000u | (uint32_t(4 + b) << 8));  // [0, 0, byte b of cols[a], copy * 8]
-          __hip_atomic_fetch_add((lds_u64_t*)(uintptr_t)addr, to_fixed_dn(bxs[a], double(by[b])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        } else {
-          const uint32_t r = (cols[a] >> (8 * b)) & 0xffu;
-          atomicAdd(&col[r << cshift], to_fixed_dn(bxs[a], double(by[b])));  // v_mul_f64 + ds_add_u64
+        for (int a = 0; a < 4; a++) {
+          if (WIDE) {
+            typedef __attribute__((address_space(3))) u64 lds_u64_t;
+            const uint32_t addr = __builtin_amdgcn_perm(cols[a], lane_copy << 3, 0x0c0c0000u | (uint32_t(4 + b) << 8));  // [0, 0, byte b of cols[a], copy * 8]
+            __hip_atomic_fetch_add((lds_u64_t*)(uintptr_t)addr, to_fixed_dn(bxs[a], double(by[b])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          } else {
+            const uint32_t r = (cols[a] >> (8 * b)) & 0xffu;
+            atomicAdd(&col[r << cshift], to_fixed_dn(bxs[a], double(by[b])));  // v_mul_f64 + ds_add_u64
+          }
+        }
+      }
+    };
+
+    // kUnroll records per thread are fetched before any of them is processed (memory-level parallelism); the
+    // geometry of all of them comes first, then -- wave-uniform choice -- the tap code with uniform or per-lane
+    // constants.  Both are branch-free per point, so the scheduler interleaves the kUnroll independent points.
+    for (uint32_t base = 0; base < cnt; base += kT * kUnroll) {
+      set_progress_priority(prio, seg.pos - ch.start + base, ch.count);
+      real xs[kUnroll], ys[kUnroll], zs[kUnroll];
+      uint32_t bins_[kUnroll];
+#pragma unroll
+      for (int k = 0; k < kUnroll; k++) {
+        const uint32_t ii = min(base + uint32_t(k) * kT + tid, cnt - 1u);
+        load_rec<real>(reinterpret_cast<const Rec*>(rec_base + size_t(ii * uint32_t(sizeof(Rec)))), xs[k], ys[k], zs[k], bins_[k]);
+      }
+      real us[kUnroll], vs[kUnroll];
+      bool ins[kUnroll];
+      bool all_in = true;
+#pragma unroll
+      for (int k = 0; k < kUnroll; k++) {
+        const bool valid = base + uint32_t(k) * kT + tid < cnt;
+        real cx, cy, cz;
+        transform_fma<real>(pose, xs[k], ys[k], zs[k], cx, cy, cz);
+        project<MODEL, real, real, true>(cam, cx, cy, cz, us[k], vs[k]);
+        // floor(u) in [0,W) and floor(v) in [0,H); NaN / inf / overflow compare false -> outlier
+        // (the reference's int conversion sends those to INT_MIN, nid_cost.hpp:52-58)
+        ins[k] = bool(int(valid) & int(us[k] >= real(0)) & int(us[k] < fW) & int(vs[k] >= real(0)) & int(vs[k] < fH));  // no short circuit: branch-free
+        inl += ins[k] ? 1u : 0u;
+        all_in = bool(int(all_in) & int(ins[k]));
+      }
+      if (__builtin_amdgcn_ballot_w64(!all_in) == 0) {
+#pragma unroll
+        for (int k = 0; k < kUnroll; k++) taps(us[k], vs[k], bins_[k], KU);
+      } else {
+#pragma unroll
+        for (int k = 0; k < kUnroll; k++) {
+          // an outlier (or a slot past the end of the segment) runs the same instructions with its knot at pixel (0,0)
+          // and zeroed constants: it adds exact zeros
+          const bool in = ins[k];
+          BsplineScale KL;
+          KL.k16 = in ? KU.k16 : 0.0;
+          KL.k46 = in ? KU.k46 : 0.0;
+          KL.k05 = in ? KU.k05 : 0.0;
+          KL.k1 = in ? KU.k1 : 0.0;
+          taps(in ? us[k] : real(0), in ? vs[k] : real(0), bins_[k], KL);
         }
       }
     }
-  };
+    const bool more = SEG && seg.pos + cnt < seg.end;  // uniform: another segment follows -> the flush leaves a zeroed tile behind
+    __syncthreads();
 
-  // kUnroll records per thread are fetched before any of them is processed (memory-level parallelism); the
-  // geometry of all of them comes first, then -- wave-uniform choice -- the tap code with uniform or per-lane
-  // constants.  Both are branch-free per point, so the scheduler interleaves the kUnroll independent points.
-  for (uint32_t base = 0; base < ch.count; base += kT * kUnroll) {
-    set_progress_priority(prio, base, ch.count);
-    real xs[kUnroll], ys[kUnroll], zs[kUnroll];
-    uint32_t bins_[kUnroll];
-#pragma unroll
-    for (int k = 0; k < kUnroll; k++) {
-      const uint32_t ii = min(base + uint32_t(k) * kT + tid, ch.count - 1u);
-      load_rec<real>(reinterpret_cast<const Rec*>(rec_base + size_t(ii * uint32_t(sizeof(Rec)))), xs[k], ys[k], zs[k], bins_[k]);
-    }
-    real us[kUnroll], vs[kUnroll];
-    bool ins[kUnroll];
-    bool all_in = true;
-#pragma unroll
-    for (int k = 0; k < kUnroll; k++) {
-      const bool valid = base + uint32_t(k) * kT + tid < ch.count;
-      real cx, cy, cz;
-      transform_fma<real>(pose, xs[k], ys[k], zs[k], cx, cy, cz);
-      project<MODEL, real, real, true>(cam, cx, cy, cz, us[k], vs[k]);
-      // floor(u) in [0,W) and floor(v) in [0,H); NaN / inf / overflow compare false -> outlier
-      // (the reference's int conversion sends those to INT_MIN, nid_cost.hpp:52-58)
-      ins[k] = bool(int(valid) & int(us[k] >= real(0)) & int(us[k] < fW) & int(vs[k] >= real(0)) & int(vs[k] < fH));  // no short circuit: branch-free
-      inl += ins[k] ? 1u : 0u;
-      all_in = bool(int(all_in) & int(ins[k]));
-    }
-    if (__builtin_amdgcn_ballot_w64(!all_in) == 0) {
-#pragma unroll
-      for (int k = 0; k < kUnroll; k++) taps(us[k], vs[k], bins_[k], KU);
-    } else {
-#pragma unroll
-      for (int k = 0; k < kUnroll; k++) {
-        // an outlier (or a slot past the end of the chunk) runs the same instructions with its knot at pixel (0,0)
-        // and zeroed constants: it adds exact zeros
-        const bool in = ins[k];
-        BsplineScale KL;
-        KL.k16 = in ? KU.k16 : 0.0;
-        KL.k46 = in ? KU.k46 : 0.0;
-        KL.k05 = in ? KU.k05 : 0.0;
-        KL.k1 = in ? KU.k1 : 0.0;
-        taps(in ? us[k] : real(0), in ? vs[k] : real(0), bins_[k], KL);
+    // flush the tile: contiguous in the [bin_points][bin_image] device layout
+    u64* dst = hist + size_t(seg.g) * size_t(tile_n);
+    for (int k = tid; k < tile_n; k += kT) {
+      u64 vv = 0;
+      for (uint32_t j = 0; j <= cmask; j++) vv += tile[(uint32_t(k) << cshift) + ((j + uint32_t(k)) & cmask)];  // rotated: conflict-free reads
+      if (more)
+        for (uint32_t j = 0; j <= cmask; j++) tile[(uint32_t(k) << cshift) + ((j + uint32_t(k)) & cmask)] = 0;
+      if (vv) {
+        atomicAdd(&dst[k], vv);
+        atomicAdd(&s_colsum[k / B], vv);
       }
     }
+    __syncthreads();
+    if (tid < GW && s_colsum[tid]) {
+      atomicAdd(&hist[size_t(B) * size_t(B) + kTailWords + col0 + uint32_t(tid)], s_colsum[tid]);
+      if (more) s_colsum[tid] = 0;  // the next flush's LDS adds come after two more barriers
+    }
+    if (!SEG || !seg.advance(seg_end)) break;
   }
 
-  // inlier count: wave-reduce, one LDS add per wave
+  // inlier count: wave-reduce, one LDS add per wave, one global add per workgroup
   const unsigned int winl = wave_sum(inl);
   if ((tid & 63) == 0 && winl) atomicAdd(s_inl, winl);
   __syncthreads();
-
-  // flush the tile: contiguous in the [bin_points][bin_image] device layout
-  u64* dst = hist + size_t(ch.group) * size_t(tile_n);
-  for (int k = tid; k < tile_n; k += kT) {
-    u64 vv = 0;
-    for (uint32_t j = 0; j <= cmask; j++) vv += tile[(uint32_t(k) << cshift) + ((j + uint32_t(k)) & cmask)];  // rotated: conflict-free reads
-    if (vv) {
-      atomicAdd(&dst[k], vv);
-      atomicAdd(&s_colsum[k / B], vv);
-    }
-  }
-  __syncthreads();
-  if (tid < GW && s_colsum[tid]) atomicAdd(&hist[size_t(B) * size_t(B) + kTailWords + col0 + uint32_t(tid)], s_colsum[tid]);
   if (tid == 0 && *s_inl) atomicAdd(&hist[size_t(B) * size_t(B) + kTailInliers], u64(*s_inl));
   stamp_end();
 }
@@ -452,9 +493,13 @@ __device__ __forceinline__ void spline_hist_body(
 // LDS bytes spline_hist_body uses (nidreg.hip sizes lds_hist the same way)
 __host__ __device__ __forceinline__ size_t spline_hist_lds_bytes(int B, int GW, int cshift) { return (size_t(GW) * size_t(B) * 8 << cshift) + size_t(GW) * 8 + 16; }
 
-template <int MODEL, typename Rec, typename real, bool WIDE, bool MULTI>
-__global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_spline_hist(
-  const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint8_t* __restrict__ img, int pitch, int W, int H, PoseParams<real> pose, CamParams<real> cam, int B,
+// waves per SIMD the WIDE kernel is compiled for: two 8-wave workgroups per CU need <= 128 VGPRs.  The straight-line kernels
+// land there by themselves; the looped ones are told to (0-2 spilled registers outside the point loop) -- except the `atan`
+// model, whose Dual3 forward mode holds ~164 either way.
+constexpr int hist_min_waves(int model, bool wide, bool seg, bool rec32) { return (wide && seg && rec32 && model != MODEL_ATAN) ? 4 : 1; }
+template <int MODEL, typename Rec, typename real, bool WIDE, bool MULTI, bool SEG>
+__global__ __launch_bounds__(WIDE ? kWideThreads : kThreads, hist_min_waves(MODEL, WIDE, SEG, sizeof(Rec) == sizeof(Rec32))) void k_spline_hist(
+  const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint32_t* __restrict__ gend, const uint8_t* __restrict__ img, int pitch, int W, int H, PoseParams<real> pose, CamParams<real> cam, int B,
   int GW, int cshift, double dn_scale, u64* __restrict__ hist, int prio, const ShardTable* __restrict__ ann, u64 ann_seq, unsigned int* ann_ticket,
   const MultiEntry* __restrict__ multi, typename multi_dyn_of<MULTI>::type dyn) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -464,11 +509,12 @@ __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_spline_hist(
     const uint32_t pair = ch.pad & 0xffu;  // Chunk::pad = pair | (index of the chunk among its pair's chunks) << 8
     const MultiEntry& e = multi[pair];
     pts = as_global(static_cast<const Rec*>(e.pts));
+    gend = as_global(e.gend);
     img = as_global(e.img);
     hist = as_global(e.hist_buf[dyn.cur[pair]]);
     dn_scale = e.k16;
   }
-  spline_hist_body<MODEL, Rec, real, WIDE, kT>(pts, ch, img, pitch, W, H, pose, cam, B, GW, cshift, dn_scale, hist, smem, prio != 0);
+  spline_hist_body<MODEL, Rec, real, WIDE, SEG, kT>(pts, ch, gend, img, pitch, W, H, pose, cam, B, GW, cshift, dn_scale, hist, smem, prio != 0);
   // a shard of a pair spread over several GPUs: the last workgroup sends this shard's inlier count to every shard
   if (!MULTI && ann && threadIdx.x == 0) shard_announce(ann, ann_seq, ann_ticket, hist + size_t(WIDE ? 256 : B) * size_t(WIDE ? 256 : B) + kTailInliers);
 }
@@ -478,11 +524,11 @@ __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_spline_hist(
 // point, truncating int cast, one count per inlier.  The arithmetic order matches the reference
 // expression tree so that, compiled with -ffp-contract=off, +,-,*,/,sqrt results are bit-identical
 // to the CPU's and the integer histogram is exactly reproducible.
-template <int MODEL, typename Rec, typename real, bool MULTI>
+template <int MODEL, typename Rec, typename real, bool MULTI, bool SEG>
 __global__ __launch_bounds__(kThreads) void k_nearest_hist(
-  const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint8_t* __restrict__ img, int pitch, int W, int H, IsoParams<real> iso, CamParams<real> cam, int B,
-  int GW, int cshift, real cos_fov, u64* __restrict__ hist, const ShardTable* __restrict__ ann, u64 ann_seq, unsigned int* ann_ticket, const MultiEntry* __restrict__ multi,
-  typename multi_dyn_of<MULTI>::type dyn) {
+  const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint32_t* __restrict__ gend, const uint8_t* __restrict__ img, int pitch, int W, int H, IsoParams<real> iso,
+  CamParams<real> cam, int B, int GW, int cshift, real cos_fov, u64* __restrict__ hist, const ShardTable* __restrict__ ann, u64 ann_seq, unsigned int* ann_ticket,
+  const MultiEntry* __restrict__ multi, typename multi_dyn_of<MULTI>::type dyn) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u64* tile = reinterpret_cast<u64*>(smem);
   const int tile_n = GW * B;
@@ -497,6 +543,7 @@ __global__ __launch_bounds__(kThreads) void k_nearest_hist(
     const uint32_t pair = ch.pad & 0xffu;  // Chunk::pad = pair | (index of the chunk among its pair's chunks) << 8
     const MultiEntry& e = multi[pair];
     pts = as_global(static_cast<const Rec*>(e.pts));
+    gend = as_global(e.gend);
     img = as_global(e.img);
     hist = as_global(e.hist_buf[dyn.cur[pair]]);
   }
@@ -506,62 +553,76 @@ __global__ __launch_bounds__(kThreads) void k_nearest_hist(
   __syncthreads();
 
   const real fW = real(W), fH = real(H);
-  const uint32_t col0 = ch.group * uint32_t(GW);
   unsigned int inl = 0;
 
-  // kUnroll records per thread are fetched before any of them is processed: one 16-B load per wave
-  // in flight is latency bound (measured 1.45 TB/s); four keep ~64 KB per CU outstanding
-  // (no progress priority here: this pass is a third of the spline passes' arithmetic per point and lives on memory-level
-  // parallelism -- with it the kernel was 10 % slower on cfg 2, 67.2 -> 73.8 us, profiles/r02g_kernel_gaps.txt)
-  for (uint32_t base = 0; base < ch.count; base += kThreads * kUnroll) {
-    real xs[kUnroll], ys[kUnroll], zs[kUnroll];
-    uint32_t bins_[kUnroll];
+  Segments seg(gend, ch);
+  for (;;) {
+    const uint32_t seg_end = SEG ? seg.seg_end() : seg.end;
+    const uint32_t cnt = seg_end - seg.pos;
+    const uint32_t col0 = seg.g * uint32_t(GW);
+    const Rec* __restrict__ recs = pts + seg.pos;
+    // kUnroll records per thread are fetched before any of them is processed: one 16-B load per wave
+    // in flight is latency bound (measured 1.45 TB/s); four keep ~64 KB per CU outstanding
+    // (no progress priority here: this pass is a third of the spline passes' arithmetic per point and lives on memory-level
+    // parallelism -- with it the kernel was 10 % slower on cfg 2, 67.2 -> 73.8 us, profiles/r02g_kernel_gaps.txt)
+    for (uint32_t base = 0; base < cnt; base += kThreads * kUnroll) {
+      real xs[kUnroll], ys[kUnroll], zs[kUnroll];
+      uint32_t bins_[kUnroll];
 #pragma unroll
-    for (int k = 0; k < kUnroll; k++) {
-      const uint32_t ii = min(base + uint32_t(k) * kThreads + tid, ch.count - 1u);
-      load_rec<real>(pts + ch.start + ii, xs[k], ys[k], zs[k], bins_[k]);
-    }
+      for (int k = 0; k < kUnroll; k++) {
+        const uint32_t ii = min(base + uint32_t(k) * kThreads + tid, cnt - 1u);
+        load_rec<real>(recs + ii, xs[k], ys[k], zs[k], bins_[k]);
+      }
 #pragma unroll
-    for (int k = 0; k < kUnroll; k++) {
-    const uint32_t i = base + uint32_t(k) * kThreads + tid;
-    if (i >= ch.count) break;
-    const real x = xs[k], y = ys[k], z = zs[k];
-    const uint32_t bin = bins_[k];
-    // Eigen 4x4 * (x y z 1): ((m0 x + m1 y) + m2 z) + m3 * 1
-    const real cx = ((iso.m[0] * x + iso.m[1] * y) + iso.m[2] * z) + iso.m[3];
-    const real cy = ((iso.m[4] * x + iso.m[5] * y) + iso.m[6] * z) + iso.m[7];
-    const real cz = ((iso.m[8] * x + iso.m[9] * y) + iso.m[10] * z) + iso.m[11];
-    const real n2 = (cx * cx + cy * cy) + cz * cz;
-    const real zn = n2 > real(0) ? cz / m_sqrt(n2) : cz;
-    const bool in_fov = !(zn < cos_fov);  // out of FoV otherwise (cost_calculator_nid.cpp:32)
-    real u, v;
-    project<MODEL, real, real>(cam, cx, cy, cz, u, v);
-    // trunc(u) in [0,W)  <=>  -1 < u < W ; NaN false (cost_calculator_nid.cpp:37-41)
-    const bool in = in_fov && (u > real(-1)) && (u < fW) && (v > real(-1)) && (v < fH);
-    if (in) {
-      inl++;
-      const int px = int(u), py = int(v);  // truncation toward zero
-      const uint32_t r = load_pixel(img, pitch, px + 1, py + 1);
-      atomicAdd(&tile[((((bin - col0) * uint32_t(B)) + r) << cshift) + (uint32_t(tid) & cmask)], u64(1));
+      for (int k = 0; k < kUnroll; k++) {
+        const uint32_t i = base + uint32_t(k) * kThreads + tid;
+        if (i >= cnt) break;
+        const real x = xs[k], y = ys[k], z = zs[k];
+        const uint32_t bin = bins_[k];
+        // Eigen 4x4 * (x y z 1): ((m0 x + m1 y) + m2 z) + m3 * 1
+        const real cx = ((iso.m[0] * x + iso.m[1] * y) + iso.m[2] * z) + iso.m[3];
+        const real cy = ((iso.m[4] * x + iso.m[5] * y) + iso.m[6] * z) + iso.m[7];
+        const real cz = ((iso.m[8] * x + iso.m[9] * y) + iso.m[10] * z) + iso.m[11];
+        const real n2 = (cx * cx + cy * cy) + cz * cz;
+        const real zn = n2 > real(0) ? cz / m_sqrt(n2) : cz;
+        const bool in_fov = !(zn < cos_fov);  // out of FoV otherwise (cost_calculator_nid.cpp:32)
+        real u, v;
+        project<MODEL, real, real>(cam, cx, cy, cz, u, v);
+        // trunc(u) in [0,W)  <=>  -1 < u < W ; NaN false (cost_calculator_nid.cpp:37-41)
+        const bool in = in_fov && (u > real(-1)) && (u < fW) && (v > real(-1)) && (v < fH);
+        if (in) {
+          inl++;
+          const int px = int(u), py = int(v);  // truncation toward zero
+          const uint32_t r = load_pixel(img, pitch, px + 1, py + 1);
+          atomicAdd(&tile[((((bin - col0) * uint32_t(B)) + r) << cshift) + (uint32_t(tid) & cmask)], u64(1));
+        }
+      }
     }
+    const bool more = SEG && seg.pos + cnt < seg.end;  // another segment follows: the flush leaves a zeroed tile behind
+    __syncthreads();
+
+    u64* dst = hist + size_t(seg.g) * size_t(tile_n);
+    for (int k = tid; k < tile_n; k += kThreads) {
+      u64 vv = 0;
+      for (uint32_t j = 0; j <= cmask; j++) vv += tile[(uint32_t(k) << cshift) + ((j + uint32_t(k)) & cmask)];
+      if (more)
+        for (uint32_t j = 0; j <= cmask; j++) tile[(uint32_t(k) << cshift) + ((j + uint32_t(k)) & cmask)] = 0;
+      if (vv) {
+        atomicAdd(&dst[k], vv);
+        atomicAdd(&s_colsum[k / B], vv);
+      }
     }
+    __syncthreads();
+    if (tid < GW && s_colsum[tid]) {
+      atomicAdd(&hist[size_t(B) * size_t(B) + kTailWords + col0 + uint32_t(tid)], s_colsum[tid]);
+      if (more) s_colsum[tid] = 0;
+    }
+    if (!SEG || !seg.advance(seg_end)) break;
   }
 
   const unsigned int winl = wave_sum(inl);
   if ((tid & 63) == 0 && winl) atomicAdd(s_inl, winl);
   __syncthreads();
-
-  u64* dst = hist + size_t(ch.group) * size_t(tile_n);
-  for (int k = tid; k < tile_n; k += kThreads) {
-    u64 vv = 0;
-    for (uint32_t j = 0; j <= cmask; j++) vv += tile[(uint32_t(k) << cshift) + ((j + uint32_t(k)) & cmask)];
-    if (vv) {
-      atomicAdd(&dst[k], vv);
-      atomicAdd(&s_colsum[k / B], vv);
-    }
-  }
-  __syncthreads();
-  if (tid < GW && s_colsum[tid]) atomicAdd(&hist[size_t(B) * size_t(B) + kTailWords + col0 + uint32_t(tid)], s_colsum[tid]);
   if (tid == 0 && *s_inl) atomicAdd(&hist[size_t(B) * size_t(B) + kTailInliers], u64(*s_inl));
   if (!MULTI && ann && tid == 0) shard_announce(ann, ann_seq, ann_ticket, hist + size_t(B) * size_t(B) + kTailInliers);
 }
@@ -899,38 +960,36 @@ __global__ __launch_bounds__(kThreads) void k_entropy_gather(
 #endif
 // how a tap finds its G value in LDS
 enum { TAP_COPIES = 0,   // gtile[(cell << cshift) + lane copy]: lane-private copies like the histogram tile (several columns per workgroup)
-       TAP_SINGLE = 1,   // one column, ONE copy at LDS address 0: byte address = bin_image << 3 (one SDWA shift)
-       TAP_WIDE = 2 };   // one column, 32 copies at LDS address 0: byte address (bin_image << 8) | (copy << 3) from ONE v_perm_b32
-                         // (k_fused, 512-thread workgroups: the WIDE histogram tile's layout, conflict-free reads)
+       TAP_SINGLE = 1 }; // one column, ONE copy at LDS address 0: byte address = bin_image << 3 (one SDWA shift)
+                         // (a 32-copy conflict-free tile with one v_perm_b32 per tap was measured in round 3: the same loop time)
 
-// The point loop of the pass as a device function (k_spline_grad; third phase of k_fused): accumulates M += gp p^T, gt += gp
-// over the chunk into acc[12].
+// The point loop of the pass over ONE segment of the workgroup's chunk (`cnt` records from `recs`, all of column group
+// col0 / GW, whose G columns sit in gtile): accumulates M += gp p^T, gt += gp into acc[12].  `done` / `total`: the chunk's
+// progress (issue priority).
 template <int MODEL, typename Rec, typename real, int TAP, int kT>
 __device__ __forceinline__ void spline_grad_loop(
-  const Rec* __restrict__ pts, const Chunk ch, const uint8_t* __restrict__ img, int pitch, int W, int H, const PoseParams<real>& pose, const CamParams<real>& cam, int B, int GW,
-  int cshift, const double* gtile, double* acc, bool prio) {
+  const Rec* __restrict__ recs, uint32_t cnt, uint32_t col0, uint32_t done, uint32_t total, const uint8_t* __restrict__ img, int pitch, int W, int H, const PoseParams<real>& pose,
+  const CamParams<real>& cam, int B, int cshift, const double* gtile, double* acc, bool prio) {
   const int tid = threadIdx.x;
   if (TAP == TAP_SINGLE) cshift = 0;
-  if (TAP == TAP_WIDE) cshift = kWideShift;
   const uint32_t cmask = (1u << cshift) - 1u;
   const real fW = real(W), fH = real(H);
-  const uint32_t col0 = ch.group * uint32_t(GW);
   const uint32_t lane_copy = uint32_t(tid) & cmask;
 
-  const char* rec_base = reinterpret_cast<const char*>(pts + ch.start);  // uniform base + 32-bit byte offsets per lane
-  for (uint32_t base = 0; base < ch.count; base += kT * kUnroll) {
-    set_progress_priority(prio, base, ch.count);
+  const char* rec_base = reinterpret_cast<const char*>(recs);  // uniform base + 32-bit byte offsets per lane
+  for (uint32_t base = 0; base < cnt; base += kT * kUnroll) {
+    set_progress_priority(prio, done + base, total);
     real xs[kUnroll], ys[kUnroll], zs[kUnroll];
     uint32_t bins_[kUnroll];
 #pragma unroll
     for (int k = 0; k < kUnroll; k++) {
-      const uint32_t ii = min(base + uint32_t(k) * kT + tid, ch.count - 1u);
+      const uint32_t ii = min(base + uint32_t(k) * kT + tid, cnt - 1u);
       load_rec<real>(reinterpret_cast<const Rec*>(rec_base + size_t(ii * uint32_t(sizeof(Rec)))), xs[k], ys[k], zs[k], bins_[k]);
     }
 #pragma unroll
     for (int k = 0; k < kUnroll; k++) {
       // (a branch-free body like k_spline_hist's was measured 15 % slower here: 173 VGPRs, 2 waves/SIMD)
-      if (base + uint32_t(k) * kT + tid >= ch.count) break;
+      if (base + uint32_t(k) * kT + tid >= cnt) break;
       const real x = xs[k], y = ys[k], z = zs[k];
       real cx, cy, cz;
       transform_fma<real>(pose, x, y, z, cx, cy, cz);
@@ -970,14 +1029,8 @@ __device__ __forceinline__ void spline_grad_loop(
           real sa = real(0), sb = real(0);
 #pragma unroll
           for (int a = 0; a < 4; a++) {
-            real g;
-            if (TAP == TAP_WIDE) {
-              const uint32_t addr = __builtin_amdgcn_perm(cols[a], lane_copy << 3, 0x0c0c0000u | (uint32_t(4 + b) << 8));  // [0, 0, byte b of cols[a], copy * 8]
-              g = real(*(lds_f64_t*)(uintptr_t)addr);
-            } else {
-              const uint32_t r = (cols[a] >> (8 * b)) & 0xffu;
-              g = TAP == TAP_SINGLE ? real(*(lds_f64_t*)(uintptr_t)(r << 3)) : real(gcol[r << cshift]);
-            }
+            const uint32_t r = (cols[a] >> (8 * b)) & 0xffu;
+            const real g = TAP == TAP_SINGLE ? real(*(lds_f64_t*)(uintptr_t)(r << 3)) : real(gcol[r << cshift]);
             sa = fma(g, dbx[a], sa);
             sb = fma(g, bx[a], sb);
           }
@@ -1083,31 +1136,55 @@ __device__ __forceinline__ EntropyScalars grad_scalars_from_partials(const u64* 
   return e;
 }
 
+// The G columns of column group g into the workgroup's LDS tile: G[c][r] = (coefA phi(h[c][r] / S) + coefB phi(q_r)) / 12 --
+// the 1/12 because the tap loop works with 6 b and 2 db/ds (bspline6 / bspline_deriv2) --, every cell in 2^cshift copies.
+// (dst: the tile, or a staging area of the same layout)
+__device__ __forceinline__ void build_gtile(const u64* __restrict__ hist, uint32_t g, int B, int GW, int cshift, double scale, double coefA, double coefB, const double* phi_q, double* gtile) {
+  const int tid = threadIdx.x;
+  const uint32_t cmask = (1u << cshift) - 1u;
+  const int tile_n = GW * B;
+  const u64* src = hist + size_t(g) * size_t(tile_n);
+  const int ncols = min(GW, B - int(g) * GW);
+  const int n = ncols * B;
+  for (int k = tid; k < n; k += kThreads) {
+    const double p = double(src[k]) * scale;
+    const double gval = (coefA * (log(p + 1e-6) + p / (p + 1e-6)) + coefB * phi_q[k % B]) * (1.0 / 12.0);
+    for (uint32_t j = 0; j <= cmask; j++) gtile[(uint32_t(k) << cshift) + ((j + uint32_t(k)) & cmask)] = gval;
+  }
+}
 // the `atan` model keeps the generic Dual3 forward mode and sits at the edge of three waves per SIMD (164-170 VGPRs; the
 // allocation granule is 8): ask for three explicitly
-constexpr int grad_min_waves(int model) { return model == MODEL_ATAN ? 3 : NID_GRAD_MIN_WAVES; }
-template <int MODEL, typename Rec, typename real, bool GW1, bool MULTI>
-__global__ __launch_bounds__(kThreads, grad_min_waves(MODEL)) void k_spline_grad(
-  const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint8_t* __restrict__ img, int pitch, int W, int H, PoseParams<real> pose, CamParams<real> cam, int B,
-  int GW, int cshift, double inv_unit, const u64* __restrict__ hist, const double* __restrict__ phi_q, const EntropyScalars* __restrict__ scal, GradTail gt, double* partials,
-  double qx, double qy, double qz, double qw, double* out, double* out_host, double tag, unsigned int* counter, int prio, const MultiEntry* __restrict__ multi,
-  typename multi_dyn_of<MULTI>::type dyn) {
+// (the looped instantiations on float records are told to stay at four -- they land at 126-130 by themselves)
+constexpr int grad_min_waves(int model, bool seg = false, bool rec32 = false) { return model == MODEL_ATAN ? 3 : ((seg && rec32) ? 4 : NID_GRAD_MIN_WAVES); }
+// LDS of the gradient kernel: G tile (one copy of one column when GW = 1, else 2^cshift copies of GW columns), reduction scratch,
+// phi(q_r), flag; SEG (GW = 1 only): kMaxSegs - 1 staged G columns behind them
+__host__ __device__ __forceinline__ size_t spline_grad_lds_bytes(int B, int GW, int cshift, bool seg) {
+  return (GW == 1 ? size_t(B) * 8 : (size_t(GW) * size_t(B) * 8 << cshift)) + size_t(kWaves) * 12 * 8 + 256 * 8 + 16 + (seg && GW == 1 ? size_t(kMaxSegs - 1) * size_t(B) * 8 : 0);
+}
+template <int MODEL, typename Rec, typename real, bool GW1, bool MULTI, bool SEG>
+__global__ __launch_bounds__(kThreads, grad_min_waves(MODEL, SEG, sizeof(Rec) == sizeof(Rec32))) void k_spline_grad(
+  const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint32_t* __restrict__ gend, const uint8_t* __restrict__ img, int pitch, int W, int H, PoseParams<real> pose,
+  CamParams<real> cam, int B, int GW, int cshift, double inv_unit, const u64* __restrict__ hist, const double* __restrict__ phi_q, const EntropyScalars* __restrict__ scal, GradTail gt,
+  double* partials, unsigned int nslots, double qx, double qy, double qz, double qw, double* out, double* out_host, double tag, unsigned int* counter, int prio,
+  const MultiEntry* __restrict__ multi, typename multi_dyn_of<MULTI>::type dyn) {
+  static_assert(!SEG || GW1, "a chunk runs across column groups only in the single-column kernels (the host builds one-segment tables otherwise)");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* gtile = reinterpret_cast<double*>(smem);
   const int tile_n = GW * B;
   if (GW1) cshift = 0;
-  const uint32_t cmask = (1u << cshift) - 1u;  // G is replicated like the histogram tile: lane-private copies, conflict-free ds_read_b64
   double* s_red = gtile + (tile_n << cshift);
   double* s_phi = s_red + kWaves * 12;  // [256] phi(q_r) when this kernel runs the entropy tail itself
   int* s_flag = reinterpret_cast<int*>(s_phi + 256);
+  double* s_stage = reinterpret_cast<double*>(s_flag + 4);  // SEG: [kMaxSegs - 1][B] G columns of the chunk's later segments
 
   const int tid = threadIdx.x;
   const Chunk ch = chunks[blockIdx.x];
-  unsigned int my_block = blockIdx.x, my_blocks = gridDim.x;  // this workgroup's slot among its pair's partials
+  unsigned int my_block = blockIdx.x, my_blocks = gridDim.x;
   if constexpr (MULTI) {
-    const uint32_t pair = ch.pad & 0xffu;  // Chunk::pad = pair | (index of the chunk among its pair's chunks) << 8
+    const uint32_t pair = ch.pad & 0xffu;  // Chunk::pad = pair | (first gradient-partial slot of the chunk among its pair's) << 8
     const MultiEntry& e = multi[pair];
     pts = as_global(static_cast<const Rec*>(e.pts));
+    gend = as_global(e.gend);
     img = as_global(e.img);
     hist = as_global(e.hist_buf[dyn.cur[pair]]);
     inv_unit = e.inv_unit;
@@ -1118,8 +1195,9 @@ __global__ __launch_bounds__(kThreads, grad_min_waves(MODEL)) void k_spline_grad
     out_host = as_global(e.out_host);
     tag = dyn.tag[pair];
     counter = as_global(e.counters) + 1;
-    my_block = ch.pad >> 8;
+    my_block = ch.pad >> 8;  // (only its being 0 matters: the pair's first chunk publishes the marginals)
     my_blocks = unsigned(e.nchunks);
+    nslots = unsigned(e.nslots);
     gt.phi_q = as_global(e.phi_q);
     gt.hist_image = as_global(e.hist_image);
     gt.hist_points = as_global(e.hist_points);
@@ -1130,29 +1208,46 @@ __global__ __launch_bounds__(kThreads, grad_min_waves(MODEL)) void k_spline_grad
     if (gt.from_partials) {
       const EntropyScalars es = grad_scalars_from_partials<kThreads>(hist, B, inv_unit, gt, s_phi, reinterpret_cast<long long*>(s_red), my_block == 0, out);
       coefA = es.coefA, coefB = es.coefB, S = es.S;
-      phi_q = s_phi;  // LDS through a generic pointer: B reads per workgroup
+      phi_q = s_phi;  // LDS through a generic pointer: B reads per tile
     } else {
       coefA = scal->coefA, coefB = scal->coefB, S = scal->S;
     }
     const double scale = inv_unit / S;
-    const u64* src = hist + size_t(ch.group) * size_t(tile_n);
-    const int ncols = min(GW, B - int(ch.group) * GW);
-    const int n = ncols * B;
-    for (int k = tid; k < n; k += kThreads) {
-      const double p = double(src[k]) * scale;
-      // times 1/12: the tap loop below works with 6 b and 2 db/ds (bspline6 / bspline_deriv2)
-      const double gval = (coefA * (log(p + 1e-6) + p / (p + 1e-6)) + coefB * phi_q[k % B]) * (1.0 / 12.0);
-      for (uint32_t j = 0; j <= cmask; j++) gtile[(uint32_t(k) << cshift) + ((j + uint32_t(k)) & cmask)] = gval;
+    // The G column(s) of EVERY segment of the chunk are built here, before the point loops: the first one in place, the others
+    // into the staging area, from where a boundary costs one LDS copy.  (Rebuilding inside the segment loop let the compiler
+    // hoist the logarithm's constants out of that loop and keep them through the point loop: 167 VGPRs; a call that is not
+    // inlined pinned the loop's values to the callee-saved registers: 145.)
+    Segments sg(gend, ch);
+    build_gtile(hist, sg.g, B, GW, cshift, scale, coefA, coefB, phi_q, gtile);
+    if constexpr (SEG) {
+      for (int s = 0; s < kMaxSegs - 1 && sg.advance(sg.seg_end()); s++) build_gtile(hist, sg.g, B, 1, 0, scale, coefA, coefB, phi_q, s_stage + s * B);
     }
   }
   __syncthreads();
 
-  double acc[12];
+  // One 12-double partial PER SEGMENT (slot = the chunk's first slot, Chunk::pad >> 8, + the segment's ordinal): the final
+  // reduction sums the slots in table order -- a fixed order, run to run.
+  unsigned int slot = SEG || MULTI ? ch.pad >> 8 : blockIdx.x;
+  Segments seg(gend, ch);
+  for (int s = 0;; s++) {
+    double acc[12];
 #pragma unroll
-  for (int k = 0; k < 12; k++) acc[k] = 0.0;
-  spline_grad_loop<MODEL, Rec, real, GW1 ? TAP_SINGLE : TAP_COPIES, kThreads>(pts, ch, img, pitch, W, H, pose, cam, B, GW, cshift, gtile, acc, prio != 0);
-  grad_reduce_store<kThreads>(acc, s_red, partials, my_block, my_blocks);
-  if (last_workgroup_arrives<true>(counter, my_blocks, s_flag)) grad_final_body<kThreads>(partials, int(my_blocks), qx, qy, qz, qw, out, out_host, tag, s_red);
+    for (int k = 0; k < 12; k++) {
+      double zero = 0.0;
+      if (SEG) asm volatile("" : "+v"(zero));  // twelve scalars: as a zero VECTOR the initialisation took a 32-register tuple at the top of the loop
+      acc[k] = zero;
+    }
+    const uint32_t seg_end = SEG ? seg.seg_end() : seg.end;
+    spline_grad_loop<MODEL, Rec, real, GW1 ? TAP_SINGLE : TAP_COPIES, kThreads>(pts + seg.pos, seg_end - seg.pos, seg.g * uint32_t(GW), seg.pos - ch.start, ch.count, img, pitch, W, H, pose,
+                                                                               cam, B, cshift, gtile, acc, prio != 0);
+    grad_reduce_store<kThreads>(acc, s_red, partials, slot, nslots);
+    if (!SEG || !seg.advance(seg_end)) break;
+    slot++;
+    __syncthreads();  // every wave has left the point loop (and s_red) before the tile changes
+    for (int k = tid; k < B; k += kThreads) gtile[k] = s_stage[s * B + k];
+    __syncthreads();
+  }
+  if (last_workgroup_arrives<true>(counter, my_blocks, s_flag)) grad_final_body<kThreads>(partials, int(nslots), qx, qy, qz, qw, out, out_host, tag, s_red);
 }
 
 #ifdef NID_COMMON_KERNELS

@@ -14,11 +14,6 @@ template <> hipError_t launch_spline_grad<float>(const PassArgs& a) {
   if (a.rec64) return hipErrorInvalidValue;
   return launch_spline_grad_rec<float, Rec32>(a);
 }
-template <> hipError_t launch_fused<float>(const PassArgs& a) {
-  if (a.nchunks == 0 || a.rec64) return hipErrorInvalidValue;
-  return launch_fused_rec<float, Rec32>(a);
-}
-template <> int occupancy_fused<float>(const PassArgs& a) { return a.rec64 ? 0 : occupancy_fused_rec<float, Rec32>(a); }
 template <> int occupancy_spline_hist<float>(const PassArgs& a) { return a.rec64 ? 0 : occupancy_spline_hist_rec<float, Rec32>(a); }
 template <> int occupancy_spline_grad<float>(const PassArgs& a) { return a.rec64 ? 0 : occupancy_spline_grad_rec<float, Rec32>(a); }
 template <> hipError_t launch_nearest_hist<float>(const PassArgs& a) {

@@ -13,11 +13,6 @@ template <> hipError_t launch_spline_grad<double>(const PassArgs& a) {
   if (a.nchunks == 0) return hipSuccess;
   return a.rec64 ? launch_spline_grad_rec<double, Rec64>(a) : launch_spline_grad_rec<double, Rec32>(a);
 }
-template <> hipError_t launch_fused<double>(const PassArgs& a) {
-  if (a.nchunks == 0) return hipErrorInvalidValue;
-  return a.rec64 ? launch_fused_rec<double, Rec64>(a) : launch_fused_rec<double, Rec32>(a);
-}
-template <> int occupancy_fused<double>(const PassArgs& a) { return a.rec64 ? occupancy_fused_rec<double, Rec64>(a) : occupancy_fused_rec<double, Rec32>(a); }
 template <> int occupancy_spline_hist<double>(const PassArgs& a) { return a.rec64 ? occupancy_spline_hist_rec<double, Rec64>(a) : occupancy_spline_hist_rec<double, Rec32>(a); }
 template <> int occupancy_spline_grad<double>(const PassArgs& a) { return a.rec64 ? occupancy_spline_grad_rec<double, Rec64>(a) : occupancy_spline_grad_rec<double, Rec32>(a); }
 template <> hipError_t launch_project<double>(int model, const double* intr, const double* dist, const double* p3, long long n, double* uv, double* jac, hipStream_t stream) {
@@ -33,9 +28,3 @@ template <> hipError_t launch_project<double>(int model, const double* intr, con
 
 }  // namespace nidreg
 
-#ifdef NID_FUSED_STAMP
-// development aid: per-workgroup phase stamps of the most recent k_fused launch of this translation unit's instantiations
-extern "C" int nidreg_debug_fused_stamps(unsigned long long* out, int words) {
-  return int(hipMemcpyFromSymbol(out, HIP_SYMBOL(nidreg::g_fused_stamp), size_t(words) * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost));
-}
-#endif

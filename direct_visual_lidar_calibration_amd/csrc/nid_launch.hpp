@@ -24,6 +24,9 @@ struct PassArgs {
   const void* pts;
   const Chunk* chunks;
   int nchunks;
+  int nslots;  // segments of the gradient pass's table: one 12-double partial each
+  int seg;     // the table of THIS launch has chunks that run across column groups: the looped (SEG) kernel instantiations
+  const uint32_t* gend;  // end offsets of the column groups among the records (a chunk may run across group boundaries)
   const uint8_t* img;  // padded, edge-replicated bin image
   int pitch, W, H, B, GW, cshift;
   int wide;  // SPLINE histogram pass: the 512-thread / 32-copy single-column specialisation (B = 256, GW = 1)
@@ -57,22 +60,11 @@ struct PassArgs {
   EntropyScalars* gt_scal;
   int gt_from_partials;
   int prio;  // progress priority (s_setprio) in the spline passes: set when the evaluation has its device to itself
-  // the one-launch evaluation (k_fused, nid_fused.hpp); chunks / nchunks = the histogram pass's table
-  const void* fused_static;  // device FusedStatic of the handle
-  int hist_cur;              // index of the histogram buffer this evaluation accumulates into
-  unsigned int* barrier;
-  unsigned int bar_base;
-  unsigned int* abort_flag;
-  unsigned long long timeout_ticks;
-  int want_grad;
-  size_t lds_fused;
 };
 
 template <typename real> hipError_t launch_spline_hist(const PassArgs& a);
 template <typename real> hipError_t launch_spline_grad(const PassArgs& a);
 template <typename real> hipError_t launch_nearest_hist(const PassArgs& a);
-template <typename real> hipError_t launch_fused(const PassArgs& a);
-template <typename real> int occupancy_fused(const PassArgs& a);
 // workgroups of the selected kernel instantiation (model, record type, tiling) that fit on one CU at once
 // (hipOccupancyMaxActiveBlocksPerMultiprocessor; 0 on error): a pass gets exactly one round of co-resident workgroups
 template <typename real> int occupancy_spline_hist(const PassArgs& a);

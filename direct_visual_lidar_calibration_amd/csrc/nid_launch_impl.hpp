@@ -5,7 +5,6 @@
 #include <vector>
 
 #include "nid_kernels.hpp"
-#include "nid_fused.hpp"
 #include "nid_launch.hpp"
 
 namespace nidreg {
@@ -65,28 +64,41 @@ template <typename real, typename Rec>
 static hipError_t launch_spline_hist_rec(const PassArgs& a) {
   const PoseParams<real> pose = make_pose<real>(a);
   const CamParams<real> cam = make_cam<real>(a.intr, a.dist);
-#define NID_LAUNCH_W(M, WIDE, THREADS)                                                                                                                 \
+  // SEG: the table has chunks that run across column-group boundaries (nid_kernels.hpp Segments)
+#define NID_LAUNCH_W(M, WIDE, THREADS, SEG)                                                                                                            \
   if (a.multi) {                                                                                                                                       \
-    auto k = k_spline_hist<M, Rec, real, WIDE, true>;                                                                                                  \
+    auto k = k_spline_hist<M, Rec, real, WIDE, true, SEG>;                                                                                             \
     hipError_t e = ensure_lds(k, a.lds_hist);                                                                                                          \
     if (e != hipSuccess) return e;                                                                                                                     \
-    hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(THREADS), a.lds_hist, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, pose, cam, \
-                       a.B, a.GW, a.cshift, a.magic, a.hist, a.prio, a.ann, a.ann_seq, a.ann_ticket, a.multi, a.dyn);                                                                           \
+    hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(THREADS), a.lds_hist, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.gend, a.img, a.pitch, a.W, a.H, pose, \
+                       cam, a.B, a.GW, a.cshift, a.magic, a.hist, a.prio, a.ann, a.ann_seq, a.ann_ticket, a.multi, a.dyn);                             \
   } else {                                                                                                                                             \
-    auto k = k_spline_hist<M, Rec, real, WIDE, false>;                                                                                                 \
+    auto k = k_spline_hist<M, Rec, real, WIDE, false, SEG>;                                                                                            \
     hipError_t e = ensure_lds(k, a.lds_hist);                                                                                                          \
     if (e != hipSuccess) return e;                                                                                                                     \
-    hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(THREADS), a.lds_hist, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, pose, cam, \
-                       a.B, a.GW, a.cshift, a.magic, a.hist, a.prio, a.ann, a.ann_seq, a.ann_ticket, a.multi, NoMultiDyn());                                                                    \
+    hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(THREADS), a.lds_hist, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.gend, a.img, a.pitch, a.W, a.H, pose, \
+                       cam, a.B, a.GW, a.cshift, a.magic, a.hist, a.prio, a.ann, a.ann_seq, a.ann_ticket, a.multi, NoMultiDyn());                      \
   }
   if (a.wide) {  // B = 256, GW = 1, 32 copies, 512 threads (see k_spline_hist)
-#define NID_LAUNCH(M) NID_LAUNCH_W(M, true, kWideThreads)
-    NID_MODEL_SWITCH(NID_LAUNCH)
+    if (a.seg) {
+#define NID_LAUNCH(M) NID_LAUNCH_W(M, true, kWideThreads, true)
+      NID_MODEL_SWITCH(NID_LAUNCH)
 #undef NID_LAUNCH
+    } else {
+#define NID_LAUNCH(M) NID_LAUNCH_W(M, true, kWideThreads, false)
+      NID_MODEL_SWITCH(NID_LAUNCH)
+#undef NID_LAUNCH
+    }
   } else {
-#define NID_LAUNCH(M) NID_LAUNCH_W(M, false, kThreads)
-    NID_MODEL_SWITCH(NID_LAUNCH)
+    if (a.seg) {
+#define NID_LAUNCH(M) NID_LAUNCH_W(M, false, kThreads, true)
+      NID_MODEL_SWITCH(NID_LAUNCH)
 #undef NID_LAUNCH
+    } else {
+#define NID_LAUNCH(M) NID_LAUNCH_W(M, false, kThreads, false)
+      NID_MODEL_SWITCH(NID_LAUNCH)
+#undef NID_LAUNCH
+    }
   }
 #undef NID_LAUNCH_W
   return hipGetLastError();
@@ -102,27 +114,35 @@ static hipError_t launch_spline_grad_rec(const PassArgs& a) {
   gt.hist_points = a.gt_hist_points;
   gt.scal = a.gt_scal;
   gt.from_partials = a.gt_from_partials;
-#define NID_LAUNCH_G(M, GW1)                                                                                                                           \
+  if (a.seg && a.GW != 1) return hipErrorInvalidValue;  // multi-segment tables are built for the single-column kernels only
+#define NID_LAUNCH_G(M, GW1, SEG)                                                                                                                      \
   if (a.multi) {                                                                                                                                       \
-    auto k = k_spline_grad<M, Rec, real, GW1, true>;                                                                                                   \
+    auto k = k_spline_grad<M, Rec, real, GW1, true, SEG>;                                                                                              \
     hipError_t e = ensure_lds(k, a.lds_grad);                                                                                                          \
     if (e != hipSuccess) return e;                                                                                                                     \
-    hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(kThreads), a.lds_grad, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, pose, cam, \
-                       a.B, a.GW, a.cshift, a.inv_unit, a.hist, a.phi_q, a.scal, gt, a.partials, a.q[0], a.q[1], a.q[2], a.q[3], a.out, a.out_host, a.tag, a.counter, a.prio, a.multi, a.dyn); \
+    hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(kThreads), a.lds_grad, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.gend, a.img, a.pitch, a.W, a.H, pose, \
+                       cam, a.B, a.GW, a.cshift, a.inv_unit, a.hist, a.phi_q, a.scal, gt, a.partials, unsigned(a.nslots), a.q[0], a.q[1], a.q[2], a.q[3], a.out, a.out_host, a.tag, \
+                       a.counter, a.prio, a.multi, a.dyn);                                                                                             \
   } else {                                                                                                                                             \
-    auto k = k_spline_grad<M, Rec, real, GW1, false>;                                                                                                  \
+    auto k = k_spline_grad<M, Rec, real, GW1, false, SEG>;                                                                                             \
     hipError_t e = ensure_lds(k, a.lds_grad);                                                                                                          \
     if (e != hipSuccess) return e;                                                                                                                     \
-    hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(kThreads), a.lds_grad, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, pose, cam, \
-                       a.B, a.GW, a.cshift, a.inv_unit, a.hist, a.phi_q, a.scal, gt, a.partials, a.q[0], a.q[1], a.q[2], a.q[3], a.out, a.out_host, a.tag, a.counter, a.prio, a.multi, \
-                       NoMultiDyn());                                                                                                                  \
+    hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(kThreads), a.lds_grad, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.gend, a.img, a.pitch, a.W, a.H, pose, \
+                       cam, a.B, a.GW, a.cshift, a.inv_unit, a.hist, a.phi_q, a.scal, gt, a.partials, unsigned(a.nslots), a.q[0], a.q[1], a.q[2], a.q[3], a.out, a.out_host, a.tag, \
+                       a.counter, a.prio, a.multi, NoMultiDyn());                                                                                      \
   }
   if (a.GW == 1) {
-#define NID_LAUNCH(M) NID_LAUNCH_G(M, true)
-    NID_MODEL_SWITCH(NID_LAUNCH)
+    if (a.seg) {
+#define NID_LAUNCH(M) NID_LAUNCH_G(M, true, true)
+      NID_MODEL_SWITCH(NID_LAUNCH)
 #undef NID_LAUNCH
+    } else {
+#define NID_LAUNCH(M) NID_LAUNCH_G(M, true, false)
+      NID_MODEL_SWITCH(NID_LAUNCH)
+#undef NID_LAUNCH
+    }
   } else {
-#define NID_LAUNCH(M) NID_LAUNCH_G(M, false)
+#define NID_LAUNCH(M) NID_LAUNCH_G(M, false, false)
     NID_MODEL_SWITCH(NID_LAUNCH)
 #undef NID_LAUNCH
   }
@@ -135,7 +155,7 @@ static int occupancy_spline_hist_rec(const PassArgs& a) {
   int n = 0;
 #define NID_OCC_W(M, WIDE, THREADS)                                                                                                   \
   {                                                                                                                                   \
-    auto k = k_spline_hist<M, Rec, real, WIDE, false>;                                                                                \
+    auto k = k_spline_hist<M, Rec, real, WIDE, false, false>;                                                                         \
     if (ensure_lds(k, a.lds_hist) != hipSuccess) return 0;                                                                            \
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(k), THREADS, a.lds_hist) != hipSuccess) n = 0; \
   }
@@ -173,7 +193,7 @@ static int occupancy_spline_grad_rec(const PassArgs& a) {
   int n = 0;
 #define NID_OCC_G(M, GW1)                                                                                                             \
   {                                                                                                                                   \
-    auto k = k_spline_grad<M, Rec, real, GW1, false>;                                                                                 \
+    auto k = k_spline_grad<M, Rec, real, GW1, false, false>;                                                                          \
     if (ensure_lds(k, a.lds_grad) != hipSuccess) return 0;                                                                            \
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(k), kThreads, a.lds_grad) != hipSuccess) n = 0; \
   }
@@ -206,116 +226,34 @@ static int occupancy_spline_grad_rec(const PassArgs& a) {
   return n;
 }
 
-static FusedArgs make_fused_args(const PassArgs& a) {
-  FusedArgs f;
-  f.pts = a.pts;
-  f.chunks = a.chunks;
-  f.img = a.img;
-  f.pitch = a.pitch;
-  f.W = a.W;
-  f.H = a.H;
-  f.B = a.B;
-  f.GW = a.GW;
-  f.cshift = a.cshift;
-  f.dn_scale = a.magic;
-  f.inv_unit = a.inv_unit;
-  f.hist = a.hist;
-  f.barrier = a.barrier;
-  f.bar_base = a.bar_base;
-  f.abort_flag = a.abort_flag;
-  f.timeout_ticks = a.timeout_ticks;
-  f.st = static_cast<const FusedStatic*>(a.fused_static);
-  for (int k = 0; k < 4; k++) f.q[k] = a.q[k];
-  f.tag = a.tag;
-  f.cur = a.hist_cur;
-  f.want_grad = a.want_grad;
-  f.prio = a.prio;
-  return f;
-}
-
-template <typename real, typename Rec>
-static hipError_t launch_fused_rec(const PassArgs& a) {
-  const PoseParams<real> pose = make_pose<real>(a);
-  const CamParams<real> cam = make_cam<real>(a.intr, a.dist);
-  const FusedArgs f = make_fused_args(a);
-#define NID_LAUNCH_F(M, WIDE, THREADS)                                                        \
-  {                                                                                           \
-    auto k = k_fused<M, Rec, real, WIDE>;                                                     \
-    hipError_t e = ensure_lds(k, a.lds_fused);                                                \
-    if (e != hipSuccess) return e;                                                            \
-    hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(THREADS), a.lds_fused, a.stream, pose, cam, f); \
-  }
-  if (a.wide) {
-#define NID_LAUNCH(M) NID_LAUNCH_F(M, true, kWideThreads)
-    NID_MODEL_SWITCH(NID_LAUNCH)
-#undef NID_LAUNCH
-  } else {
-#define NID_LAUNCH(M) NID_LAUNCH_F(M, false, kThreads)
-    NID_MODEL_SWITCH(NID_LAUNCH)
-#undef NID_LAUNCH
-  }
-#undef NID_LAUNCH_F
-  return hipGetLastError();
-}
-
-template <typename real, typename Rec>
-static int occupancy_fused_rec(const PassArgs& a) {
-  int n = 0;
-#define NID_OCC_F(M, WIDE, THREADS)                                                                                                    \
-  {                                                                                                                                    \
-    auto k = k_fused<M, Rec, real, WIDE>;                                                                                              \
-    if (ensure_lds(k, a.lds_fused) != hipSuccess) return 0;                                                                            \
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(k), THREADS, a.lds_fused) != hipSuccess) n = 0; \
-  }
-  if (a.wide) {
-#define NID_LAUNCH(M) NID_OCC_F(M, true, kWideThreads)
-    switch (a.model) {
-      case MODEL_PLUMB_BOB: NID_LAUNCH(MODEL_PLUMB_BOB); break;
-      case MODEL_FISHEYE: NID_LAUNCH(MODEL_FISHEYE); break;
-      case MODEL_OMNIDIR: NID_LAUNCH(MODEL_OMNIDIR); break;
-      case MODEL_EQUIRECT: NID_LAUNCH(MODEL_EQUIRECT); break;
-      case MODEL_ATAN: NID_LAUNCH(MODEL_ATAN); break;
-      case MODEL_RATIONAL: NID_LAUNCH(MODEL_RATIONAL); break;
-      default: return 0;
-    }
-#undef NID_LAUNCH
-  } else {
-#define NID_LAUNCH(M) NID_OCC_F(M, false, kThreads)
-    switch (a.model) {
-      case MODEL_PLUMB_BOB: NID_LAUNCH(MODEL_PLUMB_BOB); break;
-      case MODEL_FISHEYE: NID_LAUNCH(MODEL_FISHEYE); break;
-      case MODEL_OMNIDIR: NID_LAUNCH(MODEL_OMNIDIR); break;
-      case MODEL_EQUIRECT: NID_LAUNCH(MODEL_EQUIRECT); break;
-      case MODEL_ATAN: NID_LAUNCH(MODEL_ATAN); break;
-      case MODEL_RATIONAL: NID_LAUNCH(MODEL_RATIONAL); break;
-      default: return 0;
-    }
-#undef NID_LAUNCH
-  }
-#undef NID_OCC_F
-  return n;
-}
-
 template <typename real, typename Rec>
 static hipError_t launch_nearest_hist_rec(const PassArgs& a) {
   const IsoParams<real> iso = make_iso<real>(a);
   const CamParams<real> cam = make_cam<real>(a.intr, a.dist);
-#define NID_LAUNCH(M)                                                                                                                                  \
+#define NID_LAUNCH_N(M, SEG)                                                                                                                           \
   if (a.multi) {                                                                                                                                       \
-    auto k = k_nearest_hist<M, Rec, real, true>;                                                                                                       \
+    auto k = k_nearest_hist<M, Rec, real, true, SEG>;                                                                                                       \
     hipError_t e = ensure_lds(k, a.lds_hist);                                                                                                          \
     if (e != hipSuccess) return e;                                                                                                                     \
-    hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(kThreads), a.lds_hist, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, iso, cam,  \
+    hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(kThreads), a.lds_hist, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.gend, a.img, a.pitch, a.W, a.H, iso, cam,  \
                        a.B, a.GW, a.cshift, real(a.cos_fov), a.hist, a.ann, a.ann_seq, a.ann_ticket, a.multi, a.dyn);                                                                   \
   } else {                                                                                                                                             \
-    auto k = k_nearest_hist<M, Rec, real, false>;                                                                                                      \
+    auto k = k_nearest_hist<M, Rec, real, false, SEG>;                                                                                                      \
     hipError_t e = ensure_lds(k, a.lds_hist);                                                                                                          \
     if (e != hipSuccess) return e;                                                                                                                     \
-    hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(kThreads), a.lds_hist, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.img, a.pitch, a.W, a.H, iso, cam,  \
+    hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(kThreads), a.lds_hist, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.gend, a.img, a.pitch, a.W, a.H, iso, cam,  \
                        a.B, a.GW, a.cshift, real(a.cos_fov), a.hist, a.ann, a.ann_seq, a.ann_ticket, a.multi, NoMultiDyn());                                                            \
   }
-  NID_MODEL_SWITCH(NID_LAUNCH)
+  if (a.seg) {
+#define NID_LAUNCH(M) NID_LAUNCH_N(M, true)
+    NID_MODEL_SWITCH(NID_LAUNCH)
 #undef NID_LAUNCH
+  } else {
+#define NID_LAUNCH(M) NID_LAUNCH_N(M, false)
+    NID_MODEL_SWITCH(NID_LAUNCH)
+#undef NID_LAUNCH
+  }
+#undef NID_LAUNCH_N
   return hipGetLastError();
 }
 

@@ -11,12 +11,13 @@ struct EntropyScalars;
 
 // MultiNIDCost on one GPU (visual_camera_calibration.cpp:141-178: the same pose for every pair): ONE grid per pass over
 // the chunks of ALL pairs instead of three launches per pair.  Chunk::pad carries the pair's index into this table (low 8
-// bits; above them the chunk's index among its pair's chunks: its slot in the pair's gradient partials) (device
+// bits; above them the first of the chunk's slots in the pair's gradient partials, one per segment) (device
 // memory, built once per set of handles); what changes per evaluation -- which of the two histogram buffers is current,
 // the completion tag -- travels by value (MultiDyn).  multi == nullptr: the single-pair launch, unchanged.
 constexpr int kMaxMulti = 16;
 struct MultiEntry {
   const void* pts;
+  const uint32_t* gend;  // end offsets of the pair's column groups among its records (nid_kernels.hpp Segments)
   const uint8_t* img;
   u64* hist_buf[2];
   double k16;       // U/36 as a subnormal double (bspline_scale)
@@ -32,8 +33,8 @@ struct MultiEntry {
   double* out_host;
   unsigned int* counters;  // [0] entropy ticket, [1] gradient ticket
   long long zero_words;
-  int reserved0;
-  int nchunks;  // chunks of this pair in the combined gradient-pass table (their indices: Chunk::pad >> 8)
+  int nslots;   // segments (= 12-double gradient partials) of this pair in the combined gradient-pass table; a chunk's first: Chunk::pad >> 8
+  int nchunks;  // chunks of this pair in that table (the last-workgroup ticket counts them)
 };
 struct NoMultiDyn {};  // what the single-pair instantiations take in its place (no kernel-argument bytes, no branch)
 struct MultiDyn {

@@ -6,7 +6,6 @@
 // HIP kernels of nid_kernels.hpp, and creation fails when no gfx950 device is usable.
 #define NID_COMMON_KERNELS
 #include "nid_kernels.hpp"
-#include "nid_fused.hpp"
 #include "nid_launch.hpp"
 
 #include <algorithm>
@@ -72,6 +71,8 @@ struct nidreg_handle {
   int rec64 = 0;
   int64_t num_points = 0;
   int nchunks = 0;       // gradient pass / generic histogram kernels
+  int nslots = 0;        // segments in that table = 12-double partials of the gradient pass (>= nchunks)
+  int seg = 0, seg_hist = 0;  // the table (d_chunks / d_chunks_hist) has chunks that run across column groups: SEG kernels
   int nchunks_hist = 0;  // WIDE histogram kernel's own table (0 = shares d_chunks)
   double intr[5] = {0}, dist[8] = {0};
   double max_fov = 0.0;
@@ -81,6 +82,7 @@ struct nidreg_handle {
   void* d_pts = nullptr;
   Chunk* d_chunks = nullptr;
   Chunk* d_chunks_hist = nullptr;
+  uint32_t* d_gend = nullptr;  // [NG] end offsets of the column groups among the records (nid_kernels.hpp Segments)
   uint8_t* d_img = nullptr;
   u64* d_hist = nullptr;      // histogram of the current / most recent evaluation (accumulation target of pass A)
   // a shard of a ShardSet owns a range of histogram COLUMN GROUPS: it holds the points of those columns only, and its
@@ -118,17 +120,6 @@ struct nidreg_handle {
   int64_t hist_words = 0;
   std::vector<int64_t> gcount;  // record offsets of the column groups (host copy: multi-pair groups build their chunk tables from it)
   int num_cus = 256, per_cu_grad = 4, per_cu_hist = 2;
-
-  // the one-launch evaluation (k_fused, nid_fused.hpp): usable when the histogram pass's chunk table is one co-resident
-  // round of THAT kernel on this device; switched off for the handle after a launch had to be abandoned
-  bool fused_ok = false;
-  bool fused_off = false;
-  bool fused_inflight = false;
-  size_t lds_fused = 0;
-  void* d_fused_static = nullptr;     // device FusedStatic (nid_fused.hpp), carved from d_scratch
-  unsigned int* d_barrier = nullptr;  // grid-barrier block of k_fused (kBarrierWords words, carved from d_scratch)
-  unsigned int bar_base = 0;          // grid barriers completed by this handle's fused launches so far
-  unsigned long long fused_timeout_ticks = 500000ull;  // 5 ms of the 100 MHz wall clock
 
   int timing = 0;  // 1: per-kernel events (three-kernel path), 2: events around whichever path runs
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -190,6 +181,7 @@ void free_handle(nidreg_handle* h) {
   if (h->d_pts) (void)hipFree(h->d_pts);
   if (h->d_chunks) (void)hipFree(h->d_chunks);
   if (h->d_chunks_hist) (void)hipFree(h->d_chunks_hist);
+  if (h->d_gend) (void)hipFree(h->d_gend);
   if (h->d_img) (void)hipFree(h->d_img);
   if (h->own_hist) {
     if (h->d_hist_buf[0]) (void)hipFree(h->d_hist_buf[0]);
@@ -216,6 +208,10 @@ inline double fixed_unit(const nidreg_handle* h) {
 // U/36 grid steps of 2^-1074 as a subnormal double (the kernels' dn_scale / MultiEntry::k16)
 inline double fixed_unit_k(const nidreg_handle* h) { return std::ldexp(fixed_unit(h) / 36.0, -1074); }
 
+// capacity of a handle's gradient-partial buffer, in 12-double slots: its own table's segments, and room for any table a
+// multi-pair group builds for it (at most one slot per chunk plus one per column group)
+inline int partial_slots(const nidreg_handle* h) { return std::max(std::max(h->nchunks, h->nchunks_hist), 1) + h->NG + 1; }
+
 void fill_pass_args(const nidreg_handle* h, PassArgs& a) {
   std::memset(&a, 0, sizeof(a));
   a.model = h->model;
@@ -223,6 +219,9 @@ void fill_pass_args(const nidreg_handle* h, PassArgs& a) {
   a.pts = h->d_pts;
   a.chunks = h->d_chunks;
   a.nchunks = h->nchunks;
+  a.nslots = h->nslots;
+  a.seg = h->seg;
+  a.gend = h->d_gend;
   a.img = h->d_img;
   a.pitch = h->pitch;
   a.W = h->W;
@@ -260,9 +259,9 @@ inline void bump_seq(nidreg_handle* h) {
 }
 
 // Evaluations in flight per device (this process).  An evaluation that has its device to itself runs with progress
-// priority in the spline passes and -- nidreg_eval -- as ONE fused kernel; with several callers on one GPU (the reference's
-// OpenMP loop over pairs, visual_camera_calibration.cpp:161) both are off: the priority rule made competing kernels 5-16 %
-// slower (profiles/r02h_multi_pair_threads.txt), and two grid-barrier kernels must not share a device.
+// priority in the spline passes; with several callers on one GPU (the reference's OpenMP loop over pairs,
+// visual_camera_calibration.cpp:161) it is off: the rule made competing kernels 5-16 % slower
+// (profiles/r02h_multi_pair_threads.txt).
 std::atomic<int> g_inflight[NIDREG_MAX_DEVICES];
 struct InflightGuard {
   int dev;
@@ -325,6 +324,7 @@ int launch_hist_spline(nidreg_handle* h, const double* se3, bool alone = false, 
   if (h->d_chunks_hist) {
     a.chunks = h->d_chunks_hist;
     a.nchunks = h->nchunks_hist;
+    a.seg = h->seg_hist;
   }
   pose_from_se3(se3, a.R, a.t);
   for (int k = 0; k < 4; k++) h->last_q[k] = se3[k];
@@ -402,7 +402,6 @@ int eval_launch_first(nidreg_handle* h, const double* se3, bool alone = false) {
   if (h->mode != NIDREG_MODE_SPLINE) return fail(NIDREG_ERR_INVALID, "nidreg_eval: handle was created in NEAREST mode");
   HIP_TRY(hipSetDevice(h->device));
   bump_seq(h);
-  h->fused_inflight = false;
   if (h->timing) HIP_TRY(hipEventRecord(h->ev[0], h->stream));
   const int rc = launch_hist_spline(h, se3, alone);
   if (rc) return rc;
@@ -428,73 +427,12 @@ int eval_launch_rest(nidreg_handle* h, bool want_grad, bool alone = false) {
   return NIDREG_OK;
 }
 
-// The whole evaluation as ONE kernel (k_fused): histogram -> grid barrier -> distributed entropy -> grid barrier ->
-// gradient.  Only for an evaluation that is alone on its device (the barriers need every workgroup resident).
-bool fused_usable(const nidreg_handle* h) { return h->fused_ok && !h->fused_off && h->timing != 1; }
-int eval_launch_fused(nidreg_handle* h, const double* se3, bool want_grad) {
-  HIP_TRY(hipSetDevice(h->device));
-  bump_seq(h);
-  PassArgs a;
-  fill_pass_args(h, a);
-  if (h->d_chunks_hist) {
-    a.chunks = h->d_chunks_hist;
-    a.nchunks = h->nchunks_hist;
-  }
-  pose_from_se3(se3, a.R, a.t);
-  for (int k = 0; k < 4; k++) h->last_q[k] = a.q[k] = se3[k];
-  std::memcpy(h->last_R, a.R, sizeof(a.R));
-  std::memcpy(h->last_t, a.t, sizeof(a.t));
-  HIP_TRY(begin_histogram(h));
-  a.hist = h->d_hist;
-  a.prio = 1;
-  a.fused_static = h->d_fused_static;
-  a.hist_cur = h->hist_cur;
-  a.barrier = h->d_barrier;
-  a.bar_base = h->bar_base;
-  a.abort_flag = h->d_counters + 5;
-  a.timeout_ticks = h->fused_timeout_ticks;
-  a.want_grad = want_grad ? 1 : 0;
-  a.lds_fused = h->lds_fused;
-  a.tag = h->seq;
-  if (h->timing) HIP_TRY(hipEventRecord(h->ev[0], h->stream));
-  if (h->precision == NIDREG_PREC_FP32) {
-    HIP_TRY(launch_fused<float>(a));
-  } else {
-    HIP_TRY(launch_fused<double>(a));
-  }
-  if (h->timing) HIP_TRY(hipEventRecord(h->ev[5], h->stream));
-  h->bar_base += want_grad ? 2u : 1u;
-  h->hist_zeroed[h->hist_cur ^ 1] = true;  // zeroed by phase 2 for the next evaluation
-  h->ev_grad = want_grad;
-  h->fused_inflight = true;
-  return NIDREG_OK;
-}
-
-// after an abandoned fused launch: tickets, barrier counter and abort flag back to zero, both histogram buffers dirty
-int fused_recover(nidreg_handle* h) {
-  static std::atomic<bool> warned{false};
-  if (!warned.exchange(true))
-    std::fprintf(stderr, "nidreg: the one-launch evaluation could not get the whole GPU (another kernel holds compute units); handle falls back to three kernels per evaluation\n");
-  HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  HIP_TRY(hipMemsetAsync(h->d_counters, 0, 8 * sizeof(unsigned int), h->stream));
-  HIP_TRY(hipMemsetAsync(h->d_barrier, 0, size_t(kBarrierWords) * sizeof(unsigned int), h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  h->h_out[11] = 0.0;
-  h->bar_base = 0;
-  h->hist_zeroed[0] = h->hist_zeroed[1] = false;
-  h->fused_off = true;
-  h->fused_inflight = false;
-  return NIDREG_OK;
-}
-
 int eval_launch(nidreg_handle* h, const double* se3, bool want_grad, bool alone = false) {
   const int rc = eval_launch_first(h, se3, alone);
   if (rc) return rc;
   return eval_launch_rest(h, want_grad, alone);
 }
 
-constexpr int kRetryUnfused = -100;  // internal: the fused kernel abandoned the evaluation (not an ABI return value)
 int eval_finish_on(nidreg_handle* h, hipStream_t stream, double* cost, double* grad7);
 int eval_finish(nidreg_handle* h, double* cost, double* grad7) { return eval_finish_on(h, h->stream, cost, grad7); }
 // `stream` = the stream the evaluation's kernels were queued on (the handle's own, or a multi-pair group's)
@@ -528,7 +466,6 @@ int eval_finish_on(nidreg_handle* h, hipStream_t stream, double* cost, double* g
           const hipError_t q = hipStreamQuery(stream);
           if (q == hipSuccess) {
             if (!tag_seen()) HIP_TRY(hipStreamSynchronize(stream));
-            if (!tag_seen() && h->fused_inflight && h->h_out[11] != 0.0) return kRetryUnfused;  // a grid barrier of k_fused timed out
             if (!tag_seen()) return fail(NIDREG_ERR_HIP, "nidreg_eval: stream drained but the completion tag is missing");
             break;
           }
@@ -557,7 +494,6 @@ int iso_launch(nidreg_handle* h, const double* T) {
   if (h->mode != NIDREG_MODE_NEAREST) return fail(NIDREG_ERR_INVALID, "nidreg_eval_iso: handle was created in SPLINE mode");
   HIP_TRY(hipSetDevice(h->device));
   bump_seq(h);
-  h->fused_inflight = false;
   if (h->timing) HIP_TRY(hipEventRecord(h->ev[0], h->stream));
   int rc = launch_hist_nearest(h, T);
   if (rc) return rc;
@@ -641,65 +577,109 @@ struct nidreg_cloud {
 
 namespace {
 
-// ---- chunk tables: each chunk = one workgroup, points of ONE column group only.  A pass should be ONE round of co-resident
-// workgroups (`target` of them; measured on cfg 2: the per-workgroup prologue / flush is amortised over more points and no
-// partial last round is left -- 2048 chunks +4 %, 4096 +12 %).  Every group is split EVENLY into ceil(count / CH) chunks,
-// CH = N / target rounded up to whole workgroup sweeps -- and CH GROWS until the table fits the round.  Without that step a
-// cloud whose column populations are not uniform (a pair of a multi-pair set, any view-culled cloud: the rank equalisation
-// of preprocess.cpp:464-473 makes the columns of the WHOLE cloud equal, not those of a subset) got a few workgroups more
-// than the round holds, and a pass took a round plus one lone chunk: two pairs x 5M points had 519 / 1031 chunks for 512 /
-// 1024 slots and their kernels ran 85 + 100 us instead of 51 + 74 us (round 3's open question about the two-pair single
-// grid; found with the column counts of the bench scene, tools/chunk_rounds.py).  A group is never merged with another
-// one (a workgroup owns its columns), so a cloud with more non-empty groups than `target` gets one chunk per group.
-// pair < 0: a single-pair table (pad = 0); otherwise Chunk::pad = pair | (index among the pair's chunks) << 8.
-void split_groups(const int64_t* gcount, int NG, int64_t target, int threads, int pair, std::vector<Chunk>& chunks) {
-  const int64_t N = gcount[NG] - gcount[0];
-  target = std::max<int64_t>(target, 1);
-  int64_t nonempty = 0, biggest = 0;
-  for (int g = 0; g < NG; g++) {
-    const int64_t cnt = gcount[g + 1] - gcount[g];
-    if (cnt > 0) nonempty++;
-    biggest = std::max(biggest, cnt);
-  }
-  auto round_up = [threads](int64_t v) { return std::max<int64_t>(threads, ((v + threads - 1) / threads) * threads); };
-  auto count_for = [&](int64_t ch) {
-    int64_t n = 0;
-    for (int g = 0; g < NG; g++) {
-      const int64_t cnt = gcount[g + 1] - gcount[g];
-      if (cnt > 0) n += (cnt + ch - 1) / ch;
+// ---- chunk tables: each chunk = one workgroup's slice of the bucketed record array.  A pass should be ONE round of
+// co-resident workgroups (`target` of them; measured on cfg 2: the per-workgroup prologue / flush is amortised over more
+// points and no partial last round is left -- 2048 chunks +4 %, 4096 +12 %), and the round ends with its LONGEST chunk.
+// Rounds 1-3 gave every chunk the points of one column group only (a group split evenly into an integer number of chunks):
+// exact on a cloud whose columns are equally full -- the rank equalisation of preprocess.cpp:464-473 makes them so for a
+// WHOLE cloud --, but the clouds `calibrate` evaluates are view-culled (visual_camera_calibration.cpp:201-206) and a pair of
+// a multi-pair set is a subset: with columns of 0.5 ... 1.5 x the mean an integer split leaves chunks of 3/4 ... 3/2 of the
+// mean (measured: +20 % per point, profiles/r03r_culled_cloud_ab*.json).  Since round 4 a chunk is a CONTIGUOUS RANGE of
+// records that may run across group boundaries (nid_kernels.hpp Segments): the workgroup flushes / rebuilds its tile at
+// every boundary, which costs about `overhead` records' worth of time (pipeline drain, 64 KB of LDS traffic, the first
+// load latency of the next segment).  The table minimises the longest chunk under that cost model:
+//     cost(chunk) = sum over its segments of (overhead + records),
+// smallest bound C for which a greedy left-to-right fill needs <= target chunks (binary search; the fill never opens a
+// segment shorter than `overhead` at the end of a chunk, and cuts inside a group at multiples of 64 records).  A pure function
+// of (group offsets, target, overhead, max_segs): the gradient's partial sums keep a fixed order, run to run.
+// max_segs = segments a chunk may hold: kMaxSegs for the single-column kernels (B > 128) and every NEAREST table, 1 where a
+// workgroup's tile spans several columns (B <= 128: few groups, large tiles -- a chunk then ends at the group boundary as it
+// always did).  Tables without a multi-segment chunk run the straight-line kernels of rounds 1-3, the others the looped
+// (SEG) instantiations; NIDREG_MAX_SEGS=1 keeps every table on one segment per chunk (A/B runs).
+// Chunk::pad = pair | slot << 8: pair = index into the multi-pair table (0 in a single-pair table, pair < 0), slot = number of
+// segments in the table's earlier chunks -- the gradient pass stores one 12-double partial per SEGMENT, in this order.
+// *nslots_out (nullable) = segments in the whole table.
+int64_t fill_chunks(const int64_t* gcount, int NG, int64_t C, int64_t overhead, int max_segs, int pair, std::vector<Chunk>* out, int64_t* nslots_out = nullptr) {
+  int64_t nchunks = 0, cur = 0;  // cur = cost already in the open chunk (0: none open)
+  int64_t nslots = 0, first_slot = 0;
+  Chunk c{0, 0, 0, 0};
+  auto close = [&]() {
+    if (cur > 0 && out) {
+      c.pad = uint32_t(pair < 0 ? 0 : pair) | (uint32_t(first_slot) << 8);
+      out->push_back(c);
     }
-    return n;
+    cur = 0;
   };
-  int64_t CH = round_up((N + target - 1) / target);
-  const int64_t limit = std::max(target, nonempty);
-  // NIDREG_CHUNKS_NO_FIT=1: the rule of rounds 1-3 (no growth step), for A/B measurements (tools/culled_cloud_ab.py)
-  if (count_for(CH) > limit && !std::getenv("NIDREG_CHUNKS_NO_FIT")) {  // smallest CH (in whole sweeps) whose table fits: count_for is non-increasing in CH
-    int64_t lo = CH / threads, hi = round_up(biggest) / threads;  // count_for(lo * threads) > limit >= nonempty = count_for(hi * threads)
+  for (int g = 0; g < NG; g++) {
+    int64_t pos = gcount[g];
+    const int64_t hi = gcount[g + 1];
+    while (pos < hi) {
+      const int64_t rem = hi - pos;
+      int64_t room = C - cur - overhead;  // records of this group the open chunk can still take
+      if (cur > 0 && (room < std::min(rem, std::max<int64_t>(overhead, 64)) || nslots - first_slot >= max_segs)) {  // not worth a segment (or the chunk is at its segment limit): next chunk
+        close();
+        continue;
+      }
+      if (cur == 0) {
+        nchunks++;
+        c.start = uint32_t(pos);
+        c.count = 0;
+        c.group = uint32_t(g);
+        first_slot = nslots;
+        room = std::max<int64_t>(room, 64);  // an empty chunk always makes progress
+      }
+      int64_t take = std::min(rem, room);
+      if (take < rem) take = std::max<int64_t>(64, take / 64 * 64);  // cut inside a group: whole waves
+      take = std::min(take, rem);
+      c.count += uint32_t(take);
+      cur += overhead + take;
+      nslots++;
+      pos += take;
+      if (pos < hi) close();  // the group goes on in the next chunk
+    }
+  }
+  close();
+  if (nslots_out) *nslots_out = nslots;
+  return nchunks;
+}
+// returns the number of segments (= gradient partial slots) of the table appended to `chunks`
+int64_t split_groups(const int64_t* gcount, int NG, int64_t target, int64_t overhead, int max_segs, int pair, std::vector<Chunk>& chunks) {
+  const int64_t N = gcount[NG] - gcount[0];
+  if (N <= 0) return 0;
+  target = std::max<int64_t>(target, 1);
+  overhead = std::max<int64_t>(overhead, 0);
+  max_segs = std::max(1, std::min(max_segs, kMaxSegs));
+  int64_t nonempty = 0;
+  for (int g = 0; g < NG; g++) nonempty += gcount[g + 1] > gcount[g] ? 1 : 0;
+  // fill_chunks(C) is non-increasing in C; C = everything in one chunk always fits
+  int64_t lo = overhead + 63, hi = N + nonempty * overhead + 64;  // lo: too small (or just feasible -- checked first), hi: feasible
+  if (fill_chunks(gcount, NG, lo + 1, overhead, max_segs, pair, nullptr) <= target) {
+    hi = lo + 1;
+  } else {
     while (hi - lo > 1) {
       const int64_t mid = lo + (hi - lo) / 2;
-      if (count_for(mid * threads) > limit) {
-        lo = mid;
-      } else {
+      if (fill_chunks(gcount, NG, mid, overhead, max_segs, pair, nullptr) <= target) {
         hi = mid;
+      } else {
+        lo = mid;
       }
     }
-    CH = hi * threads;
   }
-  const size_t first = chunks.size();
-  for (int g = 0; g < NG; g++) {
-    const int64_t lo = gcount[g], hi = gcount[g + 1];
-    if (hi <= lo) continue;
-    const int64_t parts = (hi - lo + CH - 1) / CH;
-    const int64_t size = (((hi - lo + parts - 1) / parts + 63) / 64) * 64;  // 64 records = 1 KB: chunk starts stay aligned
-    for (int64_t st = lo; st < hi; st += size) {
-      Chunk c;
-      c.start = uint32_t(st);
-      c.count = uint32_t(std::min<int64_t>(size, hi - st));
-      c.group = uint32_t(g);
-      c.pad = pair < 0 ? 0u : (uint32_t(pair) | (uint32_t(chunks.size() - first) << 8));
-      chunks.push_back(c);
-    }
-  }
+  int64_t nslots = 0;
+  fill_chunks(gcount, NG, hi, overhead, max_segs, pair, &chunks, &nslots);
+  return nslots;
+}
+// records' worth of time one more segment costs a workgroup of the given kernel (measured orders of magnitude: a WIDE
+// histogram workgroup streams ~400 records/us and a boundary costs it ~2.5 us; a gradient / generic workgroup ~150-200
+// records/us and ~2 us).  NIDREG_SEG_OVERHEAD=<records> overrides both (A/B runs).
+int max_segments(int mode, int GW) {
+  int m = (mode == NIDREG_MODE_NEAREST || GW == 1) ? kMaxSegs : 1;
+  if (const char* e = std::getenv("NIDREG_MAX_SEGS")) m = std::max(1, std::min(m, int(std::strtol(e, nullptr, 10))));
+  return m;
+}
+int64_t segment_overhead(bool wide_hist) {
+  if (const char* e = std::getenv("NIDREG_SEG_OVERHEAD")) return std::max<int64_t>(0, std::strtoll(e, nullptr, 10));
+  return wide_hist ? 1024 : 384;
 }
 
 struct CreateOpts {
@@ -775,7 +755,7 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
   h->NEB = (B + kEntropyCols - 1) / kEntropyCols;
   h->lds_hist = (size_t(GW) * B * 8 << cshift) + size_t(GW) * 8 + 16;
   // gradient pass: a single-column workgroup (GW = 1) keeps ONE copy of its G column (k_spline_grad<.., GW1>)
-  h->lds_grad = (GW == 1 ? size_t(B) * 8 : (size_t(GW) * B * 8 << cshift)) + size_t(kWaves) * 12 * 8 + 256 * 8 + 16;  // G tile, reduction scratch, phi(q_r), flag
+  h->lds_grad = spline_grad_lds_bytes(B, GW, cshift, false);  // G tile, reduction scratch, phi(q_r), flag (+ staged columns once the table is known to need them)
   h->lds_entropy = size_t(B) * 8 + size_t(GW) * 8 + size_t(kWaves) * 8;
 
   // ---- fixed point: sum over a bin <= N * 2^frac must stay below 2^63
@@ -894,6 +874,10 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
   // ---- chunk tables (split_groups): by default 4 workgroups per CU for the 256-thread kernels, 2 per CU for the WIDE
   // histogram kernel (64 KB LDS each), which therefore has its own table
   {
+    std::vector<uint32_t> gend(static_cast<size_t>(h->NG));
+    for (int g = 0; g < h->NG; g++) gend[size_t(g)] = uint32_t(gcount[size_t(g) + 1]);
+    CREATE_TRY(hipMalloc(&h->d_gend, gend.size() * sizeof(uint32_t)));
+    CREATE_TRY(hipMemcpy(h->d_gend, gend.data(), gend.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     int num_cus = 256;
     if (hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || num_cus <= 0) num_cus = 256;
     // (Tried and dropped: emitting a group's parts part-major -- part j of every group in dispatch slot j of the CUs -- and
@@ -901,7 +885,8 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
     // (profiles/r03d_workgroup_spread.txt), but the workgroups of one CU share its issue capacity: what ends a pass is the
     // slowest CU, not the slowest workgroup, and no weighting moved the kernel times (profiles/r03e_slot_weights_no_gain.txt;
     // the part-major order itself cost 3 us in the gradient pass).)
-    auto build_chunks = [&](int target, int threads, std::vector<Chunk>& chunks) { split_groups(gcount.data(), h->NG, target, threads, -1, chunks); };
+    const int max_segs = max_segments(d->mode, GW);
+    auto build_chunks = [&](int target, bool wide_hist, std::vector<Chunk>& chunks) { return split_groups(gcount.data(), h->NG, target, segment_overhead(wide_hist), max_segs, -1, chunks); };
     // workgroups per CU that are really co-resident for THIS kernel instantiation: 4 for the pinhole family, 3 for the
     // fisheye / equirectangular gradient kernels (154-161 VGPRs) -- 1024 chunks there meant 1.33 rounds
     int per_cu_grad = 4, per_cu_hist = h->wide ? 2 : 4;
@@ -918,14 +903,17 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
     h->per_cu_grad = h->wide ? per_cu_grad : std::min(per_cu_grad, per_cu_hist);
     h->per_cu_hist = per_cu_hist;
     std::vector<Chunk> chunks;
-    build_chunks(d->target_blocks > 0 ? d->target_blocks : (h->wide ? per_cu_grad : std::min(per_cu_grad, per_cu_hist)) * num_cus, kThreads, chunks);
+    h->nslots = int(build_chunks(d->target_blocks > 0 ? d->target_blocks : (h->wide ? per_cu_grad : std::min(per_cu_grad, per_cu_hist)) * num_cus, false, chunks));
     h->nchunks = int(chunks.size());
+    h->seg = h->nslots > h->nchunks ? 1 : 0;
+    if (h->seg && GW == 1) h->lds_grad = spline_grad_lds_bytes(B, GW, cshift, true);
     CREATE_TRY(hipMalloc(&h->d_chunks, std::max<size_t>(chunks.size(), 1) * sizeof(Chunk)));
     if (!chunks.empty()) CREATE_TRY(hipMemcpy(h->d_chunks, chunks.data(), chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice));
     if (h->wide) {
       std::vector<Chunk> wide_chunks;
-      build_chunks(d->target_blocks > 0 ? d->target_blocks : per_cu_hist * num_cus, kWideThreads, wide_chunks);
+      const int64_t wide_slots = build_chunks(d->target_blocks > 0 ? d->target_blocks : per_cu_hist * num_cus, true, wide_chunks);
       h->nchunks_hist = int(wide_chunks.size());
+      h->seg_hist = wide_slots > int64_t(wide_chunks.size()) ? 1 : 0;
       CREATE_TRY(hipMalloc(&h->d_chunks_hist, std::max<size_t>(wide_chunks.size(), 1) * sizeof(Chunk)));
       if (!wide_chunks.empty()) CREATE_TRY(hipMemcpy(h->d_chunks_hist, wide_chunks.data(), wide_chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice));
     }
@@ -967,17 +955,14 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
       off = (off + bytes + 255) & ~size_t(255);
       return at;
     };
-    const int chunks_max = std::max(std::max(h->nchunks, h->nchunks_hist), 1);
-    const size_t o_part_hj = carve(size_t(std::max(h->NEB, chunks_max)) * sizeof(long long));    // k_entropy: per column block; k_fused: per workgroup
-    const size_t o_row_part = carve(size_t(std::max(h->NEB, kFusedMaxSegs)) * B * sizeof(u64));  // k_entropy: [NEB][B]; k_fused: [segments][B]
+    const size_t o_part_hj = carve(size_t(h->NEB) * sizeof(long long));   // k_entropy_owned: per column block
+    const size_t o_row_part = carve(size_t(h->NEB) * B * sizeof(u64));    // k_entropy_owned: [NEB][B]
     const size_t o_phi_q = carve(size_t(B) * sizeof(double));
     const size_t o_hist_image = carve(size_t(B) * sizeof(double));
     const size_t o_hist_points = carve(size_t(B) * sizeof(double));
     const size_t o_scal = carve(sizeof(EntropyScalars));
-    const size_t o_partials = carve(size_t(chunks_max) * 12 * sizeof(double));
+    const size_t o_partials = carve(size_t(partial_slots(h)) * 12 * sizeof(double));
     const size_t o_counters = carve(8 * sizeof(unsigned int));
-    const size_t o_barrier = carve(size_t(kBarrierWords) * sizeof(unsigned int));
-    const size_t o_fstatic = carve(sizeof(FusedStatic));
     CREATE_TRY(hipMalloc(&h->d_scratch, off));
     CREATE_TRY(hipMemset(h->d_scratch, 0, off));
     char* base = static_cast<char*>(h->d_scratch);
@@ -989,8 +974,6 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
     h->d_scal = reinterpret_cast<EntropyScalars*>(base + o_scal);
     h->d_partials = reinterpret_cast<double*>(base + o_partials);
     h->d_counters = reinterpret_cast<unsigned int*>(base + o_counters);
-    h->d_barrier = reinterpret_cast<unsigned int*>(base + o_barrier);
-    h->d_fused_static = base + o_fstatic;
   }
   CREATE_TRY(hipHostMalloc(&h->h_out, NIDREG_OUT_DOUBLES * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
   std::memset(h->h_out, 0, NIDREG_OUT_DOUBLES * sizeof(double));
@@ -1001,45 +984,6 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
     h->d_out_host = static_cast<double*>(dp);
   }
   for (int i = 0; i < 6; i++) CREATE_TRY(hipEventCreate(&h->ev[i]));
-  // ---- the one-launch evaluation (k_fused): its grid barriers need the histogram pass's whole chunk table resident at
-  // once, which the table's construction aimed at for k_spline_hist -- checked here against k_fused's own occupancy
-  // (the fisheye / equirectangular instantiations hold more registers: they keep the three-kernel path)
-  if (d->mode == NIDREG_MODE_SPLINE && h->own_hist && h->d_out_host && !opts.shard && h->own_stream) {
-    FusedStatic fs;
-    std::memset(&fs, 0, sizeof(fs));
-    fs.hist_buf[0] = h->d_hist_buf[0];
-    fs.hist_buf[1] = h->d_hist_buf[1];
-    fs.hist_words = h->hist_words;
-    fs.part_hj = h->d_part_hj;
-    fs.row_part = h->d_row_part;
-    fs.phi_q = h->d_phi_q;
-    fs.hist_image = h->d_hist_image;
-    fs.hist_points = h->d_hist_points;
-    fs.scal = h->d_scal;
-    fs.partials = h->d_partials;
-    fs.out = h->d_out;
-    fs.out_host = h->d_out_host;
-    fs.counters = h->d_counters;
-    fs.abort_host = h->d_out_host + 11;
-    CREATE_TRY(hipMemcpy(h->d_fused_static, &fs, sizeof(fs), hipMemcpyHostToDevice));
-    // opt-in: measured on the headline workload the one-launch evaluation equals the three-kernel route (0.1404-0.1413 ms
-    // against 0.1406-0.1421 ms per evaluation) and at 50M points it is 3.8 % slower (profiles/r03c_fused_ab_configs.jsonl):
-    // the two grid barriers and the entropy step spread over every workgroup cost what k_entropy's latency chain and the two
-    // launch boundaries cost (phase timeline: profiles/r03c_fused_phase_timeline.txt)
-    const char* env = std::getenv("NIDREG_FUSED");
-    const bool enabled = env && *env && *env != '0';
-    const int table = h->d_chunks_hist ? h->nchunks_hist : h->nchunks;
-    const int threads = h->wide ? kWideThreads : kThreads;
-    h->lds_fused = fused_lds_bytes(B, h->GW, h->cshift, threads);
-    if (enabled && table > 0) {
-      PassArgs oa;
-      fill_pass_args(h, oa);
-      oa.lds_fused = h->lds_fused;
-      const int occ = h->precision == NIDREG_PREC_FP32 ? occupancy_fused<float>(oa) : occupancy_fused<double>(oa);
-      h->fused_ok = occ > 0 && int64_t(occ) * h->num_cus >= table;
-    }
-    if (const char* t = std::getenv("NIDREG_FUSED_TIMEOUT_US")) h->fused_timeout_ticks = 100ull * (unsigned long long)std::max(1L, std::strtol(t, nullptr, 10));
-  }
 #undef CREATE_TRY
   *out = h;
   return NIDREG_OK;
@@ -1059,6 +1003,8 @@ struct MultiGroup {
   MultiEntry* d_table = nullptr;
   Chunk* d_chunks = nullptr;       // gradient pass / generic histogram kernels
   Chunk* d_chunks_hist = nullptr;  // WIDE histogram kernel
+  int seg = 0, seg_hist = 0;       // the combined tables have chunks that run across column groups (SEG kernels)
+  size_t lds_grad = 0;
   int nchunks = 0, nchunks_hist = 0;
   std::atomic<int> users{0};  // evaluations running on this group (acquire_group / release_group)
   uint64_t last_use = 0;
@@ -1118,8 +1064,8 @@ bool groupable(const nidreg_handle* a, const nidreg_handle* b) {
 }
 
 // chunks of one pair for a share `target` of the round (same rule as create_impl's tables: split_groups)
-void pair_chunks(const nidreg_handle* h, int pair, int64_t target, int threads, std::vector<Chunk>& chunks) {
-  split_groups(h->gcount.data(), h->NG, target, threads, pair, chunks);
+int64_t pair_chunks(const nidreg_handle* h, int pair, int64_t target, bool wide_hist, std::vector<Chunk>& chunks) {
+  return split_groups(h->gcount.data(), h->NG, target, segment_overhead(wide_hist), max_segments(h->mode, h->GW), pair, chunks);
 }
 
 // returns the group with its use count raised (release_group when the evaluation is over), or nullptr
@@ -1144,13 +1090,15 @@ MultiGroup* find_or_make_group(nidreg_handle* const* handles, int n) {
   for (int i = 0; i < n; i++) {
     nidreg_handle* h = handles[i];
     const int64_t share_grad = std::max<int64_t>(1, int64_t(h0->per_cu_grad) * h0->num_cus * std::max<int64_t>(h->num_points, 1) / total);
-    pair_chunks(h, i, share_grad, kThreads, pair_grad[size_t(i)]);
+    const int64_t pair_slots = pair_chunks(h, i, share_grad, false, pair_grad[size_t(i)]);
+    if (pair_slots > int64_t(pair_grad[size_t(i)].size())) g->seg = 1;
     if (h0->wide) {
       const int64_t share_hist = std::max<int64_t>(1, int64_t(h0->per_cu_hist) * h0->num_cus * std::max<int64_t>(h->num_points, 1) / total);
-      pair_chunks(h, i, share_hist, kWideThreads, pair_hist[size_t(i)]);
+      if (pair_chunks(h, i, share_hist, true, pair_hist[size_t(i)]) > int64_t(pair_hist[size_t(i)].size())) g->seg_hist = 1;
     }
     MultiEntry& e = table[size_t(i)];
     e.pts = h->d_pts;
+    e.gend = h->d_gend;
     e.img = h->d_img;
     e.hist_buf[0] = h->d_hist_buf[0];
     e.hist_buf[1] = h->d_hist_buf[1];
@@ -1167,9 +1115,9 @@ MultiGroup* find_or_make_group(nidreg_handle* const* handles, int n) {
     e.out_host = h->d_out_host;
     e.counters = h->d_counters;
     e.zero_words = h->hist_words;
-    e.reserved0 = 0;
+    e.nslots = int(pair_slots);
     e.nchunks = int(pair_grad[size_t(i)].size());
-    if (e.nchunks > std::max(std::max(h->nchunks, h->nchunks_hist), 1)) {  // the pair's partial buffer holds 12 doubles per chunk of ITS OWN table
+    if (e.nslots > partial_slots(h)) {  // the pair's partial buffer (12 doubles per slot) was sized at its creation
       delete g;
       if (g_rejected.size() >= kMaxRejected) g_rejected.erase(g_rejected.begin());
       g_rejected.emplace_back(handles, handles + n);
@@ -1198,6 +1146,7 @@ MultiGroup* find_or_make_group(nidreg_handle* const* handles, int n) {
   }
   g->nchunks = int(chunks.size());
   g->nchunks_hist = int(wide_chunks.size());
+  g->lds_grad = spline_grad_lds_bytes(h0->bins, h0->GW, h0->cshift, g->seg != 0);
   // least recently used out (never one that is being evaluated)
   while (g_groups.size() >= kMaxGroups) {
     size_t victim = g_groups.size();
@@ -1238,11 +1187,11 @@ int group_eval(MultiGroup* g, const double* se3, bool want_grad, double* costs, 
     std::memcpy(h->last_R, a.R, sizeof(a.R));
     std::memcpy(h->last_t, a.t, sizeof(a.t));
     h->ev_grad = want_grad;
-    h->fused_inflight = false;
-  }
+    }
   // pass A
   a.chunks = h0->wide ? g->d_chunks_hist : g->d_chunks;
   a.nchunks = h0->wide ? g->nchunks_hist : g->nchunks;
+  a.seg = h0->wide ? g->seg_hist : g->seg;
   if (h0->precision == NIDREG_PREC_FP32) {
     HIP_TRY(launch_spline_hist<float>(a));
   } else {
@@ -1259,6 +1208,8 @@ int group_eval(MultiGroup* g, const double* se3, bool want_grad, double* costs, 
   if (want_grad) {
     a.chunks = g->d_chunks;
     a.nchunks = g->nchunks;
+    a.seg = g->seg;
+    a.lds_grad = g->lds_grad;
     a.gt_from_partials = 1;
     if (h0->precision == NIDREG_PREC_FP32) {
       HIP_TRY(launch_spline_grad<float>(a));
@@ -1317,6 +1268,7 @@ int group_eval_iso(MultiGroup* g, const double* T, double* costs) {
   }
   a.chunks = g->d_chunks;
   a.nchunks = g->nchunks;
+  a.seg = g->seg;
   if (h0->precision == NIDREG_PREC_FP32) {
     HIP_TRY(launch_nearest_hist<float>(a));
   } else {
@@ -1402,8 +1354,7 @@ int shard_launch_phase(ShardSet* set, int g, int phase, bool alone) {
   const bool grad = set->job_mode == NIDREG_MODE_SPLINE && set->job_grad;
   if (phase == 0) {
     bump_seq(h);
-    h->fused_inflight = false;
-    h->h_out[10] = 0.0;
+      h->h_out[10] = 0.0;
     if (h->timing) HIP_TRY(hipEventRecord(h->ev[0], h->stream));
     if (h->nchunks == 0) {  // no points in this shard's columns: no histogram kernel runs, announce S_g = 0
       HIP_TRY(begin_histogram(h));
@@ -1809,17 +1760,6 @@ int nidreg_eval(nidreg_handle* h, const double* se3, double* cost, double* grad7
   if (!h || !se3) return fail(NIDREG_ERR_INVALID, "nidreg_eval: null argument");
   if (h->set) return set_eval(h->set, NIDREG_MODE_SPLINE, se3, cost, grad7);
   InflightGuard guard(h->device);
-  if (guard.alone && h->mode == NIDREG_MODE_SPLINE && fused_usable(h)) {
-    int rc = eval_launch_fused(h, se3, grad7 != nullptr);
-    if (rc) return rc;
-    rc = eval_finish(h, cost, grad7);
-    if (rc != kRetryUnfused) return rc;
-    // Not every workgroup became resident within the timeout (something else holds CUs of this GPU): the kernel has
-    // ended by itself.  Put the handle back into a clean state and repeat the evaluation with the three-kernel path;
-    // the handle stays on that path.
-    rc = fused_recover(h);
-    if (rc) return rc;
-  }
   const int rc = eval_launch(h, se3, grad7 != nullptr, guard.alone);
   if (rc) return rc;
   return eval_finish(h, cost, grad7);
@@ -2146,12 +2086,13 @@ int nidreg_debug_partition_groups(const int64_t* gcount, int NG, int n, int* cut
 }
 
 /* test hook (tests/test_host_logic.py; not part of the drop-in surface): the chunk table split_groups builds for a share
- * `target` of a round -- gcount[NG + 1] record offsets of the column groups -> up to cap rows {start, count, group, pad};
+ * `target` of a round, a per-segment cost of `overhead` records and at most max_segs segments per chunk -- gcount[NG + 1] record offsets of the column groups ->
+ * up to cap rows {start, count, group, pad};
  * returns the number of chunks (also when it exceeds cap) */
-int nidreg_debug_chunk_table(const int64_t* gcount, int NG, int target, int threads, int pair, uint32_t* rows_out, int cap) {
-  if (!gcount || NG < 1 || threads < 1) return NIDREG_ERR_INVALID;
+int nidreg_debug_chunk_table(const int64_t* gcount, int NG, int target, int overhead, int max_segs, int pair, uint32_t* rows_out, int cap) {
+  if (!gcount || NG < 1 || overhead < 0 || max_segs < 1) return NIDREG_ERR_INVALID;
   std::vector<Chunk> chunks;
-  split_groups(gcount, NG, target, threads, pair, chunks);
+  split_groups(gcount, NG, target, overhead, max_segs, pair, chunks);
   for (size_t k = 0; k < chunks.size() && int(k) < cap && rows_out; k++) {
     rows_out[4 * k] = chunks[k].start, rows_out[4 * k + 1] = chunks[k].count, rows_out[4 * k + 2] = chunks[k].group, rows_out[4 * k + 3] = chunks[k].pad;
   }
@@ -2185,7 +2126,7 @@ int nidreg_get_info(nidreg_handle* h, int64_t* info8) {
     info8[6] = 0;
     for (nidreg_handle* sh : h->set->shards) info8[6] += sh->num_points;
   }
-  info8[7] = (h->rec64 ? 0 : 1) | (h->fused_ok && !h->fused_off ? 2 : 0) | (int64_t(1 << h->cshift) << 8);
+  info8[7] = (h->rec64 ? 0 : 1) | (h->seg ? 2 : 0) | (h->seg_hist ? 4 : 0) | (int64_t(1 << h->cshift) << 8);
   return NIDREG_OK;
 }
 

@@ -250,7 +250,8 @@ class _Handle:
         keys = ["record_bytes", "num_chunks", "columns_per_group", "frac_bits", "lds_bytes", "image_pitch", "num_points", "float32_records"]
         out = dict(zip(keys, [int(x) for x in v]))
         out["lds_copies"] = out["float32_records"] >> 8
-        out["fused"] = (out["float32_records"] >> 1) & 1  # evaluations run as one kernel (k_fused) when alone on the device
+        out["segmented"] = (out["float32_records"] >> 1) & 1       # gradient-pass table: chunks run across column groups (looped kernels)
+        out["segmented_hist"] = (out["float32_records"] >> 2) & 1  # the WIDE histogram kernel's table
         out["float32_records"] &= 1
         return out
 

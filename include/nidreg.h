@@ -46,11 +46,9 @@
  *     Handles sharded over several GPUs are evaluated one after the other on every device they share
  *     (a per-device lock inside nidreg_eval*: each of them uses all of its GPUs anyway).
  *   - an evaluation that has its device to itself runs with issue priority by progress in the two streaming kernels;
- *     evaluations that share a device (concurrent callers) run without it.  NIDREG_FUSED=1 in the environment at handle
- *     creation (opt-in; measured equal to the default route on the headline workload and slower at 50M points) runs such
- *     an evaluation as ONE kernel: histogram -> grid barrier -> entropy -> grid barrier -> gradient (csrc/nid_fused.hpp).
- *     The cost and the histograms are bit-identical on both routes (fixed-point histogram, fixed-point entropy sums), the
- *     gradient equal up to the order of the workgroup partials.
+ *     evaluations that share a device (concurrent callers) run without it.  The cost and the histograms do not depend
+ *     on it, nor on the chunk tables or the GPU count (fixed-point histogram, fixed-point entropy sums: bit-identical);
+ *     the gradient is equal up to the order of the workgroup partials, which is a fixed function of the handle.
  *   - the caller keeps ownership of every host buffer; nidreg_create copies what it needs.
  */
 #ifndef NIDREG_H
@@ -271,16 +269,15 @@ void nidreg_trim(void);
  * recorded on the handle's stream, i.e. the stream the kernels run on):
  * [0]=whole launch sequence [1]=histogram memset [2]=histogram kernel [3]=entropy kernels
  * [4]=gradient kernel (0 if not run) [5]=gradient finalisation.
- * nidreg_set_timing(h, 1): an event after every kernel -- the evaluation then runs as three kernels; (h, 2): only [0], around
- * whichever route runs (one fused kernel when the handle has its device to itself); (h, 0): off. */
+ * nidreg_set_timing(h, 1): an event after every kernel; (h, 2): only [0], around the whole evaluation; (h, 0): off. */
 int nidreg_set_timing(nidreg_handle* h, int enable);
 int nidreg_get_timing(nidreg_handle* h, float* ms6);
 
 /* layout facts for DESIGN.md / bench: [0]=record bytes per point on device, [1]=number of chunks,
  * [2]=columns per group, [3]=fixed-point fraction bits, [4]=LDS bytes per workgroup,
- * [5]=padded image pitch, [6]=points stored, [7]=bit0: float32 records, bit1: nidreg_eval runs as ONE fused kernel when the
- * handle has its device to itself (csrc/nid_fused.hpp; opt-in: NIDREG_FUSED=1 in the environment at creation),
- * bits 8..: LDS copies per histogram cell */
+ * [5]=padded image pitch, [6]=points stored, [7]=bit0: float32 records, bit1: the gradient-pass chunk table has chunks that run
+ * across column groups (the looped kernel instantiations, csrc/nid_kernels.hpp Segments), bit2: so has the WIDE histogram
+ * kernel's table, bits 8..: LDS copies per histogram cell */
 int nidreg_get_info(nidreg_handle* h, int64_t* info8);
 
 const char* nidreg_last_error(void);

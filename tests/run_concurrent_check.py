@@ -1,4 +1,4 @@
-"""Helper of test_concurrent_callers.py (its own process: NIDREG_FUSED is read when a handle is created):
+"""Helper of test_concurrent_callers.py (its own process):
 k pairs evaluated one by one, then by k threads that call their own NIDCost at the same pose behind a barrier -- the
 reference's OpenMP loop over pairs (visual_camera_calibration.cpp:161).  Prints one JSON line."""
 import json
@@ -38,9 +38,8 @@ for t in th:
 for t in th:
     t.join()
 dt = time.perf_counter() - t0
-# the cost comes from the integer histogram and integer entropy sums: identical bit for bit whichever route (one fused kernel
-# when the caller is alone on the device, three kernels otherwise) evaluates it; the gradient's workgroup partials follow
-# the route's chunk table: equal to rounding
+# the cost comes from the integer histogram and integer entropy sums: identical bit for bit however the kernels of the
+# callers interleave; the gradient's workgroup partials follow the chunk table: equal to rounding
 same = all(a[0] == b[0] and a[1] == b[1] and np.allclose(a[2], b[2], rtol=1e-12, atol=1e-15) for ra, rb in zip(single, threaded) for a, b in zip(ra, rb))
 maxdiff = max(abs(a[1] - b[1]) for ra, rb in zip(single, threaded) for a, b in zip(ra, rb))
 # mixed use afterwards: different poses per thread
@@ -58,7 +57,7 @@ for t in th:
 for t in th:
     t.join()
 mixed_ok = all(mixed[i][1] == single[i % len(poses)][i][1] for i in range(k))
-print(json.dumps({"pairs": k, "fused": os.environ.get("NIDREG_FUSED", ""), "cost_identical_grad_equal": bool(same), "max_cost_diff": float(maxdiff), "mixed_poses_ok": bool(mixed_ok),
+print(json.dumps({"pairs": k, "cost_identical_grad_equal": bool(same), "max_cost_diff": float(maxdiff), "mixed_poses_ok": bool(mixed_ok),
                   "us_per_multi_eval": round(1e6 * dt / len(poses), 1)}))
 for c in costs:
     c.close()

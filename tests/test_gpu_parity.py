@@ -922,3 +922,60 @@ def test_multi_pair_single_grid_matches_individual_evaluations(bins, monkeypatch
     assert okr and cr == solo[0](poses[3])[1] + solo[1](poses[3])[1] + solo[3](poses[3])[1]
     for c in costs + solo:
         c.close()
+
+
+@pytest.mark.parametrize("model", ["plumb_bob", "equirectangular"])
+def test_chunks_across_column_groups_match_one_group_per_chunk(model, monkeypatch):
+    """Round 4: on a cloud whose histogram columns are unequally full (every view-culled cloud) a chunk is a contiguous range of
+    records that may run across column groups; the workgroup flushes / re-zeroes its histogram tile, or switches to the next
+    staged G column, at each boundary (csrc/nid_kernels.hpp Segments, the looped kernel instantiations).  Against tables of
+    one group per chunk (NIDREG_MAX_SEGS=1, the rule of rounds 1-3): fixed-point histogram and cost bit for bit, gradient to
+    rounding; against the oracle: the usual bars.  SPLINE (WIDE and generic histogram kernels, gradient) and NEAREST."""
+    s = scene_for(model, n=120000, seed=31)
+    rng = np.random.default_rng(2)
+    col = np.minimum((s.intensities * 256).astype(int), 255)
+    keep_p = rng.uniform(0.05, 1.0, 256)
+    keep_p[rng.integers(0, 256, 40)] = 0.0  # empty columns too
+    keep = rng.uniform(size=col.shape[0]) < keep_p[col]
+    pts, ints = np.ascontiguousarray(s.points[keep]), np.ascontiguousarray(s.intensities[keep])
+    proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
+    x = s.T_camera_lidar_init
+    ref = oracle_lib.nid_cost(s.model, s.intrinsics, s.distortion, s.image_f64, pts, ints, 256, x, want_hist=True)
+    for tuning in ({}, {"lds_copies": 16}, {"target_blocks": 40}, {"target_blocks": 3000}):
+        seg = nid.NIDCost(proj, s.image_f64, pts, ints, 256, **tuning)
+        monkeypatch.setenv("NIDREG_MAX_SEGS", "1")
+        one = nid.NIDCost(proj, s.image_f64, pts, ints, 256, **tuning)
+        monkeypatch.delenv("NIDREG_MAX_SEGS")
+        if tuning.get("target_blocks", 0) != 3000:
+            assert seg.info()["segmented"] == 1 and one.info()["segmented"] == 0, (tuning, seg.info(), one.info())
+        for _ in range(2):  # both histogram buffers
+            ok0, c0, g0 = seg(x)
+            ok1, c1, g1 = one(x)
+            assert ok0 and ok1 and c0 == c1
+            h0, h1 = seg.histogram_fixed(), one.histogram_fixed()
+            assert np.array_equal(h0[0], h1[0]) and h0[1] == h1[1]
+            assert np.allclose(g0, g1, rtol=1e-11, atol=1e-14)
+        parity.check_cost(c0, ref["cost"])
+        parity.check_grad(g0, ref["grad"])
+        joint, hi, hp = seg.histograms()
+        parity.check_hist(joint, ref["hist"])
+        assert np.array_equal(hp, ref["hist_points"])
+        okc, cc, _ = seg(x, want_grad=False)
+        assert okc and cc == c0
+        seg.close()
+        one.close()
+    # NEAREST twin: integer histogram bit for bit against the oracle, with chunks across groups
+    max_fov = oracle_lib.estimate_camera_fov(s.model, s.intrinsics, s.distortion, s.width, s.height)
+    T = se3.to_matrix(x)
+    ref_cost, ref_hist = oracle_lib.cost_calculator_nid(s.model, s.intrinsics, s.distortion, s.image_u8, pts, ints, 256, max_fov, T, want_hist=True)
+    for bins, tb in ((256, 0), (256, 48), (16, 0)):
+        if bins != 256:
+            ref_cost, ref_hist = oracle_lib.cost_calculator_nid(s.model, s.intrinsics, s.distortion, s.image_u8, pts, ints, bins, max_fov, T, want_hist=True)
+        calc = nid.CostCalculatorNID(proj, s.image_u8, pts, ints, nid.NIDCostParams(bins), max_fov=max_fov, target_blocks=tb)
+        if bins == 256:
+            assert calc.info()["segmented"] == 1
+        for _ in range(2):
+            c = calc.calculate(T)
+            fx, inl, frac = calc.histogram_fixed()
+            assert np.array_equal(fx, ref_hist) and inl == ref_hist.sum() and abs(c - ref_cost) <= 1e-12
+        calc.close()

@@ -147,50 +147,73 @@ def test_column_group_partition_of_a_sharded_pair():
 
 
 def test_chunk_tables_fit_one_round_of_workgroups():
-    """The chunk table of a pass (csrc/nidreg.hip split_groups, through a test hook -- host arithmetic, no GPU): every record in
-    exactly one chunk, a chunk inside one column group, and never more chunks than the round holds when the groups allow it
-    -- also for column populations that are not uniform (a pair of a multi-pair set, a view-culled cloud): the rule without
-    the last step gave two pairs x 5M points 519 / 1031 workgroups for 512 / 1024 slots, and every pass a round plus one lone
-    chunk (round 3)."""
+    """The chunk table of a pass (csrc/nidreg.hip split_groups, through a test hook -- host arithmetic, no GPU).  Since round 4 a
+    chunk is a contiguous range of records that may run across column-group boundaries (the workgroup flushes its tile at each
+    one), and the table minimises the longest chunk under the cost model  cost = sum over segments of (overhead + records):
+    every record in exactly one chunk, `group` = the group of the chunk's first record, never more chunks than the round
+    holds, and no chunk costlier than the mean cost plus what one segment may add -- also for column populations that are
+    not uniform (a pair of a multi-pair set, a view-culled cloud: the clouds `calibrate` really evaluates)."""
     import ctypes
 
     from direct_visual_lidar_calibration_amd import _lib
 
     lib = _lib.load()
-    lib.nidreg_debug_chunk_table.argtypes = [ctypes.POINTER(ctypes.c_int64), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32), ctypes.c_int]
+    lib.nidreg_debug_chunk_table.argtypes = [ctypes.POINTER(ctypes.c_int64), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32), ctypes.c_int]
 
-    def table(counts, target, threads, pair=-1):
+    def table(counts, target, overhead, pair=-1, max_segs=4):
         g = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
         cap = 4 * (len(counts) + target) + 16
         rows = (ctypes.c_uint32 * (4 * cap))()
-        n = lib.nidreg_debug_chunk_table(g.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), len(counts), target, threads, pair, rows, cap)
+        n = lib.nidreg_debug_chunk_table(g.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), len(counts), target, overhead, max_segs, pair, rows, cap)
         assert 0 <= n <= cap
         return np.array(rows[: 4 * n], dtype=np.int64).reshape(n, 4), g
 
+    def chunk_cost(start, count, g, overhead):
+        """segments the chunk [start, start + count) is cut into by the group offsets g, and its cost"""
+        lo = np.searchsorted(g, start, side="right") - 1
+        hi = np.searchsorted(g, start + count, side="left")
+        segs = sum(1 for k in range(lo, hi) if min(g[k + 1], start + count) > max(g[k], start))
+        return segs, segs * overhead + count
+
     rng = np.random.default_rng(11)
-    cases = [(np.full(256, 39062), 1024, 256), (np.full(256, 39062), 512, 512)]  # cfg 2: exactly one round, as before
-    cases += [(rng.binomial(40000, 0.5, 256) + rng.integers(-600, 600, 256), t, th) for t, th in ((512, 256), (256, 512), (1024, 256))]  # a pair of a multi-pair set
+    cases = [(np.full(256, 39062), 1024, 384), (np.full(256, 39062), 512, 1024)]  # cfg 2
+    cases += [(rng.binomial(40000, 0.5, 256) + rng.integers(-600, 600, 256), t, ov) for t, ov in ((512, 384), (256, 1024), (1024, 384))]  # a pair of a multi-pair set
     culled = rng.integers(0, 60000, 256)
     culled[rng.integers(0, 256, 100)] = 0
-    cases += [(culled, 1024, 256), (culled, 512, 512), (culled, 64, 256), (np.array([5]), 1024, 256), (np.zeros(16, dtype=np.int64), 1024, 256), (rng.integers(0, 300, 16), 1024, 256)]
-    for counts, target, threads in cases:
-        for pair in (-1, 3):
-            rows, g = table(counts, target, threads, pair)
+    cases += [(culled, 1024, 384), (culled, 512, 1024), (culled, 64, 384), (np.array([5]), 1024, 384), (np.zeros(16, dtype=np.int64), 1024, 384), (rng.integers(0, 300, 16), 1024, 384),
+              (rng.integers(0, 40, 256), 1024, 1024), (culled, 1024, 0)]
+    for counts, target, overhead in cases:
+        for pair, max_segs in ((-1, 4), (3, 4), (-1, 1)):
+            rows, g = table(counts, target, overhead, pair, max_segs)
+            n_rec = int(g[-1])
             nonempty = int(np.count_nonzero(counts))
-            assert len(rows) <= max(target, nonempty), (len(rows), target, nonempty)
-            assert len(rows) >= nonempty
-            covered = np.zeros(int(g[-1]), dtype=np.int32)
+            assert len(rows) <= max(target, -(-nonempty // max_segs)) and (len(rows) > 0) == (n_rec > 0)  # (a chunk holds at most max_segs groups)
+            covered = np.zeros(n_rec, dtype=np.int32)
+            costs = []
+            slot = 0  # Chunk::pad = pair | (segments in the table's earlier chunks) << 8: one gradient partial per segment, in table order
             for k, (start, count, group, pad) in enumerate(rows):
-                assert count > 0 and g[group] <= start and start + count <= g[group + 1]
-                assert (start - g[group]) % 64 == 0
+                assert count > 0 and g[group] <= start < g[group + 1]  # the group of the chunk's first record
+                if start > g[group]:
+                    assert (start - g[group]) % 64 == 0  # cuts inside a group fall on whole waves
                 covered[start : start + count] += 1
-                assert pad == (0 if pair < 0 else (pair | (k << 8)))
+                assert pad == ((0 if pair < 0 else pair) | (slot << 8))
+                segs, cost = chunk_cost(start, count, g, overhead)
+                assert 1 <= segs <= max_segs  # max_segs = 1: a chunk inside one column group, as in rounds 1-3 (kernels whose tile spans several columns)
+                slot += segs
+                costs.append(cost)
             assert np.all(covered == 1)
-            if len(rows):
-                # even split: the chunks of one group differ by less than one 64-record step (the last takes the remainder)
-                for grp in np.unique(rows[:, 2]):
-                    c = rows[rows[:, 2] == grp, 1]
-                    assert c.max() - c.min() < 64 * len(c) + 64
-    # the uniform cloud keeps the table it always had
-    rows, _ = table(np.full(256, 39062), 1024, 256)
+            if len(rows) and max_segs > 1:
+                nonempty = int(np.count_nonzero(counts))
+                # the longest chunk: no worse than an even share of the total cost plus one segment's overhead and rounding
+                # (a lower bound on any table of `target` chunks is (records + nonempty * overhead) / target)
+                # (+5 %: a chunk that reaches its segment limit closes early and the others take up the slack)
+                bound = 1.05 * (n_rec + (nonempty + target) * overhead) / target + overhead + 128
+                assert max(costs) <= bound, (max(costs), bound, len(rows), target)
+    # the uniform cloud keeps the table it always had: four equal parts per column
+    rows, _ = table(np.full(256, 39062), 1024, 384)
     assert len(rows) == 1024 and rows[:, 1].max() <= 9792
+    rows, _ = table(np.full(256, 39062), 512, 1024)
+    assert len(rows) == 512 and rows[:, 1].max() <= 19584
+    # a view-culled cloud: the longest chunk stays within a few per cent of the mean, where whole parts per column left 3/4 ... 3/2
+    rows, g = table(culled, 1024, 384)
+    assert rows[:, 1].max() <= 1.08 * culled.sum() / 1024 + 64, (rows[:, 1].max(), culled.sum() / 1024)

@@ -54,12 +54,34 @@ def test_no_spline_kernel_uses_scratch(kernel_metadata):
     _, meta = kernel_metadata
     for name, m in {**_find(meta, "k_spline_hist"), **_find(meta, "k_spline_grad")}.items():
         assert m["vgpr"] <= 168, (name, m)  # at least three waves per SIMD for every camera model
+        looped = re.search(r"Lb1EEEv", name) is not None  # template <MODEL, Rec, real, WIDE | GW1, MULTI, SEG>: SEG = the segment loop
         if "k_spline_gradILi4E" in name:
             # the `atan` model (generic Dual3 forward mode) is held at three waves per SIMD by its launch bounds and may park a
             # few registers in scratch outside the point loop
             assert m["vgpr_spill"] <= 8 and m["scratch"] <= 64, (name, m)
+        elif looped:
+            # the looped (SEG) instantiations on float records are compiled for four waves per SIMD and may park one or two
+            # registers in scratch OUTSIDE the point loop (checked below); the double-record ones are left alone
+            assert m["vgpr_spill"] <= 2 and m["scratch"] <= 16, (name, m)
         else:
+            # the straight-line kernels (every table whose chunks lie inside one column group: the headline) are those of round 3
             assert m["vgpr_spill"] == 0 and m["scratch"] == 0, (name, m)
+
+
+def test_looped_kernels_keep_scratch_out_of_the_point_loop(kernel_metadata):
+    """Round 4: chunks may run across column groups; the SEG instantiations wrap the point loop in a segment loop.  Whatever
+    they spill must stay outside the innermost loops (the 16 taps per point)."""
+    text, meta = kernel_metadata
+    for name, m in {**_find(meta, "k_spline_hist"), **_find(meta, "k_spline_grad")}.items():
+        if not m["scratch"] or "ILi4E" in name:
+            continue
+        start = text.index("\n" + name + ":")
+        body = text[start:text.index(".Lfunc_end", start)]
+        # basic blocks that hold tap code: many LDS operations
+        for block in re.split(r"\n\.LBB\d+_\d+:", body):
+            lds = len(re.findall(r"^\s+ds_(add_u64|read_b64|add_rtn_u64)", block, flags=re.M))
+            if lds >= 16:
+                assert "scratch_" not in block, name
 
 
 def test_every_model_but_atan_fits_four_waves_per_simd_in_the_gradient_pass(kernel_metadata):
@@ -72,7 +94,7 @@ def test_every_model_but_atan_fits_four_waves_per_simd_in_the_gradient_pass(kern
 
 def test_wave_sums_use_dpp_not_the_lds_crossbar(kernel_metadata):
     text, _ = kernel_metadata
-    start = text.index("k_spline_gradILi0ENS_5Rec32EdLb1ELb0E")
+    start = text.index("k_spline_gradILi0ENS_5Rec32EdLb1ELb0ELb0E")
     body = text[start:text.index(".Lfunc_end", start)]
     assert "row_bcast:31" in body and "ds_bpermute" not in body
 
@@ -89,7 +111,7 @@ def test_spline_kernels_use_global_not_flat_memory_instructions(kernel_metadata)
     pointer, and every record load, image gather and histogram flush through it became a FLAT instruction (64-bit lane
     addresses, counted on lgkmcnt as well as vmcnt: the waits for the LDS atomics also waited for the record prefetch).
     as_global() (nid_multi.hpp) restores the single-pair kernels' forms.  The one FLAT load the gradient kernels may keep is
-    phi(q_r), read from LDS or global memory through one pointer in the prologue; k_fused is not covered."""
+    phi(q_r), read from LDS or global memory through one pointer in the prologue."""
     text, meta = kernel_metadata
     checked = 0
     for name in {**_find(meta, "k_spline_hist"), **_find(meta, "k_spline_grad")}:
@@ -100,8 +122,8 @@ def test_spline_kernels_use_global_not_flat_memory_instructions(kernel_metadata)
         # a handful per workgroup) and the phi(q_r) load; not allowed: record loads (dwordx3 / dwordx4) and the flush's atomics
         hot = [f for f in flat if f in ("flat_load_dwordx3", "flat_load_dwordx4") or f.startswith("flat_atomic_add_x2")]
         assert not hot, (name, hot)
-        if "Lb1EEEv" in name and "k_spline_hist" in name:  # the multi-pair histogram kernel: nothing FLAT at all
+        if re.search(r"Lb1ELb[01]EEEv", name) and "k_spline_hist" in name:  # the multi-pair histogram kernels (<.., MULTI = true, SEG>): nothing FLAT at all
             assert not flat, (name, flat)
         assert re.search(r"^\s+global_load_dwordx4\s+v\[\d+:\d+\], v\d+, s\[\d+:\d+\]", body, flags=re.M), name  # SGPR base + 32-bit lane offset
         checked += 1
-    assert checked >= 96  # 6 models x 2 record types x (WIDE / GW1) x (single / multi) x 2 passes
+    assert checked >= 168  # 6 models x 2 record types x (WIDE / generic) x (single / multi) x (straight / looped) histogram kernels + the gradient kernels (no looped generic one)

@@ -42,7 +42,7 @@ for _ in range(1 if os.environ.get("RUN_SCENE_QUICK") else 5):
     cost.eval_batch(block[:8] if os.environ.get("RUN_SCENE_QUICK") else block)
     wb.append((time.perf_counter() - t0) * 1e3 / (8 if os.environ.get("RUN_SCENE_QUICK") else len(block)))
 wall_batch_ms = float(np.median(wb))
-# the whole evaluation between two HIP events, whichever route runs it (one fused kernel with NIDREG_FUSED=1)
+# the whole evaluation between two HIP events
 cost.set_timing(2)
 whole = []
 for k in range(max(steps, 10)):
@@ -59,4 +59,4 @@ for k in range(steps):
     if k >= 2:
         for key, v in cost.timing_ms().items():
             acc.setdefault(key, []).append(v)
-print(json.dumps({"prec": prec, "bins": bins, "info": cost.info(), "kernel_ms": {k: round(float(np.mean(v)), 4) for k, v in acc.items()}, "wall_ms": round(wall_ms, 4), "wall_batch_ms": round(wall_batch_ms, 4), "whole_eval_event_ms": round(whole_ms, 4), "fused_env": os.environ.get("NIDREG_FUSED", ""), "last_cost": c, "last_grad": [float(v) for v in g], "evals_per_s": round(1e3 / float(np.mean(acc["total"])), 1) if "total" in acc else None}))
+print(json.dumps({"prec": prec, "bins": bins, "info": cost.info(), "kernel_ms": {k: round(float(np.mean(v)), 4) for k, v in acc.items()}, "wall_ms": round(wall_ms, 4), "wall_batch_ms": round(wall_batch_ms, 4), "whole_eval_event_ms": round(whole_ms, 4), "last_cost": c, "last_grad": [float(v) for v in g], "evals_per_s": round(1e3 / float(np.mean(acc["total"])), 1) if "total" in acc else None}))

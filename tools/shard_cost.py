@@ -4,7 +4,7 @@ own host thread on its own hardware queue like shards on different devices): wit
 is negligible, the time per evaluation beyond the plain handle's is the protocol -- the announce at the end of the histogram
 kernel, k_entropy_owned's flag wait and push, k_entropy_gather's flag wait, one more launch, the host-thread hand-off.
 Also the 10M-point case for the record (there the shards' kernels share the one GPU, so nothing is gained -- it only shows
-the protocol at full size).  The plain handle is measured on both routes (one fused kernel / three kernels).
+the protocol at full size).
 Usage: shard_cost.py [bins]"""
 import json
 import os
@@ -28,8 +28,7 @@ for label, n_points in (("tiny", 4096), ("10M", 10_000_000)):
     rng = np.random.default_rng(3)
     poses = np.ascontiguousarray([synth.random_pose_near(s.T_camera_lidar_true, rng) for _ in range(40)])
     row = {}
-    for n in (0, 1, 2, 3, 4, 8):
-        os.environ["NIDREG_FUSED"] = "1" if n == 0 else "0"  # n = 0: the plain handle's one-launch route; 1: its three-kernel route
+    for n in (1, 2, 3, 4, 8):
         c = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, bins, devices=None if n <= 1 else [0] * n)
         c.eval_batch(poses[:5])
         ts = []
@@ -42,7 +41,7 @@ for label, n_points in (("tiny", 4096), ("10M", 10_000_000)):
             t0 = time.perf_counter()
             c.eval_batch(poses, want_grad=False)
             ts2.append((time.perf_counter() - t0) / len(poses))
-        row["plain_fused" if n == 0 else ("plain_three_kernels" if n == 1 else f"shards_{n}")] = {"us_per_eval_cost_grad": round(1e6 * float(np.median(ts)), 2), "us_per_eval_cost_only": round(1e6 * float(np.median(ts2)), 2), "cost0": float(costs[0])}
+        row["plain_three_kernels" if n == 1 else f"shards_{n}"] = {"us_per_eval_cost_grad": round(1e6 * float(np.median(ts)), 2), "us_per_eval_cost_only": round(1e6 * float(np.median(ts2)), 2), "cost0": float(costs[0])}
         c.close()
     out[label] = row
 print(json.dumps(out))
