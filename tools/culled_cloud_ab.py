@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """A/B of the chunk rule on a VIEW-CULLED cloud (the clouds `calibrate` really evaluates: visual_camera_calibration.cpp:201-206
 culls before every inner solve).  The rank equalisation makes the columns of the whole cloud equally full; the culled
-subset's columns are not, and the chunk rule of rounds 1-3 could give its tables a few workgroups more than one round holds
-(DESIGN.md section 4).  Builds the cost object with nidreg_create_from_cloud (device-resident cull + build) under
-NIDREG_CHUNKS_NO_FIT=1 (old rule) and without (split_groups' growth step), prints table sizes and microseconds per evaluation.
-Usage: culled_cloud_ab.py [points] [camera]"""
+subset's columns are not.  Builds the cost object with nidreg_create_from_cloud (device-resident cull + build) with chunk
+tables of one column group per chunk (NIDREG_MAX_SEGS=1: the constraint of rounds 1-3) and with chunks that may run across
+groups (round 4, csrc/nidreg.hip split_groups), prints table sizes, microseconds per evaluation, per-kernel event times and
+nanoseconds per kept point.
+Usage: culled_cloud_ab.py [points] [camera] [shift_m]"""
 import json
 import os
 import sys
@@ -18,32 +19,48 @@ from direct_visual_lidar_calibration_amd import nid, se3, synth  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 camera = sys.argv[2] if len(sys.argv) > 2 else "pinhole_1080p"
+shift = float(sys.argv[3]) if len(sys.argv) > 3 else 6.0
 s = synth.make_scene(camera, num_points=n, seed=20250525, device="cuda:0")
 proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
 # a cloud that covers more than the view, so that culling removes a non-uniform part of every column: the scene's points
-# plus a copy pushed sideways out of the image
-pts = np.concatenate([s.points, s.points + np.array([6.0, 0.0, 0.0, 0.0])])
+# plus a copy pushed sideways out of the image (float32-representable like PLY data, so the records stay 16 bytes)
+moved = (s.points + np.array([shift, 0.0, 0.0, 0.0])).astype(np.float32).astype(np.float64)
+pts = np.concatenate([s.points, moved])
 ints = np.concatenate([s.intensities, s.intensities[::-1]])
 cloud = nid.Cloud(pts, ints)
 T = se3.to_matrix(s.T_camera_lidar_init)
 rng = np.random.default_rng(5)
-poses = [synth.random_pose_near(s.T_camera_lidar_true, rng) for _ in range(40)]
-out = {}
-for label, env in (("old_rule", "1"), ("fit_one_round", None)):
+poses = np.ascontiguousarray([synth.random_pose_near(s.T_camera_lidar_true, rng) for _ in range(40)])
+out = {"camera": camera, "input_points": int(pts.shape[0])}
+ref = None
+for label, env in (("one_group_per_chunk", "1"), ("chunks_across_groups", None)):
     if env:
-        os.environ["NIDREG_CHUNKS_NO_FIT"] = env
+        os.environ["NIDREG_MAX_SEGS"] = env
     else:
-        os.environ.pop("NIDREG_CHUNKS_NO_FIT", None)
+        os.environ.pop("NIDREG_MAX_SEGS", None)
     cost = nid.NIDCost.from_cloud(proj, s.image_f64, cloud, 256, cull=(T, 0.0, True))
     info = cost.info()
-    for x in poses[:5]:
-        cost(x)
+    cost.eval_batch(poses[:5])
     ts = []
     for _ in range(10):
         t0 = time.perf_counter()
-        for x in poses:
-            cost(x)
+        ok, cs, gs = cost.eval_batch(poses)
         ts.append((time.perf_counter() - t0) / len(poses))
-    out[label] = {"kept_points": int(info.get("num_points", -1)), "num_chunks": int(info.get("num_chunks", -1)), "us_per_eval": round(1e6 * float(np.median(ts)), 2)}
+    cost.set_timing(True)
+    acc = {}
+    for x in poses[:12]:
+        cost(x)
+        for key, v in cost.timing_ms().items():
+            acc.setdefault(key, []).append(v)
+    cost.set_timing(False)
+    kept = int(info.get("num_points", -1))
+    us = 1e6 * float(np.median(ts))
+    out[label] = {"kept_points": kept, "record_bytes": int(info["record_bytes"]), "num_chunks": int(info.get("num_chunks", -1)), "segmented": [int(info["segmented"]), int(info["segmented_hist"])],
+                  "us_per_eval": round(us, 2), "ns_per_point": round(1e3 * us / max(kept, 1), 3), "kernel_us": {k: round(1e3 * float(np.mean(v[2:])), 2) for k, v in acc.items()}}
+    if ref is None:
+        ref = (cs.copy(), gs.copy())
+    else:
+        out["cost_bits_equal"] = bool(np.array_equal(ref[0], cs))
+        out["grad_max_rel_diff"] = float(np.max(np.abs(ref[1] - gs) / (np.abs(ref[1]) + 1e-300)))
     cost.close()
 print(json.dumps(out))
