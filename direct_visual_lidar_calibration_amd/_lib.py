@@ -65,7 +65,7 @@ EXPORTS = [
     "nidreg_eval_iso_multi", "nidreg_get_hist", "nidreg_get_hist_fixed", "nidreg_project", "nidreg_project_model", "nidreg_view_culling", "nidreg_hist_words", "nidreg_shard_hist",
     "nidreg_shard_entropy", "nidreg_shard_grad", "nidreg_shard_finish", "nidreg_set_timing", "nidreg_get_timing", "nidreg_get_info", "nidreg_last_error",
     "nidreg_version", "nidreg_colorizer_create", "nidreg_colorizer_update", "nidreg_colorizer_device_colors", "nidreg_colorizer_destroy", "nidreg_generate_lidar_image",
-    "nidreg_equalize_intensities", "nidreg_num_shards", "nidreg_shard_devices", "nidreg_trim", "nidreg_eval_batch",
+    "nidreg_equalize_intensities", "nidreg_num_shards", "nidreg_shard_devices", "nidreg_trim", "nidreg_eval_batch", "nidreg_submit", "nidreg_submit_iso", "nidreg_wait", "nidreg_eval_pipelined",
 ]
 
 _lib = None
@@ -93,6 +93,10 @@ def load():
     lib.nidreg_eval.argtypes = [ctypes.c_void_p, c_double_p, c_double_p, c_double_p]
     lib.nidreg_eval_iso.argtypes = [ctypes.c_void_p, c_double_p, c_double_p]
     lib.nidreg_eval_batch.argtypes = [ctypes.c_void_p, c_double_p, ctypes.c_int, c_double_p, c_double_p]
+    lib.nidreg_eval_pipelined.argtypes = [ctypes.c_void_p, c_double_p, ctypes.c_int, c_double_p, c_double_p]
+    lib.nidreg_submit.argtypes = [ctypes.c_void_p, c_double_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int64)]
+    lib.nidreg_submit_iso.argtypes = [ctypes.c_void_p, c_double_p, ctypes.POINTER(ctypes.c_int64)]
+    lib.nidreg_wait.argtypes = [ctypes.c_void_p, ctypes.c_int64, c_double_p, c_double_p]
     lib.nidreg_eval_multi.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, c_double_p, c_double_p, c_double_p, c_double_p]
     lib.nidreg_eval_iso_multi.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, c_double_p, c_double_p]
     lib.nidreg_get_hist.argtypes = [ctypes.c_void_p, c_double_p, c_double_p, c_double_p]

@@ -339,6 +339,13 @@ struct Segments {
   }
 };
 
+// Between two segments: wait for this wave's outstanding global stores / atomics (the flush, the partial sums).  gfx9 counts
+// loads and stores on the one vmcnt and completes them out of order with respect to each other, so with stores possibly in
+// flight on the segment loop's back edge the compiler has to wait for vmcnt(0) at EVERY use of a prefetched record -- the
+// four record loads of an iteration are then no longer consumed one by one (measured: the looped histogram kernel +20-30 %).
+// An s_waitcnt it can see on that edge gives the point loop its vmcnt(3) / (2) / (1) back.
+__device__ __forceinline__ void drain_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }  // vmcnt(0), expcnt / lgkmcnt untouched
+
 // The pass as a device function.  `smem` = the workgroup's dynamic LDS (tile at its start); kT = threads per workgroup.
 template <int MODEL, typename Rec, typename real, bool WIDE, bool SEG, int kT>
 __device__ __forceinline__ void spline_hist_body(
@@ -362,10 +369,7 @@ __device__ __forceinline__ void spline_hist_body(
 
   const int tid = threadIdx.x;
   stamp_begin();
-  for (int k = tid; k < tile_w; k += kT) tile[k] = 0;
   if (tid == 0) *s_inl = 0;
-  if (tid < GW) s_colsum[tid] = 0;
-  __syncthreads();
 
   const real fW = real(W), fH = real(H);
   const uint32_t lane_copy = uint32_t(tid) & cmask;
@@ -374,6 +378,11 @@ __device__ __forceinline__ void spline_hist_body(
 
   Segments seg(gend, ch);
   for (;;) {
+    // a zeroed tile for every segment (coalesced stores; zeroing inside the flush below -- 32 more LDS addresses per thread in the
+    // WIDE kernel -- took the looped kernel from 93 to 161 VGPRs)
+    for (int k = tid; k < tile_w; k += kT) tile[k] = 0;
+    if (tid < GW) s_colsum[tid] = 0;
+    __syncthreads();
     const uint32_t seg_end = SEG ? seg.seg_end() : seg.end;
     const uint32_t cnt = seg_end - seg.pos;  // >= 1
     const uint32_t col0 = seg.g * uint32_t(GW);
@@ -459,7 +468,6 @@ __device__ __forceinline__ void spline_hist_body(
         }
       }
     }
-    const bool more = SEG && seg.pos + cnt < seg.end;  // uniform: another segment follows -> the flush leaves a zeroed tile behind
     __syncthreads();
 
     // flush the tile: contiguous in the [bin_points][bin_image] device layout
@@ -467,19 +475,15 @@ __device__ __forceinline__ void spline_hist_body(
     for (int k = tid; k < tile_n; k += kT) {
       u64 vv = 0;
       for (uint32_t j = 0; j <= cmask; j++) vv += tile[(uint32_t(k) << cshift) + ((j + uint32_t(k)) & cmask)];  // rotated: conflict-free reads
-      if (more)
-        for (uint32_t j = 0; j <= cmask; j++) tile[(uint32_t(k) << cshift) + ((j + uint32_t(k)) & cmask)] = 0;
       if (vv) {
         atomicAdd(&dst[k], vv);
         atomicAdd(&s_colsum[k / B], vv);
       }
     }
     __syncthreads();
-    if (tid < GW && s_colsum[tid]) {
-      atomicAdd(&hist[size_t(B) * size_t(B) + kTailWords + col0 + uint32_t(tid)], s_colsum[tid]);
-      if (more) s_colsum[tid] = 0;  // the next flush's LDS adds come after two more barriers
-    }
+    if (tid < GW && s_colsum[tid]) atomicAdd(&hist[size_t(B) * size_t(B) + kTailWords + col0 + uint32_t(tid)], s_colsum[tid]);
     if (!SEG || !seg.advance(seg_end)) break;
+    drain_vmem();
   }
 
   // inlier count: wave-reduce, one LDS add per wave, one global add per workgroup
@@ -493,10 +497,10 @@ __device__ __forceinline__ void spline_hist_body(
 // LDS bytes spline_hist_body uses (nidreg.hip sizes lds_hist the same way)
 __host__ __device__ __forceinline__ size_t spline_hist_lds_bytes(int B, int GW, int cshift) { return (size_t(GW) * size_t(B) * 8 << cshift) + size_t(GW) * 8 + 16; }
 
-// waves per SIMD the WIDE kernel is compiled for: two 8-wave workgroups per CU need <= 128 VGPRs.  The straight-line kernels
-// land there by themselves; the looped ones are told to (0-2 spilled registers outside the point loop) -- except the `atan`
-// model, whose Dual3 forward mode holds ~164 either way.
-constexpr int hist_min_waves(int model, bool wide, bool seg, bool rec32) { return (wide && seg && rec32 && model != MODEL_ATAN) ? 4 : 1; }
+// waves per SIMD the WIDE kernel is compiled for: two 8-wave workgroups per CU need <= 128 VGPRs; both the straight-line and
+// the looped kernels land there by themselves (the `atan` model's Dual3 forward mode holds ~164 either way), so no bound is
+// imposed (a forced bound made the compiler give up the four-deep record prefetch: +20-30 % on the looped kernel).
+constexpr int hist_min_waves(int, bool, bool, bool) { return 1; }
 template <int MODEL, typename Rec, typename real, bool WIDE, bool MULTI, bool SEG>
 __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads, hist_min_waves(MODEL, WIDE, SEG, sizeof(Rec) == sizeof(Rec32))) void k_spline_hist(
   const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint32_t* __restrict__ gend, const uint8_t* __restrict__ img, int pitch, int W, int H, PoseParams<real> pose, CamParams<real> cam, int B,
@@ -547,16 +551,16 @@ __global__ __launch_bounds__(kThreads) void k_nearest_hist(
     img = as_global(e.img);
     hist = as_global(e.hist_buf[dyn.cur[pair]]);
   }
-  for (int k = tid; k < tile_w; k += kThreads) tile[k] = 0;
   if (tid == 0) *s_inl = 0;
-  if (tid < GW) s_colsum[tid] = 0;
-  __syncthreads();
 
   const real fW = real(W), fH = real(H);
   unsigned int inl = 0;
 
   Segments seg(gend, ch);
   for (;;) {
+    for (int k = tid; k < tile_w; k += kThreads) tile[k] = 0;  // a zeroed tile for every segment
+    if (tid < GW) s_colsum[tid] = 0;
+    __syncthreads();
     const uint32_t seg_end = SEG ? seg.seg_end() : seg.end;
     const uint32_t cnt = seg_end - seg.pos;
     const uint32_t col0 = seg.g * uint32_t(GW);
@@ -598,26 +602,21 @@ __global__ __launch_bounds__(kThreads) void k_nearest_hist(
         }
       }
     }
-    const bool more = SEG && seg.pos + cnt < seg.end;  // another segment follows: the flush leaves a zeroed tile behind
     __syncthreads();
 
     u64* dst = hist + size_t(seg.g) * size_t(tile_n);
     for (int k = tid; k < tile_n; k += kThreads) {
       u64 vv = 0;
       for (uint32_t j = 0; j <= cmask; j++) vv += tile[(uint32_t(k) << cshift) + ((j + uint32_t(k)) & cmask)];
-      if (more)
-        for (uint32_t j = 0; j <= cmask; j++) tile[(uint32_t(k) << cshift) + ((j + uint32_t(k)) & cmask)] = 0;
       if (vv) {
         atomicAdd(&dst[k], vv);
         atomicAdd(&s_colsum[k / B], vv);
       }
     }
     __syncthreads();
-    if (tid < GW && s_colsum[tid]) {
-      atomicAdd(&hist[size_t(B) * size_t(B) + kTailWords + col0 + uint32_t(tid)], s_colsum[tid]);
-      if (more) s_colsum[tid] = 0;
-    }
+    if (tid < GW && s_colsum[tid]) atomicAdd(&hist[size_t(B) * size_t(B) + kTailWords + col0 + uint32_t(tid)], s_colsum[tid]);
     if (!SEG || !seg.advance(seg_end)) break;
+    drain_vmem();
   }
 
   const unsigned int winl = wave_sum(inl);
@@ -1243,6 +1242,7 @@ __global__ __launch_bounds__(kThreads, grad_min_waves(MODEL, SEG, sizeof(Rec) ==
     grad_reduce_store<kThreads>(acc, s_red, partials, slot, nslots);
     if (!SEG || !seg.advance(seg_end)) break;
     slot++;
+    drain_vmem();
     __syncthreads();  // every wave has left the point loop (and s_red) before the tile changes
     for (int k = tid; k < B; k += kThreads) gtile[k] = s_stage[s * B + k];
     __syncthreads();

@@ -115,6 +115,18 @@ struct nidreg_handle {
   double seq = 0.0;                    // completion tag of the evaluation in flight (host-mapped polling)
   uint64_t seq_bits = 0;               // its bit pattern (what the acquire load of the tag compares against)
   unsigned int evals_since_reap = 0;
+  // asynchronous evaluations (nidreg_submit / nidreg_wait): a ring of host-mapped result blocks, one per evaluation in flight
+  double* h_ring = nullptr;   // [kAsyncDepth][NIDREG_OUT_DOUBLES], pinned, host-mapped (allocated at the first submit)
+  double* d_ring = nullptr;   // its device address
+  struct Pending {
+    double seq = 0.0;        // 0: free
+    uint64_t bits = 0;
+    bool grad = false, done = false, counted = false;  // done: evaluated synchronously inside nidreg_submit (sharded handles, ext_out); counted: holds an in-flight count of its device
+    int rc = 0;
+    double res[8] = {0};
+  };
+  Pending pending[8];
+  int async_outstanding = 0;
 
   size_t lds_hist = 0, lds_grad = 0, lds_entropy = 0;
   int64_t hist_words = 0;
@@ -191,6 +203,7 @@ void free_handle(nidreg_handle* h) {
   if (h->own_out && h->d_out) (void)hipFree(h->d_out);
   if (h->d_scratch) (void)hipFree(h->d_scratch);
   if (h->h_out) (void)hipHostFree(h->h_out);
+  if (h->h_ring) (void)hipHostFree(h->h_ring);
   for (int i = 0; i < 6; i++)
     if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -433,12 +446,15 @@ int eval_launch(nidreg_handle* h, const double* se3, bool want_grad, bool alone 
   return eval_launch_rest(h, want_grad, alone);
 }
 
-int eval_finish_on(nidreg_handle* h, hipStream_t stream, double* cost, double* grad7);
-int eval_finish(nidreg_handle* h, double* cost, double* grad7) { return eval_finish_on(h, h->stream, cost, grad7); }
+int eval_finish_block(nidreg_handle* h, hipStream_t stream, const double* block, uint64_t seq_bits, bool polled, double* cost, double* grad7);
 // `stream` = the stream the evaluation's kernels were queued on (the handle's own, or a multi-pair group's)
-int eval_finish_on(nidreg_handle* h, hipStream_t stream, double* cost, double* grad7) {
+int eval_finish_on(nidreg_handle* h, hipStream_t stream, double* cost, double* grad7) { return eval_finish_block(h, stream, h->h_out, h->seq_bits, h->d_out_host != nullptr, cost, grad7); }
+int eval_finish(nidreg_handle* h, double* cost, double* grad7) { return eval_finish_on(h, h->stream, cost, grad7); }
+// `block` = the host-mapped result block the evaluation writes (the handle's own, or a slot of its asynchronous ring) and
+// `seq_bits` the completion tag expected in its last word
+int eval_finish_block(nidreg_handle* h, hipStream_t stream, const double* block, uint64_t seq_bits, bool polled, double* cost, double* grad7) {
   HIP_TRY(hipSetDevice(h->device));
-  if (h->d_out_host) {
+  if (polled) {
     // the finalising workgroup wrote the results and then this evaluation's tag into host-mapped memory:
     // poll the tag (a few us cheaper than hipStreamSynchronize); look at the stream now and then so that a
     // faulted kernel cannot hang the caller, and so the runtime can retire finished commands
@@ -447,8 +463,8 @@ int eval_finish_on(nidreg_handle* h, hipStream_t stream, double* cost, double* g
     // to every 100-200 us evaluation): `pause` spinning for the first 2 ms -- every evaluation up to ~100M points --,
     // then 50 us naps, so that N in-flight handles (one OpenMP thread per pair in the reference) do not burn N cores
     // through a long wait; the stream is looked at once per millisecond so that a faulted kernel cannot hang the caller.
-    const double* flag = h->h_out + 15;
-    auto tag_seen = [&]() { return __atomic_load_n(reinterpret_cast<const uint64_t*>(flag), __ATOMIC_ACQUIRE) == h->seq_bits; };
+    const double* flag = block + 15;
+    auto tag_seen = [&]() { return __atomic_load_n(reinterpret_cast<const uint64_t*>(flag), __ATOMIC_ACQUIRE) == seq_bits; };
     if (!tag_seen()) {
       struct timespec t0;
       clock_gettime(CLOCK_MONOTONIC, &t0);
@@ -484,10 +500,10 @@ int eval_finish_on(nidreg_handle* h, hipStream_t stream, double* cost, double* g
   } else {
     HIP_TRY(hipStreamSynchronize(stream));
   }
-  if (cost) *cost = h->h_out[0];
+  if (cost) *cost = block[0];
   if (grad7)
-    for (int k = 0; k < 7; k++) grad7[k] = h->h_out[1 + k];
-  return h->h_out[8] != 0.0 ? NIDREG_FALSE : NIDREG_OK;
+    for (int k = 0; k < 7; k++) grad7[k] = block[1 + k];
+  return block[8] != 0.0 ? NIDREG_FALSE : NIDREG_OK;
 }
 
 int iso_launch(nidreg_handle* h, const double* T) {
@@ -1765,6 +1781,92 @@ int nidreg_eval(nidreg_handle* h, const double* se3, double* cost, double* grad7
   return eval_finish(h, cost, grad7);
 }
 
+// ---- asynchronous evaluations: nidreg_submit* queue the kernels of one evaluation and return, nidreg_wait collects.  The
+// kernels of consecutive evaluations of a handle run back to back on its stream (the histogram double buffer and the
+// scratch are only ever touched in stream order), each evaluation writes its results and completion tag into its own block
+// of a host-mapped ring, and the host turnaround between evaluations (7-14 us of every synchronous one) disappears for a
+// caller that holds several independent poses: Nelder-Mead's initial simplex (nelder_mead.hpp:32-57), multi-start, batches.
+constexpr int kAsyncDepth = 8;
+static int async_submit(nidreg_handle* h, int mode, const double* pose, bool want_grad, int64_t* ticket) {
+  if (!h || !pose || !ticket) return fail(NIDREG_ERR_INVALID, "nidreg_submit: null argument");
+  if (h->mode != mode) return fail(NIDREG_ERR_INVALID, mode == NIDREG_MODE_SPLINE ? "nidreg_submit: handle was created in NEAREST mode" : "nidreg_submit_iso: handle was created in SPLINE mode");
+  if (h->async_outstanding >= kAsyncDepth) return fail(NIDREG_ERR_INVALID, "nidreg_submit: too many evaluations in flight on this handle (8): nidreg_wait first");
+  if (h->set || !h->d_out_host || h->timing) {
+    // a handle sharded over several GPUs (its shards hand-shake inside the kernels), results in a caller's buffer, or
+    // per-kernel timing: evaluated here and now, the ticket just carries the results
+    bump_seq(h);  // a ticket of its own (the evaluation below takes the next sequence numbers)
+    const int64_t t = int64_t(h->seq);
+    nidreg_handle::Pending& p = h->pending[t % kAsyncDepth];
+    if (p.seq != 0.0) return fail(NIDREG_ERR_INVALID, "nidreg_submit: ticket ring collision (wait for the oldest evaluation first)");
+    double c = 0.0, g[7] = {0};
+    const int rc = mode == NIDREG_MODE_SPLINE ? nidreg_eval(h, pose, &c, want_grad ? g : nullptr) : nidreg_eval_iso(h, pose, &c);
+    if (rc < 0) return rc;
+    p.seq = double(t);
+    p.done = true;
+    p.counted = false;
+    p.rc = rc;
+    p.grad = want_grad;
+    p.res[0] = c;
+    for (int k = 0; k < 7; k++) p.res[1 + k] = g[k];
+    h->async_outstanding++;
+    *ticket = t;
+    return NIDREG_OK;
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  if (!h->h_ring) {
+    HIP_TRY(hipHostMalloc(&h->h_ring, size_t(kAsyncDepth) * NIDREG_OUT_DOUBLES * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(h->h_ring, 0, size_t(kAsyncDepth) * NIDREG_OUT_DOUBLES * sizeof(double));
+    void* dp = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&dp, h->h_ring, 0));
+    h->d_ring = static_cast<double*>(dp);
+  }
+  // the launch helpers write to h->d_out_host with tag h->seq: point them at this evaluation's ring block for the launch
+  const int64_t t = int64_t(h->seq) + 1;
+  nidreg_handle::Pending& p = h->pending[t % kAsyncDepth];
+  if (p.seq != 0.0) return fail(NIDREG_ERR_INVALID, "nidreg_submit: ticket ring collision (wait for the oldest evaluation first)");
+  double* const own = h->d_out_host;
+  h->d_out_host = h->d_ring + size_t(t % kAsyncDepth) * NIDREG_OUT_DOUBLES;
+  // alone on the device = nothing in flight but this handle's own earlier submissions (they run before it, in stream order)
+  const bool alone = h->device >= 0 && h->device < NIDREG_MAX_DEVICES && g_inflight[h->device].fetch_add(1, std::memory_order_acq_rel) == h->async_outstanding;
+  const int rc = mode == NIDREG_MODE_SPLINE ? eval_launch(h, pose, want_grad, alone) : iso_launch(h, pose);
+  h->d_out_host = own;
+  if (rc) {
+    if (h->device >= 0 && h->device < NIDREG_MAX_DEVICES) g_inflight[h->device].fetch_sub(1, std::memory_order_acq_rel);
+    return rc;
+  }
+  p.seq = h->seq;  // == t
+  p.bits = h->seq_bits;
+  p.grad = want_grad;
+  p.done = false;
+  p.counted = true;
+  h->async_outstanding++;
+  *ticket = t;
+  return NIDREG_OK;
+}
+
+int nidreg_submit(nidreg_handle* h, const double* se3, int want_grad, int64_t* ticket) { return async_submit(h, NIDREG_MODE_SPLINE, se3, want_grad != 0, ticket); }
+int nidreg_submit_iso(nidreg_handle* h, const double* T, int64_t* ticket) { return async_submit(h, NIDREG_MODE_NEAREST, T, false, ticket); }
+
+int nidreg_wait(nidreg_handle* h, int64_t ticket, double* cost, double* grad7) {
+  if (!h || ticket <= 0) return fail(NIDREG_ERR_INVALID, "nidreg_wait: bad argument");
+  nidreg_handle::Pending& p = h->pending[ticket % kAsyncDepth];
+  if (p.seq != double(ticket)) return fail(NIDREG_ERR_INVALID, "nidreg_wait: unknown ticket (already collected, or never issued by this handle)");
+  int rc;
+  if (p.done) {
+    rc = p.rc;
+    if (cost) *cost = p.res[0];
+    if (grad7 && p.grad)
+      for (int k = 0; k < 7; k++) grad7[k] = p.res[1 + k];
+  } else {
+    rc = eval_finish_block(h, h->stream, h->h_ring + size_t(ticket % kAsyncDepth) * NIDREG_OUT_DOUBLES, p.bits, true, cost, p.grad ? grad7 : nullptr);
+  }
+  if (p.counted && h->device >= 0 && h->device < NIDREG_MAX_DEVICES) g_inflight[h->device].fetch_sub(1, std::memory_order_acq_rel);
+  p = nidreg_handle::Pending();
+  h->async_outstanding--;
+  if (h->mode == NIDREG_MODE_NEAREST && rc >= 0) rc = NIDREG_OK;  // CostCalculatorNID has no finite check
+  return rc;
+}
+
 int nidreg_eval_batch(nidreg_handle* h, const double* se3s, int n, double* costs, double* grads7) {
   if (!h || !se3s || n < 0) return fail(NIDREG_ERR_INVALID, "nidreg_eval_batch: bad argument");
   int worst = NIDREG_OK;
@@ -1774,6 +1876,39 @@ int nidreg_eval_batch(nidreg_handle* h, const double* se3s, int n, double* costs
     if (rc < 0) return rc;
     if (rc != NIDREG_OK) worst = rc;
     if (costs) costs[i] = c;
+  }
+  return worst;
+}
+
+// n INDEPENDENT poses through the submit / wait pair: up to kAsyncDepth evaluations queued ahead of the one being collected
+int nidreg_eval_pipelined(nidreg_handle* h, const double* se3s, int n, double* costs, double* grads7) {
+  if (!h || !se3s || n < 0) return fail(NIDREG_ERR_INVALID, "nidreg_eval_pipelined: bad argument");
+  if (h->async_outstanding != 0) return fail(NIDREG_ERR_INVALID, "nidreg_eval_pipelined: collect the handle's outstanding tickets first");
+  int worst = NIDREG_OK;
+  int64_t tickets[kAsyncDepth];
+  int head = 0, tail = 0;  // poses submitted / collected
+  const int depth = kAsyncDepth - 1;
+  auto drain = [&]() {  // after a failure: collect what is still in flight so that the handle stays usable
+    for (; tail < head; tail++) (void)nidreg_wait(h, tickets[tail % kAsyncDepth], nullptr, nullptr);
+  };
+  while (tail < n) {
+    while (head < n && head - tail < depth) {
+      const int rc = nidreg_submit(h, se3s + 7 * size_t(head), grads7 != nullptr, &tickets[head % kAsyncDepth]);
+      if (rc < 0) {
+        drain();
+        return rc;
+      }
+      head++;
+    }
+    double c = 0.0;
+    const int rc = nidreg_wait(h, tickets[tail % kAsyncDepth], &c, grads7 ? grads7 + 7 * size_t(tail) : nullptr);
+    tail++;
+    if (rc < 0) {
+      drain();
+      return rc;
+    }
+    if (rc != NIDREG_OK) worst = rc;
+    if (costs) costs[tail - 1] = c;
   }
   return worst;
 }

@@ -293,14 +293,32 @@ class NIDCost(_Handle):
             _lib.check(rc, "nidreg_eval")
         return rc == _lib.NIDREG_OK, c.value, (g.copy() if want_grad else None)
 
-    def eval_batch(self, poses, want_grad=True):
-        """``n`` synchronous evaluations back to back inside the library (an optimiser's inner loop without the
-        per-call Python / ctypes overhead).  Returns ``(all_ok, costs[n], grads[n,7] | None)``."""
+    def eval_batch(self, poses, want_grad=True, pipelined=False):
+        """``n`` evaluations back to back inside the library (an optimiser's inner loop without the per-call Python /
+        ctypes overhead): synchronous -- each completes, host sync included, before the next starts -- or, for INDEPENDENT
+        poses, ``pipelined`` through the submit / wait pair (no host round trip between them).  Returns
+        ``(all_ok, costs[n], grads[n,7] | None)``."""
         x = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 7)
         costs = np.empty(x.shape[0])
         grads = np.empty((x.shape[0], 7)) if want_grad else None
-        rc = _lib.check(self._lib.nidreg_eval_batch(self.h, _dp(x), x.shape[0], _dp(costs), _dp(grads)), "nidreg_eval_batch")
+        fn = self._lib.nidreg_eval_pipelined if pipelined else self._lib.nidreg_eval_batch
+        rc = _lib.check(fn(self.h, _dp(x), x.shape[0], _dp(costs), _dp(grads)), "nidreg_eval_pipelined" if pipelined else "nidreg_eval_batch")
         return rc == _lib.NIDREG_OK, costs, grads
+
+    def submit(self, T_camera_lidar_params, want_grad=True):
+        """``nidreg_submit``: queue one evaluation, return its ticket (at most 8 in flight per handle)."""
+        x = np.ascontiguousarray(T_camera_lidar_params, dtype=np.float64).reshape(7)
+        t = ctypes.c_int64(0)
+        _lib.check(self._lib.nidreg_submit(self.h, _dp(x), 1 if want_grad else 0, ctypes.byref(t)), "nidreg_submit")
+        return (t.value, want_grad)
+
+    def wait(self, ticket):
+        """``nidreg_wait``: ``(ok, cost, grad | None)`` of the evaluation behind ``ticket`` (from :meth:`submit`)."""
+        t, want_grad = ticket
+        c = ctypes.c_double(float("nan"))
+        g = np.empty(7) if want_grad else None
+        rc = _lib.check(self._lib.nidreg_wait(self.h, t, ctypes.byref(c), _dp(g)), "nidreg_wait")
+        return rc == _lib.NIDREG_OK, c.value, g
 
     # split-phase API for point-sharded multi-GPU evaluation (see parallel.ShardedNIDCost)
     def shard_hist(self, x):
@@ -447,6 +465,18 @@ class CostCalculatorNID(_Handle):
         T = np.ascontiguousarray(np.asarray(T_camera_lidar, dtype=np.float64).reshape(4, 4))
         cost = ctypes.c_double(float("nan"))
         _lib.check(self._lib.nidreg_eval_iso(self.h, _dp(T), ctypes.byref(cost)), "nidreg_eval_iso")
+        return cost.value
+
+    def submit(self, T_camera_lidar):
+        """``nidreg_submit_iso``: queue one ``calculate``, return its ticket (at most 8 in flight per handle)."""
+        T = np.ascontiguousarray(np.asarray(T_camera_lidar, dtype=np.float64).reshape(4, 4))
+        t = ctypes.c_int64(0)
+        _lib.check(self._lib.nidreg_submit_iso(self.h, _dp(T), ctypes.byref(t)), "nidreg_submit_iso")
+        return t.value
+
+    def wait(self, ticket):
+        cost = ctypes.c_double(float("nan"))
+        _lib.check(self._lib.nidreg_wait(self.h, ticket, ctypes.byref(cost), None), "nidreg_wait")
         return cost.value
 
 

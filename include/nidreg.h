@@ -173,6 +173,26 @@ int nidreg_eval_batch(nidreg_handle* h, const double* se3s, int n, double* costs
 /* CostCalculatorNID::calculate at a row-major 4x4 T_camera_lidar */
 int nidreg_eval_iso(nidreg_handle* h, const double* T_camera_lidar, double* cost);
 
+/* Asynchronous evaluation, for callers that hold several INDEPENDENT poses -- Nelder-Mead's initial simplex
+ * (include/dfo/nelder_mead.hpp:32-57 evaluates its n + 1 vertices before the first step), multi-start, finite-difference
+ * checks; a line search (BFGS, visual_camera_calibration.cpp:210-229) has nothing to overlap and keeps nidreg_eval.
+ * nidreg_submit queues the kernels of NIDCost::operator() (want_grad != 0: with the Jacobian) and returns at once with a
+ * ticket; nidreg_submit_iso does the same for CostCalculatorNID::calculate.  nidreg_wait blocks until that evaluation is
+ * complete and returns what nidreg_eval / nidreg_eval_iso would have (cost, grad7 when it was asked for; NIDREG_FALSE for a
+ * non-finite NID).  The evaluations of one handle run back to back in submission order -- no host round trip between
+ * them --, each into its own host-mapped result block; tickets may be collected in any order.  At most 8 evaluations of a
+ * handle may be in flight (NIDREG_ERR_INVALID beyond that: collect first); a handle must not be destroyed, and its
+ * histograms not read, while tickets are outstanding.  Handles spread over several GPUs, handles with caller-provided
+ * result buffers and handles with timing enabled evaluate inside nidreg_submit (the ticket then only carries the results).
+ * Results are bit-identical to the synchronous calls. */
+int nidreg_submit(nidreg_handle* h, const double* se3, int want_grad, int64_t* ticket);
+int nidreg_submit_iso(nidreg_handle* h, const double* T_camera_lidar, int64_t* ticket);
+int nidreg_wait(nidreg_handle* h, int64_t ticket, double* cost, double* grad7);
+
+/* nidreg_eval_batch's arguments and results for n INDEPENDENT poses, through the submit / wait pair: up to 7 evaluations
+ * queued ahead of the one being collected (the handle must have no outstanding tickets). */
+int nidreg_eval_pipelined(nidreg_handle* h, const double* se3s, int n, double* costs, double* grads7);
+
 /* MultiNIDCost::operator(): trust gate against init_se3 (NULL = no gate), all pairs in flight at once, plain sum
  * of costs / gradients, NIDREG_FALSE if the gate rejects or any pair is non-finite.  Handles on different GPUs run
  * concurrently (every GPU's histogram pass is queued before the rest).  2..16 compatible SPLINE handles on ONE GPU

@@ -941,13 +941,19 @@ def test_chunks_across_column_groups_match_one_group_per_chunk(model, monkeypatc
     proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
     x = s.T_camera_lidar_init
     ref = oracle_lib.nid_cost(s.model, s.intrinsics, s.distortion, s.image_f64, pts, ints, 256, x, want_hist=True)
-    for tuning in ({}, {"lds_copies": 16}, {"target_blocks": 40}, {"target_blocks": 3000}):
+    # (tuning, NIDREG_SEG_OVERHEAD): the default cost model keeps a cloud this small on one group per chunk; a small per-segment
+    # cost, or few workgroups, makes the chunks run across groups -- in the gradient table and in the WIDE histogram table
+    for tuning, overhead, expect in (({}, None, None), ({}, "16", (1, 1)), ({"lds_copies": 16}, "16", (1, 0)), ({"target_blocks": 40}, None, (1, 1)), ({"target_blocks": 3000}, "0", None)):
+        if overhead is not None:
+            monkeypatch.setenv("NIDREG_SEG_OVERHEAD", overhead)
         seg = nid.NIDCost(proj, s.image_f64, pts, ints, 256, **tuning)
         monkeypatch.setenv("NIDREG_MAX_SEGS", "1")
         one = nid.NIDCost(proj, s.image_f64, pts, ints, 256, **tuning)
         monkeypatch.delenv("NIDREG_MAX_SEGS")
-        if tuning.get("target_blocks", 0) != 3000:
-            assert seg.info()["segmented"] == 1 and one.info()["segmented"] == 0, (tuning, seg.info(), one.info())
+        monkeypatch.delenv("NIDREG_SEG_OVERHEAD", raising=False)
+        assert (one.info()["segmented"], one.info()["segmented_hist"]) == (0, 0)
+        if expect is not None:
+            assert (seg.info()["segmented"], seg.info()["segmented_hist"]) == expect, (tuning, overhead, seg.info())
         for _ in range(2):  # both histogram buffers
             ok0, c0, g0 = seg(x)
             ok1, c1, g1 = one(x)
@@ -972,10 +978,64 @@ def test_chunks_across_column_groups_match_one_group_per_chunk(model, monkeypatc
         if bins != 256:
             ref_cost, ref_hist = oracle_lib.cost_calculator_nid(s.model, s.intrinsics, s.distortion, s.image_u8, pts, ints, bins, max_fov, T, want_hist=True)
         calc = nid.CostCalculatorNID(proj, s.image_u8, pts, ints, nid.NIDCostParams(bins), max_fov=max_fov, target_blocks=tb)
-        if bins == 256:
+        if tb:
             assert calc.info()["segmented"] == 1
         for _ in range(2):
             c = calc.calculate(T)
             fx, inl, frac = calc.histogram_fixed()
             assert np.array_equal(fx, ref_hist) and inl == ref_hist.sum() and abs(c - ref_cost) <= 1e-12
         calc.close()
+
+
+def test_submit_wait_matches_synchronous_evaluation():
+    """nidreg_submit / nidreg_wait (round 4): up to eight evaluations of a handle in flight, each into its own result block;
+    collected in any order they equal the synchronous calls bit for bit (cost AND gradient: same kernels, same chunk table,
+    same order of partial sums).  Also the pipelined batch, cost-only submissions, the NEAREST twin, and the error paths."""
+    s = scene_for("plumb_bob", n=50000, seed=3)
+    proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
+    rng = np.random.default_rng(12)
+    poses = np.ascontiguousarray([synth.random_pose_near(s.T_camera_lidar_true, rng) for _ in range(19)])
+    for bins in (16, 256):
+        cost = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, bins)
+        ok_s, c_s, g_s = cost.eval_batch(poses)
+        tickets = [cost.submit(x) for x in poses[:8]]
+        with pytest.raises(RuntimeError):
+            cost.submit(poses[8])  # a ninth evaluation in flight
+        for k in reversed(range(8)):  # any order
+            ok, c, g = cost.wait(tickets[k])
+            assert ok and c == c_s[k] and np.array_equal(g, g_s[k])
+        with pytest.raises(RuntimeError):
+            cost.wait(tickets[3])  # collected already
+        # synchronous and asynchronous calls interleaved; cost-only submissions
+        t0 = cost.submit(poses[9], want_grad=False)
+        okm, cm, gm = cost(poses[10])
+        t1 = cost.submit(poses[11])
+        assert okm and cm == c_s[10] and np.array_equal(gm, g_s[10])
+        ok1, c1, g1 = cost.wait(t1)
+        ok0, c0, g0 = cost.wait(t0)
+        assert ok0 and c0 == c_s[9] and g0 is None and ok1 and c1 == c_s[11] and np.array_equal(g1, g_s[11])
+        ok_p, c_p, g_p = cost.eval_batch(poses, pipelined=True)
+        assert ok_p == ok_s and np.array_equal(c_p, c_s) and np.array_equal(g_p, g_s)
+        ok_q, c_q, g_q = cost.eval_batch(poses, want_grad=False, pipelined=True)
+        assert ok_q and np.array_equal(c_q, c_s) and g_q is None
+        # the histograms afterwards are those of the last evaluation queued
+        fx = cost.histogram_fixed()
+        cost(poses[-1])
+        assert np.array_equal(fx[0], cost.histogram_fixed()[0])
+        cost.close()
+    max_fov = oracle_lib.estimate_camera_fov(s.model, s.intrinsics, s.distortion, s.width, s.height)
+    calc = nid.CostCalculatorNID(proj, s.image_u8, s.points, s.intensities, nid.NIDCostParams(256), max_fov=max_fov)
+    mats = [se3.to_matrix(x) for x in poses[:7]]  # Nelder-Mead's initial simplex: 7 vertices (nelder_mead.hpp:32-57)
+    sync = [calc.calculate(T) for T in mats]
+    tickets = [calc.submit(T) for T in mats]
+    assert [calc.wait(t) for t in tickets] == sync
+    calc.close()
+    # a handle spread over several (here: co-located) shards evaluates inside submit; the ticket carries the results
+    sharded = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, 256, devices=[0, 0])
+    plain = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, 256)
+    t = sharded.submit(poses[0])
+    oks, cs, gs = sharded.wait(t)
+    okp, cp, gp = plain(poses[0])
+    assert oks and okp and cs == cp and np.allclose(gs, gp, rtol=1e-11, atol=1e-14)
+    sharded.close()
+    plain.close()
