@@ -159,6 +159,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="points of the workload the CPU oracle is timed on (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="N>1: skip the multi_gpu.* cases (configs[2], [3], [4], single-process route)")
+    ap.add_argument("--no-config-legs", action="store_true", help="N=1: skip the other BASELINE configs and the view-culled form of the workload")
     ap.add_argument("--extra-points-scale", type=float, default=1.0, help="scale the point counts of the multi_gpu.* cases (tests)")
     args = ap.parse_args()
 
@@ -325,7 +326,16 @@ def main():
         insts = {k_: pk[k_].get("valu_insts") for k_ in route if k_ in pk and k_ != "k_entropy"}
         if insts and all(v for v in insts.values()):
             floor_us = {k_: v * 4.0 / NUM_SIMDS / (SHADER_GHZ * 1e3) for k_, v in insts.items()}
+            # VALU-busy fraction of a kernel: SQ_ACTIVE_INST_VALU (cycles a CU's VALUs are issuing, summed over the CUs) over the
+            # CU-cycles of its duration (256 CUs x kernel time x 2.4 GHz)
+            busy = {}
+            for k_ in insts:
+                act = pk[k_].get("valu_active_quad_cycles")
+                t_ms = ks.get(k_) or {"k_spline_hist": kt.get("hist"), "k_spline_grad": kt.get("grad")}.get(k_)
+                if act and t_ms:
+                    busy[k_] = round(act / (256 * t_ms * 1e-3 * SHADER_GHZ * 1e9), 3)
             valu = {
+                "busy_frac": busy or None,
                 "insts_per_point": {k_: round(v * 64.0 / n_local, 1) for k_, v in insts.items()},
                 "issue_floor_us": {k_: round(v, 2) for k_, v in floor_us.items()},
                 "frac_of_evaluation": round(sum(floor_us.values()) / (ms_per_step * 1e3), 3),
@@ -393,6 +403,47 @@ def main():
         again.close()
         if python_call_rate:
             extra["python_call_evals_per_s"] = round(python_call_rate, 1)
+
+    # ---- the same workload with the evaluations queued ahead (nidreg_submit / nidreg_wait): what a caller with independent
+    # poses in hand gets -- Nelder-Mead's initial simplex, multi-start, batches; `value` stays the synchronous rate
+    pipelined = None
+    if rank == 0 and world == 1 and plain:
+        bp = np.ascontiguousarray([poses[k % len(poses)] for k in range(args.steps)])
+        cost.eval_batch(bp[:8], pipelined=True)
+        tp = []
+        for _ in range(15):
+            t1 = time.perf_counter()
+            cost.eval_batch(bp, pipelined=True)
+            tp.append((time.perf_counter() - t1) / len(bp))
+        pipelined = {"evals_per_s": round(1.0 / float(np.median(tp)), 1), "ms_per_step": round(1e3 * float(np.median(tp)), 5), "in_flight": 7,
+                     "frac": round(eval_bytes / float(np.median(tp)) / 1e9 / HBM_PEAK_GBS, 4) if roof else None}
+
+    # ---- the view-culled form of the workload (what `calibrate` evaluates: visual_camera_calibration.cpp:201-206 culls before
+    # every inner solve): the scene plus a copy pushed out of the view, culled and bucketed on the device
+    culled = None
+    if rank == 0 and world == 1 and plain and not args.no_config_legs:
+        try:
+            from direct_visual_lidar_calibration_amd import se3 as _se3c
+
+            moved = (pts + np.array([6.0, 0.0, 0.0, 0.0])).astype(np.float32).astype(np.float64)
+            cl = nid.Cloud(np.concatenate([pts, moved]), np.concatenate([ints, ints[::-1]]), device=local_rank)
+            del moved
+            cc = nid.NIDCost.from_cloud(proj, scene.image_f64, cl, args.bins, cull=(_se3c.to_matrix(scene.T_camera_lidar_init), 0.0, True), precision=args.precision)
+            bp = np.ascontiguousarray([poses[k % len(poses)] for k in range(20)])
+            cc.eval_batch(bp[:5])
+            tcs = []
+            for _ in range(9):
+                t1 = time.perf_counter()
+                cc.eval_batch(bp)
+                tcs.append((time.perf_counter() - t1) / len(bp))
+            kept = int(cc.info()["num_points"])
+            us = 1e6 * float(np.median(tcs))
+            culled = {"in_pts": int(2 * pts.shape[0]), "kept": kept, "us_per_eval": round(us, 2), "ns_per_pt": round(1e3 * us / kept, 3), "headline_ns_per_pt": round(1e6 * ms_per_step / pts.shape[0], 3),
+                      "frac": round(algorithmic_bytes(kept, scene.width, scene.height, args.bins) / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "seg": [int(cc.info()["segmented"]), int(cc.info()["segmented_hist"])]}
+            cc.close()
+            cl.close()
+        except Exception as exc:  # an informational leg must not cost the headline line
+            culled = {"error": f"{type(exc).__name__}: {exc}"[:200]}
 
     # ---- CPU baseline: the oracle (faithful restatement, 1 core, Jet<7>) on a bounded sample
     cpu = None
@@ -476,6 +527,39 @@ def main():
     cost.close()
     del scene, pts, ints
 
+    # ---- every other BASELINE.json config on this one GPU (one pair each; the sharded / per-GPU forms are the N > 1 legs):
+    # ms per synchronous cost+Jacobian evaluation, algorithmic GB/s, fraction of the HBM roof
+    configs = None
+    if rank == 0 and world == 1 and not args.no_config_legs and (args.points, args.camera, args.bins) == (10_000_000, "pinhole_1080p", 256):
+        configs = {}
+        t_legs = time.time()
+        for key, camera, n_points, bins_ in (("c1", "pinhole_vga", 100_000, 16), ("c3", "equirect_2k", 10_000_000, 256), ("c3b", "omnidir_2k", 10_000_000, 256),
+                                             ("c4", "fisheye_1080p", 5_000_000, 256), ("c5", "pinhole_4k", 50_000_000, 256)):
+            if time.time() - t_legs > 90.0:
+                configs[key] = {"error": "skipped: the config legs' time budget (90 s) was used up"}
+                continue
+            try:
+                s_ = synth.make_scene(camera, num_points=int(n_points * args.extra_points_scale), seed=20250523 + 7, device=f"cuda:{local_rank}")
+                pr_ = nid.create_camera(s_.model, s_.intrinsics, s_.distortion)
+                c_ = nid.NIDCost(pr_, s_.image_f64, s_.points, s_.intensities, bins_, device=local_rank, precision=args.precision)
+                ps_ = np.ascontiguousarray([synth.random_pose_near(s_.T_camera_lidar_true, rng) for _ in range(20)])
+                c_.eval_batch(ps_[:4])
+                reps = 12 if n_points <= 10_000_000 else 5
+                tl = []
+                for _ in range(reps):
+                    t1 = time.perf_counter()
+                    c_.eval_batch(ps_)
+                    tl.append((time.perf_counter() - t1) / len(ps_))
+                msl = 1e3 * float(np.median(tl))
+                ab = algorithmic_bytes(s_.points.shape[0], s_.width, s_.height, bins_)
+                configs[key] = {"pts": int(s_.points.shape[0]), "cam": camera, "bins": bins_, "ms_per_step": round(msl, 5), "evals_per_s": round(1e3 / msl, 1), "gbs": round(ab / (msl * 1e-3) / 1e9, 1),
+                                "frac": round(ab / (msl * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                c_.close()
+                del s_, c_
+                torch.cuda.empty_cache()
+            except Exception as exc:
+                configs[key] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+
     # ------------------------------------------------------------------ N>1: the other multi-GPU cases, same JSON line
     multi = None
     if world > 1 and not args.no_extra_legs:
@@ -486,11 +570,26 @@ def main():
         steps2 = max(5, args.steps // 2)
         blocks2 = max(3, args.blocks // 5)
 
+        t_legs = time.time()
+        leg_budget_s = float(os.environ.get("NIDREG_BENCH_LEG_BUDGET_S", "600"))
+
         def leg(name, fn):
+            # every optional case is bounded: a case that fails (an exchange that times out: NIDREG_SHARD_TIMEOUT_MS, one
+            # evaluation) is recorded as an error, and once the cases together have used their wall-clock budget the rest is
+            # skipped -- on every rank alike (the decision is rank 0's, broadcast) -- so that the headline line always comes out
+            skip = torch.tensor([1 if time.time() - t_legs > leg_budget_s else 0], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+            if dist is not None:
+                dist.broadcast(skip, src=0)
+            if int(skip.item()):
+                multi[name] = {"error": f"skipped: the multi_gpu cases' wall-clock budget ({leg_budget_s:.0f} s) was used up"}
+                return
+            t_leg = time.time()
             try:
                 multi[name] = fn()
             except Exception as exc:  # an optional case must not cost the headline line
                 multi[name] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+            if isinstance(multi[name], dict):
+                multi[name]["leg_s"] = round(time.time() - t_leg, 1)
             if dist is not None:
                 dist.barrier(group=cpu_group)
 
@@ -583,6 +682,9 @@ def main():
                 "later_handles": round(units_per_step * 50.0 / (extra["setup_again_s"] + 50.0 * ms_per_step * 1e-3), 1) if extra and "setup_again_s" in extra else None,
             },
             "roofline": roof,
+            "pipelined": pipelined,
+            "culled": culled,
+            "configs": configs,
             "cpu_baseline": cpu,
             "other_entry_points": extra,
             "multi_gpu": multi,

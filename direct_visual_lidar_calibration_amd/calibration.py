@@ -233,20 +233,39 @@ class VisualCameraCalibration:
         T0 = se3.to_matrix(init_x)
         best = [math.inf]
 
-        def f(x6):
-            T = T0 @ se3.pose3_expmap(x6)  # init * Pose3::Expmap(x) (:104)
-            total = 0.0
-            for c in calcs:
-                total += c.calculate(T)
+        def note(total, T):
             if total < best[0]:
                 best[0] = total
                 if self.callback:
                     self.callback(se3.from_matrix(T))
             return total
 
+        def f(x6):
+            T = T0 @ se3.pose3_expmap(x6)  # init * Pose3::Expmap(x) (:104)
+            total = 0.0
+            for c in calcs:
+                total += c.calculate(T)
+            return note(total, T)
+
+        def f_many(xs):
+            # vertices that do not depend on each other (initial simplex, shrink step): every (vertex, pair) evaluation queued
+            # before the first is collected (nidreg_submit_iso / nidreg_wait; at most 8 in flight per handle), then the same
+            # sums, comparisons and callbacks as f, vertex by vertex in order
+            Ts = [T0 @ se3.pose3_expmap(x6) for x6 in xs]
+            out = []
+            for lo in range(0, len(Ts), 8):
+                tickets = [[c.submit(T) for c in calcs] for T in Ts[lo : lo + 8]]
+                for T, row in zip(Ts[lo : lo + 8], tickets):
+                    total = 0.0
+                    for c, t in zip(calcs, row):
+                        total += c.wait(t)
+                    out.append(note(total, T))
+            return out
+
         p = NelderMeadParams(init_step=self.params.nelder_mead_init_step, convergence_var_thresh=self.params.nelder_mead_convergence_criteria,
                              max_iterations=self.params.max_inner_iterations)
-        result = NelderMead(p).optimize(f, np.zeros(6))
+        batched = len(calcs) > 0 and all(hasattr(c, "submit") and hasattr(c, "wait") for c in calcs)
+        result = NelderMead(p).optimize(f, np.zeros(6), batch_function=f_many if batched else None)
         T = T0 @ se3.pose3_expmap(result.x)
         for c in calcs:
             if hasattr(c, "close"):

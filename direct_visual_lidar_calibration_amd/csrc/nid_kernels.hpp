@@ -528,10 +528,36 @@ __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads, hist_min_waves(MODE
 // point, truncating int cast, one count per inlier.  The arithmetic order matches the reference
 // expression tree so that, compiled with -ffp-contract=off, +,-,*,/,sqrt results are bit-identical
 // to the CPU's and the integer histogram is exactly reproducible.
+// Round 4: the kernel decides in two tiers.  What the histogram needs from a point is three DECISIONS -- inside the FoV cone,
+// inside the image, which pixel --, not the projected coordinates themselves.  The FAST tier (plumb_bob, double precision)
+// computes zn, u, v the way the SPLINE kernels do (fused multiply-adds, v_rcp / v_rsq + one Newton step: ~75 instead of ~137
+// VALU instructions per point) together with a bound on how far these values can be from the reference's (below); a point
+// whose decisions all lie outside that band keeps them, and only lanes inside the band (a few per 10^7 points; `ballot`)
+// repeat the point in the reference's exact expression order.  The integer histogram stays bit-exact against the CPU
+// (tests: every model and bin count, 10M points, and points placed 1e-13 ... 1e-9 around every kind of decision boundary).
+//
+// The bound.  Both tiers evaluate the same real-valued functions of the same inputs; with eps = 2^-52:
+//   c = M p + t:   |c_fast - c_exact| <= e1 = 8 eps (rmax (|x| + |y| + |z|) + tmax)   per component (three products, three
+//                  sums, either association; rmax / tmax = largest |entry| of the rotation block / the translation);
+//   zn = cz / |c|: |d zn| <= sqrt(3) e1 / |c| + 16 eps                                 -> band bz = 8 e1 / |c| + 1e-14;
+//   px = cx / cz:  |d px| <= e1 (1 + |px|) / |cz| + 1.5e-14 |px|  (one-Newton-step reciprocal: 2^-46 relative); same for py;
+//   (u, v) = f D(px, py) + c0 with |px|, |py| <= pmax = tan(max_fov) for a point inside the cone, D's Jacobian row sums <= K
+//                  there (from the distortion coefficients, on the host): |d u| <= A e1 / |cz| + Bc with
+//                  A = 2 fmax K (1 + pmax) and Bc = fmax (4e-14 K pmax + 2e-14 R pmax) + 1e-15 (W + H + |cx| + |cy|),
+//                  R = sup |radial factor|                                               -> band bu = A e1 / |cz| + Bc.
+// Every factor carries a margin of >= 2 over the first-order term; second-order terms are below 2^-20 of them whenever the
+// band is small enough to matter (a band >= 0.5 px sends the lane to the exact tier by itself).  NaN / inf anywhere compare
+// false, i.e. "inside the band": those points take the exact tier and behave like the reference.
+struct NearestFast {
+  double er, et;  // 8 eps rmax, 8 eps tmax
+  double A, Bc;
+  int on;         // 0: exact tier only (other camera models, max_fov close to 90 degrees, fp32 geometry)
+};
+
 template <int MODEL, typename Rec, typename real, bool MULTI, bool SEG>
 __global__ __launch_bounds__(kThreads) void k_nearest_hist(
   const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint32_t* __restrict__ gend, const uint8_t* __restrict__ img, int pitch, int W, int H, IsoParams<real> iso,
-  CamParams<real> cam, int B, int GW, int cshift, real cos_fov, u64* __restrict__ hist, const ShardTable* __restrict__ ann, u64 ann_seq, unsigned int* ann_ticket,
+  CamParams<real> cam, int B, int GW, int cshift, real cos_fov, NearestFast fast, u64* __restrict__ hist, const ShardTable* __restrict__ ann, u64 ann_seq, unsigned int* ann_ticket,
   const MultiEntry* __restrict__ multi, typename multi_dyn_of<MULTI>::type dyn) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u64* tile = reinterpret_cast<u64*>(smem);
@@ -544,7 +570,7 @@ __global__ __launch_bounds__(kThreads) void k_nearest_hist(
   const int tid = threadIdx.x;
   const Chunk ch = chunks[blockIdx.x];
   if constexpr (MULTI) {  // one grid over several pairs (see k_spline_hist)
-    const uint32_t pair = ch.pad & 0xffu;  // Chunk::pad = pair | (index of the chunk among its pair's chunks) << 8
+    const uint32_t pair = ch.pad & 0xffu;  // Chunk::pad = pair | (first gradient-partial slot of the chunk) << 8
     const MultiEntry& e = multi[pair];
     pts = as_global(static_cast<const Rec*>(e.pts));
     gend = as_global(e.gend);
@@ -555,6 +581,24 @@ __global__ __launch_bounds__(kThreads) void k_nearest_hist(
 
   const real fW = real(W), fH = real(H);
   unsigned int inl = 0;
+  constexpr bool kFastTier = MODEL == MODEL_PLUMB_BOB && std::is_same<real, double>::value;
+
+  // the reference's expression order (cost_calculator_nid.cpp:30-47): +, -, *, /, sqrt bit-identical to the CPU's
+  auto exact = [&](real x, real y, real z, bool& in, int& px, int& py) {
+    // Eigen 4x4 * (x y z 1): ((m0 x + m1 y) + m2 z) + m3 * 1
+    const real cx = ((iso.m[0] * x + iso.m[1] * y) + iso.m[2] * z) + iso.m[3];
+    const real cy = ((iso.m[4] * x + iso.m[5] * y) + iso.m[6] * z) + iso.m[7];
+    const real cz = ((iso.m[8] * x + iso.m[9] * y) + iso.m[10] * z) + iso.m[11];
+    const real n2 = (cx * cx + cy * cy) + cz * cz;
+    const real zn = n2 > real(0) ? cz / m_sqrt(n2) : cz;
+    const bool in_fov = !(zn < cos_fov);  // out of FoV otherwise (cost_calculator_nid.cpp:32)
+    real u, v;
+    project<MODEL, real, real>(cam, cx, cy, cz, u, v);
+    // trunc(u) in [0,W)  <=>  -1 < u < W ; NaN false (cost_calculator_nid.cpp:37-41)
+    in = in_fov && (u > real(-1)) && (u < fW) && (v > real(-1)) && (v < fH);
+    px = in ? int(u) : 0;  // truncation toward zero
+    py = in ? int(v) : 0;
+  };
 
   Segments seg(gend, ch);
   for (;;) {
@@ -565,10 +609,10 @@ __global__ __launch_bounds__(kThreads) void k_nearest_hist(
     const uint32_t cnt = seg_end - seg.pos;
     const uint32_t col0 = seg.g * uint32_t(GW);
     const Rec* __restrict__ recs = pts + seg.pos;
-    // kUnroll records per thread are fetched before any of them is processed: one 16-B load per wave
-    // in flight is latency bound (measured 1.45 TB/s); four keep ~64 KB per CU outstanding
-    // (no progress priority here: this pass is a third of the spline passes' arithmetic per point and lives on memory-level
-    // parallelism -- with it the kernel was 10 % slower on cfg 2, 67.2 -> 73.8 us, profiles/r02g_kernel_gaps.txt)
+    // kUnroll records per thread are fetched before any of them is processed, the decisions of all of them come before the
+    // first pixel gather, and the gathers before the first LDS add: every memory latency of an iteration is paid once.
+    // (Until round 3 the four points ran one after the other, each through its own gather: 40 % of the wave cycles waited
+    // on memory, profiles/r04a_pmc_summary_nearest.txt.)  No progress priority here (profiles/r02g_kernel_gaps.txt).
     for (uint32_t base = 0; base < cnt; base += kThreads * kUnroll) {
       real xs[kUnroll], ys[kUnroll], zs[kUnroll];
       uint32_t bins_[kUnroll];
@@ -577,28 +621,59 @@ __global__ __launch_bounds__(kThreads) void k_nearest_hist(
         const uint32_t ii = min(base + uint32_t(k) * kThreads + tid, cnt - 1u);
         load_rec<real>(recs + ii, xs[k], ys[k], zs[k], bins_[k]);
       }
+      bool ins[kUnroll], need[kUnroll];
+      int pxs[kUnroll], pys[kUnroll];
+      bool any_need = false;
 #pragma unroll
       for (int k = 0; k < kUnroll; k++) {
-        const uint32_t i = base + uint32_t(k) * kThreads + tid;
-        if (i >= cnt) break;
-        const real x = xs[k], y = ys[k], z = zs[k];
-        const uint32_t bin = bins_[k];
-        // Eigen 4x4 * (x y z 1): ((m0 x + m1 y) + m2 z) + m3 * 1
-        const real cx = ((iso.m[0] * x + iso.m[1] * y) + iso.m[2] * z) + iso.m[3];
-        const real cy = ((iso.m[4] * x + iso.m[5] * y) + iso.m[6] * z) + iso.m[7];
-        const real cz = ((iso.m[8] * x + iso.m[9] * y) + iso.m[10] * z) + iso.m[11];
-        const real n2 = (cx * cx + cy * cy) + cz * cz;
-        const real zn = n2 > real(0) ? cz / m_sqrt(n2) : cz;
-        const bool in_fov = !(zn < cos_fov);  // out of FoV otherwise (cost_calculator_nid.cpp:32)
-        real u, v;
-        project<MODEL, real, real>(cam, cx, cy, cz, u, v);
-        // trunc(u) in [0,W)  <=>  -1 < u < W ; NaN false (cost_calculator_nid.cpp:37-41)
-        const bool in = in_fov && (u > real(-1)) && (u < fW) && (v > real(-1)) && (v < fH);
-        if (in) {
+        ins[k] = false;
+        pxs[k] = pys[k] = 0;
+        need[k] = base + uint32_t(k) * kThreads + tid < cnt;  // (a valid slot)
+      }
+      bool fast_on = false;
+      if constexpr (kFastTier) fast_on = fast.on != 0;  // uniform
+      if (fast_on) {
+#pragma unroll
+        for (int k = 0; k < kUnroll; k++) {  // branch-free: the four points interleave
+          const bool valid = need[k];
+          const double x = xs[k], y = ys[k], z = zs[k];
+          const double cx = fma(double(iso.m[2]), z, fma(double(iso.m[1]), y, fma(double(iso.m[0]), x, double(iso.m[3]))));
+          const double cy = fma(double(iso.m[6]), z, fma(double(iso.m[5]), y, fma(double(iso.m[4]), x, double(iso.m[7]))));
+          const double cz = fma(double(iso.m[10]), z, fma(double(iso.m[9]), y, fma(double(iso.m[8]), x, double(iso.m[11]))));
+          const double n2 = fma(cx, cx, fma(cy, cy, cz * cz));
+          const double rs = fast_rsq(n2);  // NaN for n2 == 0
+          const double e1 = fma(fast.er, (fabs(x) + fabs(y)) + fabs(z), fast.et);
+          const double dz = fma(cz, rs, -double(cos_fov));
+          const bool fov_safe = fabs(dz) > fma(8.0 * e1, rs, 1e-14);
+          const bool in_fov = !(dz < 0.0);
+          real u, v;
+          project<MODEL, real, real, true>(cam, real(cx), real(cy), real(cz), u, v);
+          const double bu = fma(fast.A * e1, fabs(fast_rcp(cz)), fast.Bc);
+          const bool uv_safe = bool(int(fabs(double(u) - rint(double(u))) > bu) & int(fabs(double(v) - rint(double(v))) > bu));
+          const bool in_rng = bool(int(u > real(-1)) & int(u < fW) & int(v > real(-1)) & int(v < fH));
+          // decided: safely outside the cone (u, v do not matter), or safely inside it with every pixel decision safe
+          const bool decided = bool(int(fov_safe) & (int(!in_fov) | int(uv_safe)));
+          need[k] = bool(int(valid) & int(!decided));
+          ins[k] = bool(int(valid) & int(decided) & int(in_fov) & int(in_rng));
+          pxs[k] = ins[k] ? int(u) : 0;
+          pys[k] = ins[k] ? int(v) : 0;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kUnroll; k++) any_need = bool(int(any_need) | int(need[k]));
+      if (__builtin_amdgcn_ballot_w64(any_need) != 0) {  // a lane of this wave sits inside a band (or the fast tier is off)
+#pragma unroll
+        for (int k = 0; k < kUnroll; k++)
+          if (need[k]) exact(xs[k], ys[k], zs[k], ins[k], pxs[k], pys[k]);
+      }
+      uint32_t rs_[kUnroll];
+#pragma unroll
+      for (int k = 0; k < kUnroll; k++) rs_[k] = load_pixel(img, pitch, pxs[k] + 1, pys[k] + 1);  // (an outlier reads padded pixel (1, 1))
+#pragma unroll
+      for (int k = 0; k < kUnroll; k++) {
+        if (ins[k]) {
           inl++;
-          const int px = int(u), py = int(v);  // truncation toward zero
-          const uint32_t r = load_pixel(img, pitch, px + 1, py + 1);
-          atomicAdd(&tile[((((bin - col0) * uint32_t(B)) + r) << cshift) + (uint32_t(tid) & cmask)], u64(1));
+          atomicAdd(&tile[((((bins_[k] - col0) * uint32_t(B)) + rs_[k]) << cshift) + (uint32_t(tid) & cmask)], u64(1));
         }
       }
     }

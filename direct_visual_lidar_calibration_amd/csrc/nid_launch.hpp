@@ -17,6 +17,11 @@ namespace nidreg {
 struct Chunk;
 struct EntropyScalars;
 struct ShardTable;
+// k_nearest_hist's fast decision tier (nid_kernels.hpp): error-bound coefficients of this pose and camera, from the host
+struct NearestFastArgs {
+  double er, et, A, Bc;
+  int on;
+};
 
 struct PassArgs {
   int model;
@@ -36,6 +41,7 @@ struct PassArgs {
   double magic;     // 2^(frac_bits - 1074): subnormal pre-scale of the x-weights
   double inv_unit;  // 2^(-frac_bits)
   double cos_fov;
+  NearestFastArgs nfast;  // NEAREST: the fast decision tier's band coefficients (on = 0: exact tier only)
   unsigned long long* hist;
   const double* phi_q;
   const EntropyScalars* scal;

@@ -230,19 +230,21 @@ template <typename real, typename Rec>
 static hipError_t launch_nearest_hist_rec(const PassArgs& a) {
   const IsoParams<real> iso = make_iso<real>(a);
   const CamParams<real> cam = make_cam<real>(a.intr, a.dist);
+  NearestFast fast;
+  fast.er = a.nfast.er, fast.et = a.nfast.et, fast.A = a.nfast.A, fast.Bc = a.nfast.Bc, fast.on = a.nfast.on;
 #define NID_LAUNCH_N(M, SEG)                                                                                                                           \
   if (a.multi) {                                                                                                                                       \
     auto k = k_nearest_hist<M, Rec, real, true, SEG>;                                                                                                       \
     hipError_t e = ensure_lds(k, a.lds_hist);                                                                                                          \
     if (e != hipSuccess) return e;                                                                                                                     \
     hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(kThreads), a.lds_hist, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.gend, a.img, a.pitch, a.W, a.H, iso, cam,  \
-                       a.B, a.GW, a.cshift, real(a.cos_fov), a.hist, a.ann, a.ann_seq, a.ann_ticket, a.multi, a.dyn);                                                                   \
+                       a.B, a.GW, a.cshift, real(a.cos_fov), fast, a.hist, a.ann, a.ann_seq, a.ann_ticket, a.multi, a.dyn);                                                                   \
   } else {                                                                                                                                             \
     auto k = k_nearest_hist<M, Rec, real, false, SEG>;                                                                                                      \
     hipError_t e = ensure_lds(k, a.lds_hist);                                                                                                          \
     if (e != hipSuccess) return e;                                                                                                                     \
     hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(kThreads), a.lds_hist, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.gend, a.img, a.pitch, a.W, a.H, iso, cam,  \
-                       a.B, a.GW, a.cshift, real(a.cos_fov), a.hist, a.ann, a.ann_seq, a.ann_ticket, a.multi, NoMultiDyn());                                                            \
+                       a.B, a.GW, a.cshift, real(a.cos_fov), fast, a.hist, a.ann, a.ann_seq, a.ann_ticket, a.multi, NoMultiDyn());                                                            \
   }
   if (a.seg) {
 #define NID_LAUNCH(M) NID_LAUNCH_N(M, true)

@@ -354,9 +354,44 @@ int launch_hist_spline(nidreg_handle* h, const double* se3, bool alone = false, 
   return NIDREG_OK;
 }
 
+// k_nearest_hist's fast decision tier (nid_kernels.hpp NearestFast): the coefficients of its error bound for this pose and
+// this camera.  plumb_bob in double precision only, and only for a FoV cone comfortably below 90 degrees (the bound on the
+// normalised image coordinates is tan(max_fov)); NIDREG_NEAREST_EXACT=1 switches the tier off (A/B runs, bisecting).
+NearestFastArgs nearest_fast_args(const nidreg_handle* h, const double* T) {
+  NearestFastArgs f;
+  std::memset(&f, 0, sizeof(f));
+  static const bool off = [] {
+    const char* e = std::getenv("NIDREG_NEAREST_EXACT");
+    return e && *e && *e != '0';
+  }();
+  const double cos_fov = std::cos(h->max_fov);
+  if (off || h->model != NIDREG_MODEL_PLUMB_BOB || h->precision != NIDREG_PREC_FP64 || !(cos_fov > 0.1)) return f;
+  const double eps = std::ldexp(1.0, -52);
+  double rmax = 0.0, tmax = 0.0;
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) rmax = std::max(rmax, std::fabs(T[4 * r + c]));
+    tmax = std::max(tmax, std::fabs(T[4 * r + 3]));
+  }
+  const double pmax = std::tan(h->max_fov) * 1.001 + 1e-6, r2 = pmax * pmax;
+  const double k1 = std::fabs(h->dist[0]), k2 = std::fabs(h->dist[1]), p1 = std::fabs(h->dist[2]), p2 = std::fabs(h->dist[3]), k3 = std::fabs(h->dist[4]);
+  const double R = 1.0 + r2 * (k1 + r2 * (k2 + r2 * k3));        // sup |1 + k1 r2 + k2 r4 + k3 r6|
+  const double Rp = k1 + r2 * (2.0 * k2 + r2 * 3.0 * k3);         // sup |d(radial factor) / d r2|
+  const double Kx = R + 4.0 * r2 * Rp + 4.0 * p1 * pmax + 8.0 * p2 * pmax;  // row sums of d(dx, dy)/d(px, py) on |px|, |py| <= pmax
+  const double Ky = R + 4.0 * r2 * Rp + 8.0 * p1 * pmax + 4.0 * p2 * pmax;
+  const double K = 1.5 * std::max(Kx, Ky);
+  const double fmax = std::max(std::fabs(h->intr[0]), std::fabs(h->intr[1]));
+  f.er = 8.0 * eps * rmax;
+  f.et = 8.0 * eps * tmax;
+  f.A = 2.0 * fmax * K * (1.0 + pmax);
+  f.Bc = fmax * (4e-14 * K * pmax + 2e-14 * R * pmax) + 1e-15 * (double(h->W) + double(h->H) + std::fabs(h->intr[2]) + std::fabs(h->intr[3]));
+  f.on = std::isfinite(f.A) && std::isfinite(f.Bc) && std::isfinite(f.er) && std::isfinite(f.et) ? 1 : 0;
+  return f;
+}
+
 int launch_hist_nearest(nidreg_handle* h, const double* T, u64 ann_seq = 0) {
   PassArgs a;
   fill_pass_args(h, a);
+  a.nfast = nearest_fast_args(h, T);
   if (ann_seq) {
     a.ann = h->d_shard_tab;
     a.ann_seq = ann_seq;
@@ -1274,6 +1309,7 @@ int group_eval_iso(MultiGroup* g, const double* T, double* costs) {
   a.dyn.want_grad = 0;
   a.dyn.neb = h0->NEB;
   for (int k = 0; k < 12; k++) a.iso[k] = T[k];
+  a.nfast = nearest_fast_args(h0, T);
   for (int i = 0; i < n; i++) {
     nidreg_handle* h = g->hs[size_t(i)];
     bump_seq(h);
@@ -2261,7 +2297,9 @@ int nidreg_get_info(nidreg_handle* h, int64_t* info8) {
     info8[6] = 0;
     for (nidreg_handle* sh : h->set->shards) info8[6] += sh->num_points;
   }
-  info8[7] = (h->rec64 ? 0 : 1) | (h->seg ? 2 : 0) | (h->seg_hist ? 4 : 0) | (int64_t(1 << h->cshift) << 8);
+  const double ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+  const int nfast = h->mode == NIDREG_MODE_NEAREST ? nearest_fast_args(h, ident).on : 0;
+  info8[7] = (h->rec64 ? 0 : 1) | (h->seg ? 2 : 0) | (h->seg_hist ? 4 : 0) | (nfast ? 8 : 0) | (int64_t(1 << h->cshift) << 8);
   return NIDREG_OK;
 }
 

@@ -49,7 +49,11 @@ class NelderMead:
         var = ((xs - m) ** 2).sum(axis=0)
         return var[1:].sum() < thresh
 
-    def optimize(self, function, x0):  # nelder_mead.hpp:32-102
+    def optimize(self, function, x0, batch_function=None):  # nelder_mead.hpp:32-102
+        """``batch_function(list of vertices) -> list of values`` (optional) is used where the reference evaluates vertices that
+        do not depend on each other -- the n + 1 vertices of the initial simplex (nelder_mead.hpp:37-45) and the n vertices of
+        a shrink step (:88-92) -- so that a GPU objective can have them all in flight at once (nidreg_submit / nidreg_wait);
+        it must return what ``function`` would, vertex by vertex, in order."""
         p = self.params
         x0 = np.asarray(x0, dtype=np.float64)
         n = x0.shape[0]
@@ -61,12 +65,19 @@ class NelderMead:
             evals += 1
             return float(function(v))
 
-        rows = [np.concatenate([[fn(x0)], x0])]
+        def fn_many(vs):
+            nonlocal evals
+            if batch_function is None:
+                return [fn(v) for v in vs]
+            evals += len(vs)
+            return [float(y) for y in batch_function(vs)]
+
+        verts = [x0]
         for i in range(n):
             xi = x0.copy()
             xi[i] += p.init_step
-            rows.append(np.concatenate([[fn(xi)], xi]))
-        x = np.array(rows)
+            verts.append(xi)
+        x = np.array([np.concatenate([[y], v]) for y, v in zip(fn_many(verts), verts)])
 
         for it in range(p.max_iterations):
             result.num_iterations = it
@@ -92,7 +103,8 @@ class NelderMead:
                 else:
                     for j in range(1, x.shape[0]):
                         x[j] = x[0] + p.rho * (x[j] - x[0])
-                        x[j, 0] = fn(x[j, 1:])
+                    for j, y in enumerate(fn_many([x[j, 1:].copy() for j in range(1, x.shape[0])]), start=1):
+                        x[j, 0] = y
             if self.callback:
                 self.callback(x[0, 1:].copy())
 

@@ -1039,3 +1039,74 @@ def test_submit_wait_matches_synchronous_evaluation():
     assert oks and okp and cs == cp and np.allclose(gs, gp, rtol=1e-11, atol=1e-14)
     sharded.close()
     plain.close()
+
+
+@pytest.mark.parametrize("pose", ["identity", "init"])
+def test_nearest_fast_tier_decides_like_the_reference_around_every_boundary(pose):
+    """k_nearest_hist's fast decision tier (round 4; plumb_bob, fp64): zn, u, v by fused multiply-adds and one-Newton-step
+    reciprocals, kept only where every decision -- inside the FoV cone, inside the image, which pixel -- lies outside a proven
+    error band; lanes inside the band repeat the point in the reference's exact expression order.  Points placed 0 ... 1e-8 px
+    around pixel boundaries and the image border, and 0 ... 1e-8 rad around the FoV cone (a cone that cuts through the image),
+    with lens distortion and a general pose: the integer histogram must equal the oracle's bit for bit, as must the histogram
+    of a handle with the tier switched off."""
+    s = scene_for("plumb_bob", n=2000)
+    W, H = s.width, s.height
+    intr, dist = list(s.intrinsics), list(s.distortion)
+    fx, fy, cx, cy = intr[:4]
+    x = np.array([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0]) if pose == "identity" else s.T_camera_lidar_init
+    T = se3.to_matrix(x)
+    R, t = T[:3, :3], T[:3, 3]
+    rng = np.random.default_rng(99)
+    deltas = np.array([0.0, 1e-13, -1e-13, 1e-12, -1e-12, 1e-11, -1e-11, 1e-10, -1e-10, 1e-9, -1e-9, 1e-8, -1e-8])
+    n = 12000
+    u = rng.integers(0, W, n).astype(np.float64) + deltas[rng.integers(0, len(deltas), n)]
+    v = rng.integers(0, H, n).astype(np.float64) + deltas[rng.integers(0, len(deltas), n)]
+    half = rng.random(n) < 0.5  # half of them near a boundary in one coordinate only
+    u = np.where(half & (rng.random(n) < 0.5), rng.uniform(0, W, n), u)
+    v = np.where(half & (rng.random(n) < 0.5), rng.uniform(0, H, n), v)
+    nb = 1500  # the image border: trunc(u) in [0, W)  <=>  -1 < u < W
+    ub = np.where(rng.random(nb) < 0.5, -1.0, float(W)) + deltas[rng.integers(0, len(deltas), nb)]
+    vb = np.where(rng.random(nb) < 0.5, -1.0, float(H)) + deltas[rng.integers(0, len(deltas), nb)]
+    u = np.concatenate([u, ub, rng.uniform(0, W, nb)])
+    v = np.concatenate([v, rng.uniform(0, H, nb), vb])
+    z = rng.uniform(1.5, 25.0, u.shape[0])
+    pc = np.stack([(u - cx) / fx * z, (v - cy) / fy * z, z], -1)
+    for _ in range(8):  # Newton on (x, y) at fixed depth, with the oracle's own projection and Jacobian
+        uv, J = oracle_lib.project_jacobian("plumb_bob", intr, dist, pc)
+        r = np.stack([u, v], -1) - uv
+        J2 = J.reshape(-1, 2, 3)[:, :, :2]
+        pc[:, :2] += np.linalg.solve(J2, r[:, :, None])[:, :, 0]
+    max_fov = 0.55  # radians: a cone through the image (the corners of this camera sit at ~0.74)
+    nf = 3000
+    dth = np.array([0.0, 1e-15, -1e-15, 1e-14, -1e-14, 1e-13, -1e-13, 1e-12, -1e-12, 1e-10, -1e-10, 1e-8, -1e-8])
+    th = max_fov + dth[rng.integers(0, len(dth), nf)]
+    ph = rng.uniform(0, 2 * np.pi, nf)
+    rr = rng.uniform(1.5, 25.0, nf)
+    cone = np.stack([rr * np.sin(th) * np.cos(ph), rr * np.sin(th) * np.sin(ph), rr * np.cos(th)], -1)
+    pc = np.concatenate([pc, cone, np.zeros((3, 3))])  # and points at the camera centre (|p_cam| = 0)
+    pl = (pc - t) @ R  # R^T (p_cam - t)
+    pts = np.concatenate([pl, np.ones((pl.shape[0], 1))], -1)
+    ints = (np.floor(rng.random(pts.shape[0]) * 256) / 256).astype(np.float64)
+    proj = nid.create_camera("plumb_bob", intr, dist)
+    for bins in (256, 16):
+        ref_cost, ref_hist = oracle_lib.cost_calculator_nid("plumb_bob", intr, dist, s.image_u8, pts, ints, bins, max_fov, T, want_hist=True)
+        calc = nid.CostCalculatorNID(proj, s.image_u8, pts, ints, nid.NIDCostParams(bins), max_fov=max_fov)
+        assert calc.info()["nearest_fast"] == 1 and calc.info()["float32_records"] == 0
+        c = calc.calculate(T)
+        fx_, inl, frac = calc.histogram_fixed()
+        assert np.array_equal(fx_, ref_hist) and inl == ref_hist.sum()
+        assert abs(c - ref_cost) <= 1e-12
+        assert 0.2 * pts.shape[0] < inl < 0.95 * pts.shape[0]  # the cone and the border really cut the set
+        calc.close()
+    # float records (what PLY data gives): the placement is lost to the float rounding, the decisions must still agree
+    pts32 = pts.astype(np.float32).astype(np.float64)
+    ref_cost, ref_hist = oracle_lib.cost_calculator_nid("plumb_bob", intr, dist, s.image_u8, pts32, ints, 256, max_fov, T, want_hist=True)
+    calc = nid.CostCalculatorNID(proj, s.image_u8, pts32, ints, nid.NIDCostParams(256), max_fov=max_fov)
+    assert calc.info()["float32_records"] == 1
+    calc.calculate(T)
+    assert np.array_equal(calc.histogram_fixed()[0], ref_hist)
+    calc.close()
+    # a cone close to 90 degrees, another camera model: no fast tier
+    wide = nid.CostCalculatorNID(proj, s.image_u8, pts32, ints, nid.NIDCostParams(256), max_fov=1.5)
+    assert wide.info()["nearest_fast"] == 0
+    wide.close()
