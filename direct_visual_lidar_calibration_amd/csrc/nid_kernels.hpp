@@ -554,17 +554,22 @@ struct NearestFast {
   int on;         // 0: exact tier only (other camera models, max_fov close to 90 degrees, fp32 geometry)
 };
 
+// LDS of the NEAREST kernel: the tile counts POINTS, and a workgroup's chunk holds fewer than 2^32 of them -- 32-bit cells
+// (ds_add_u32, half the LDS of the SPLINE tiles: 16 KB at 256 cells x 16 copies), summed to 64 bits in the flush
+__host__ __device__ __forceinline__ size_t nearest_hist_lds_bytes(int B, int GW, int cshift) { return (((size_t(GW) * size_t(B) * 4 << cshift) + 7) & ~size_t(7)) + size_t(GW) * 8 + 16; }
+// five waves per SIMD for the fast-tier instantiation (96 VGPRs, nothing spilled; 104-106 without the bound)
+constexpr int nearest_min_waves(int model, bool is_double, bool rec32, bool seg) { return (model == MODEL_PLUMB_BOB && is_double && rec32 && !seg) ? 5 : 1; }
 template <int MODEL, typename Rec, typename real, bool MULTI, bool SEG>
-__global__ __launch_bounds__(kThreads) void k_nearest_hist(
+__global__ __launch_bounds__(kThreads, nearest_min_waves(MODEL, std::is_same<real, double>::value, sizeof(Rec) == sizeof(Rec32), SEG)) void k_nearest_hist(
   const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint32_t* __restrict__ gend, const uint8_t* __restrict__ img, int pitch, int W, int H, IsoParams<real> iso,
   CamParams<real> cam, int B, int GW, int cshift, real cos_fov, NearestFast fast, u64* __restrict__ hist, const ShardTable* __restrict__ ann, u64 ann_seq, unsigned int* ann_ticket,
   const MultiEntry* __restrict__ multi, typename multi_dyn_of<MULTI>::type dyn) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  u64* tile = reinterpret_cast<u64*>(smem);
+  uint32_t* tile = reinterpret_cast<uint32_t*>(smem);
   const int tile_n = GW * B;
   const int tile_w = tile_n << cshift;
   const uint32_t cmask = (1u << cshift) - 1u;
-  u64* s_colsum = tile + tile_w;  // GW words: this workgroup's contribution to each column sum
+  u64* s_colsum = reinterpret_cast<u64*>(smem + ((size_t(tile_w) * 4 + 7) & ~size_t(7)));  // GW words: this workgroup's contribution to each column sum
   unsigned int* s_inl = reinterpret_cast<unsigned int*>(s_colsum + GW);
 
   const int tid = threadIdx.x;
@@ -673,7 +678,7 @@ __global__ __launch_bounds__(kThreads) void k_nearest_hist(
       for (int k = 0; k < kUnroll; k++) {
         if (ins[k]) {
           inl++;
-          atomicAdd(&tile[((((bins_[k] - col0) * uint32_t(B)) + rs_[k]) << cshift) + (uint32_t(tid) & cmask)], u64(1));
+          atomicAdd(&tile[((((bins_[k] - col0) * uint32_t(B)) + rs_[k]) << cshift) + (uint32_t(tid) & cmask)], 1u);
         }
       }
     }

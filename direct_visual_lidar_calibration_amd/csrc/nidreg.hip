@@ -746,7 +746,13 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
   *out = nullptr;
   if (d->struct_size != int32_t(sizeof(nidreg_desc))) return fail(NIDREG_ERR_INVALID, "nidreg_create: struct_size mismatch");
   if (d->model_id < 0 || d->model_id > 5) return fail(NIDREG_ERR_INVALID, "nidreg_create: unknown camera model");
-  if (d->bins < 2 || d->bins > NIDREG_MAX_BINS) return fail(NIDREG_ERR_INVALID, "nidreg_create: bins must be in [2, 256]");
+  // The reference takes any int (src/calibrate.cpp:175 --nid_bins, nid_cost.hpp:23); its own data path quantises BOTH inputs
+  // to 256 levels before the cost sees them -- the camera image is 8-bit (pix = k / 255, visual_camera_calibration.cpp:204),
+  // the LiDAR intensities are rank-equalised to floor(256 i / n) / 256 (preprocess.cpp:464-473) -- so more than 256 bins
+  // only adds rows and columns that stay empty.  The kernels' layouts (8-bit bin image, one histogram column of <= 256 cells
+  // per LDS tile) are built on that bound: refused, not truncated.
+  if (d->bins < 2 || d->bins > NIDREG_MAX_BINS)
+    return fail(NIDREG_ERR_INVALID, "nidreg_create: bins must be in [2, 256] (the reference accepts any --nid_bins, but its 8-bit images and 256-level equalised intensities fill at most 256 bins per axis; larger histograms are refused, not truncated)");
   if (d->width < 1 || d->height < 1 || (!d->image && !opts.shard)) return fail(NIDREG_ERR_INVALID, "nidreg_create: bad image");
   const nidreg_handle* master = opts.shard ? opts.master : nullptr;
   if (opts.shard && !master) return fail(NIDREG_ERR_INVALID, "nidreg_create: shard without a master");
@@ -804,7 +810,7 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
   h->cshift = cshift;
   h->NG = (B + GW - 1) / GW;
   h->NEB = (B + kEntropyCols - 1) / kEntropyCols;
-  h->lds_hist = (size_t(GW) * B * 8 << cshift) + size_t(GW) * 8 + 16;
+  h->lds_hist = d->mode == NIDREG_MODE_NEAREST ? nearest_hist_lds_bytes(B, GW, cshift) : (size_t(GW) * B * 8 << cshift) + size_t(GW) * 8 + 16;
   // gradient pass: a single-column workgroup (GW = 1) keeps ONE copy of its G column (k_spline_grad<.., GW1>)
   h->lds_grad = spline_grad_lds_bytes(B, GW, cshift, false);  // G tile, reduction scratch, phi(q_r), flag (+ staged columns once the table is known to need them)
   h->lds_entropy = size_t(B) * 8 + size_t(GW) * 8 + size_t(kWaves) * 8;

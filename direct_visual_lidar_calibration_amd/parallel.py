@@ -25,56 +25,20 @@ def shard_slice(num_points, rank, world):
     return lo, hi
 
 
-def exchange_slices(words, n):
-    """Word ranges of the in-library histogram exchange (csrc/nid_kernels.hpp k_shard_exchange): shard ``g`` sums words
-    ``[words*g//n, words*(g+1)//n)`` over all partial histograms and delivers them to every shard."""
-    return [(words * g // n, words * (g + 1) // n) for g in range(n)]
-
-
-def one_shot_all_reduce(t, group=None):
-    """The exchange kernel's data movement spelled with torch.distributed primitives every backend has (the CPU tests
-    drive it over gloo): every rank reads its slice of every peer's partial (here: an all-gather of the partials, of
-    which it uses its slice), sums it, and the summed slices are gathered back into everybody's full buffer.
-    Integer tensors: the result equals ``dist.all_reduce(t, SUM)`` bit for bit."""
-    n = dist.get_world_size(group)
-    me = dist.get_rank(group)
-    parts = [torch.empty_like(t) for _ in range(n)]
-    dist.all_gather(parts, t, group=group)
-    lo, hi = exchange_slices(t.numel(), n)[me]
-    mine = torch.zeros(hi - lo, dtype=t.dtype)
-    for p_ in parts:
-        mine += p_[lo:hi]
-    sizes = [b - a for a, b in exchange_slices(t.numel(), n)]
-    width = max(sizes) if sizes else 0
-    padded = torch.zeros(width, dtype=t.dtype)
-    padded[: hi - lo] = mine
-    gathered = [torch.empty_like(padded) for _ in range(n)]
-    dist.all_gather(gathered, padded, group=group)
-    out = torch.empty_like(t)
-    for g, (a, b) in enumerate(exchange_slices(t.numel(), n)):
-        out[a:b] = gathered[g][: b - a]
-    t.copy_(out)
-    return t
-
-
 class ShardedEvaluator:
     """Split-phase protocol over any backend exposing
     ``shard_hist(x)``, ``hist_tensor`` (int64), ``shard_entropy()``, ``shard_grad()``,
     ``grad_tensor`` (float64[7]) and ``shard_finish(want_grad) -> (ok, cost, grad)``."""
 
-    def __init__(self, backend, group=None, one_shot=False):
+    def __init__(self, backend, group=None):
         self.backend = backend
         self.group = group
-        self.one_shot = one_shot  # histogram exchange by the in-library kernel's slice protocol instead of all_reduce
 
     def __call__(self, x, want_grad=True):
         b = self.backend
         b.shard_hist(x)
         if dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            if self.one_shot:
-                one_shot_all_reduce(b.hist_tensor, self.group)
-            else:
-                dist.all_reduce(b.hist_tensor, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(b.hist_tensor, op=dist.ReduceOp.SUM, group=self.group)
         b.shard_entropy()
         if want_grad:
             b.shard_grad()

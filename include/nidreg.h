@@ -103,7 +103,10 @@ typedef struct nidreg_desc {
   int32_t model_id;         /* NIDREG_MODEL_* */
   int32_t mode;             /* NIDREG_MODE_* */
   int32_t precision;        /* NIDREG_PREC_* */
-  int32_t bins;             /* nid_bins, 2..256 */
+  int32_t bins;             /* nid_bins, 2..256.  The reference takes any int (src/calibrate.cpp:175, nid_cost.hpp:23), but its data path
+                               quantises both inputs to 256 levels (8-bit images, visual_camera_calibration.cpp:204; intensities equalised to
+                               floor(256 i / n) / 256, preprocess.cpp:464-473): more bins only add empty rows / columns.  Larger values are
+                               REFUSED with NIDREG_ERR_INVALID (tests/test_abi.py), never truncated. */
   double intrinsics[5];     /* exactly the model's count is read */
   double distortion[8];     /* already zero-padded / truncated like create_camera.cpp:24-27 */
   int32_t width, height;    /* image cols, rows */
