@@ -694,6 +694,26 @@ int64_t fill_chunks(const int64_t* gcount, int NG, int64_t C, int64_t overhead, 
   return nchunks;
 }
 // returns the number of segments (= gradient partial slots) of the table appended to `chunks`
+// smallest cost bound for which the fill needs <= target chunks (or, when even one chunk per group is too many, the bound that
+// gives one chunk per group) -- and the number of chunks at that bound
+int64_t best_bound(const int64_t* gcount, int NG, int64_t target, int64_t overhead, int max_segs, int64_t N, int64_t nonempty, int64_t* nchunks_out) {
+  // fill_chunks(C) is non-increasing in C; C = everything in one chunk always fits (as far as max_segs allows)
+  int64_t lo = overhead + 63, hi = N + nonempty * overhead + 64;  // lo: too small (or just feasible -- checked first), hi: feasible
+  if (fill_chunks(gcount, NG, lo + 1, overhead, max_segs, -1, nullptr) <= target) {
+    hi = lo + 1;
+  } else {
+    while (hi - lo > 1) {
+      const int64_t mid = lo + (hi - lo) / 2;
+      if (fill_chunks(gcount, NG, mid, overhead, max_segs, -1, nullptr) <= target) {
+        hi = mid;
+      } else {
+        lo = mid;
+      }
+    }
+  }
+  *nchunks_out = fill_chunks(gcount, NG, hi, overhead, max_segs, -1, nullptr);
+  return hi;
+}
 int64_t split_groups(const int64_t* gcount, int NG, int64_t target, int64_t overhead, int max_segs, int pair, std::vector<Chunk>& chunks) {
   const int64_t N = gcount[NG] - gcount[0];
   if (N <= 0) return 0;
@@ -702,22 +722,27 @@ int64_t split_groups(const int64_t* gcount, int NG, int64_t target, int64_t over
   max_segs = std::max(1, std::min(max_segs, kMaxSegs));
   int64_t nonempty = 0;
   for (int g = 0; g < NG; g++) nonempty += gcount[g + 1] > gcount[g] ? 1 : 0;
-  // fill_chunks(C) is non-increasing in C; C = everything in one chunk always fits
-  int64_t lo = overhead + 63, hi = N + nonempty * overhead + 64;  // lo: too small (or just feasible -- checked first), hi: feasible
-  if (fill_chunks(gcount, NG, lo + 1, overhead, max_segs, pair, nullptr) <= target) {
-    hi = lo + 1;
-  } else {
-    while (hi - lo > 1) {
-      const int64_t mid = lo + (hi - lo) / 2;
-      if (fill_chunks(gcount, NG, mid, overhead, max_segs, pair, nullptr) <= target) {
-        hi = mid;
-      } else {
-        lo = mid;
-      }
+  int64_t n_one = 0;
+  const int64_t c_one = best_bound(gcount, NG, target, overhead, 1, N, nonempty, &n_one);
+  int64_t bound = c_one;
+  int segs = 1;
+  if (max_segs > 1) {
+    // Chunks across groups only where they PAY: the looped kernel instantiations run 2-6 % slower per point than the
+    // straight-line ones (measured, profiles/r04c_culled_cloud_ab.jsonl: on clouds whose columns are nearly equally full the
+    // better balance did not make up for it), so the segmented table must beat the best one-group-per-chunk table by
+    // NIDREG_SEG_MIN_GAIN (default 10 %) in the cost model -- rounds x longest chunk -- to be chosen.
+    const char* mg = std::getenv("NIDREG_SEG_MIN_GAIN");
+    const double min_gain = mg ? std::max(0.0, std::strtod(mg, nullptr)) : 0.10;
+    int64_t n_seg = 0;
+    const int64_t c_seg = best_bound(gcount, NG, target, overhead, max_segs, N, nonempty, &n_seg);
+    const double t_one = double(c_one) * double((n_one + target - 1) / target), t_seg = double(c_seg) * double((n_seg + target - 1) / target);
+    if (t_seg * (1.0 + min_gain) < t_one) {
+      bound = c_seg;
+      segs = max_segs;
     }
   }
   int64_t nslots = 0;
-  fill_chunks(gcount, NG, hi, overhead, max_segs, pair, &chunks, &nslots);
+  fill_chunks(gcount, NG, bound, overhead, segs, pair, &chunks, &nslots);
   return nslots;
 }
 // records' worth of time one more segment costs a workgroup of the given kernel (measured orders of magnitude: a WIDE

@@ -943,14 +943,16 @@ def test_chunks_across_column_groups_match_one_group_per_chunk(model, monkeypatc
     ref = oracle_lib.nid_cost(s.model, s.intrinsics, s.distortion, s.image_f64, pts, ints, 256, x, want_hist=True)
     # (tuning, NIDREG_SEG_OVERHEAD): the default cost model keeps a cloud this small on one group per chunk; a small per-segment
     # cost, or few workgroups, makes the chunks run across groups -- in the gradient table and in the WIDE histogram table
-    for tuning, overhead, expect in (({}, None, None), ({}, "16", (1, 1)), ({"lds_copies": 16}, "16", (1, 0)), ({"target_blocks": 40}, None, (1, 1)), ({"target_blocks": 3000}, "0", None)):
+    for tuning, overhead, expect in (({}, None, None), ({}, "16", (1, 1)), ({"lds_copies": 16}, "16", (1, 0)), ({"target_blocks": 40}, "384", (1, 1)), ({"target_blocks": 3000}, "0", None)):
         if overhead is not None:
             monkeypatch.setenv("NIDREG_SEG_OVERHEAD", overhead)
+            monkeypatch.setenv("NIDREG_SEG_MIN_GAIN", "0")  # (by default a segmented table must win by 10 % in the cost model to be used)
         seg = nid.NIDCost(proj, s.image_f64, pts, ints, 256, **tuning)
         monkeypatch.setenv("NIDREG_MAX_SEGS", "1")
         one = nid.NIDCost(proj, s.image_f64, pts, ints, 256, **tuning)
         monkeypatch.delenv("NIDREG_MAX_SEGS")
         monkeypatch.delenv("NIDREG_SEG_OVERHEAD", raising=False)
+        monkeypatch.delenv("NIDREG_SEG_MIN_GAIN", raising=False)
         assert (one.info()["segmented"], one.info()["segmented_hist"]) == (0, 0)
         if expect is not None:
             assert (seg.info()["segmented"], seg.info()["segmented_hist"]) == expect, (tuning, overhead, seg.info())
@@ -977,7 +979,9 @@ def test_chunks_across_column_groups_match_one_group_per_chunk(model, monkeypatc
     for bins, tb in ((256, 0), (256, 48), (16, 0)):
         if bins != 256:
             ref_cost, ref_hist = oracle_lib.cost_calculator_nid(s.model, s.intrinsics, s.distortion, s.image_u8, pts, ints, bins, max_fov, T, want_hist=True)
+        monkeypatch.setenv("NIDREG_SEG_MIN_GAIN", "0")
         calc = nid.CostCalculatorNID(proj, s.image_u8, pts, ints, nid.NIDCostParams(bins), max_fov=max_fov, target_blocks=tb)
+        monkeypatch.delenv("NIDREG_SEG_MIN_GAIN")
         if tb:
             assert calc.info()["segmented"] == 1
         for _ in range(2):

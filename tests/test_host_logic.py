@@ -207,7 +207,9 @@ def test_chunk_tables_fit_one_round_of_workgroups():
                 # the longest chunk: no worse than an even share of the total cost plus one segment's overhead and rounding
                 # (a lower bound on any table of `target` chunks is (records + nonempty * overhead) / target)
                 # (+5 %: a chunk that reaches its segment limit closes early and the others take up the slack)
-                bound = 1.05 * (n_rec + (nonempty + target) * overhead) / target + overhead + 128
+                # (x 1.10: a table of one group per chunk is kept unless chunks across groups gain more than 10 % in the cost model --
+                # the looped kernel instantiations are a few per cent slower per point, NIDREG_SEG_MIN_GAIN)
+                bound = 1.10 * 1.05 * (n_rec + (nonempty + target) * overhead) / target + overhead + 128
                 assert max(costs) <= bound, (max(costs), bound, len(rows), target)
     # the uniform cloud keeps the table it always had: four equal parts per column
     rows, _ = table(np.full(256, 39062), 1024, 384)
@@ -216,4 +218,8 @@ def test_chunk_tables_fit_one_round_of_workgroups():
     assert len(rows) == 512 and rows[:, 1].max() <= 19584
     # a view-culled cloud: the longest chunk stays within a few per cent of the mean, where whole parts per column left 3/4 ... 3/2
     rows, g = table(culled, 1024, 384)
-    assert rows[:, 1].max() <= 1.08 * culled.sum() / 1024 + 64, (rows[:, 1].max(), culled.sum() / 1024)
+    assert rows[:, 1].max() <= 1.10 * 1.08 * culled.sum() / 1024 + 64, (rows[:, 1].max(), culled.sum() / 1024)
+    # two workgroups per column on average (the WIDE histogram kernel's table) and columns of 0 ... 60 000 points: chunks across
+    # groups win by more than the threshold and are used
+    rows, g = table(culled, 512, 1024)
+    assert (rows[-1, 3] >> 8) + 1 > len(rows) and rows[:, 1].max() <= 1.08 * culled.sum() / 512 + 64

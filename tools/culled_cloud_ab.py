@@ -5,7 +5,9 @@ subset's columns are not.  Builds the cost object with nidreg_create_from_cloud 
 tables of one column group per chunk (NIDREG_MAX_SEGS=1: the constraint of rounds 1-3) and with chunks that may run across
 groups (round 4, csrc/nidreg.hip split_groups), prints table sizes, microseconds per evaluation, per-kernel event times and
 nanoseconds per kept point.
-Usage: culled_cloud_ab.py [points] [camera] [shift_m]"""
+`skew`: the pushed-out copy carries darker surfaces (intensity^2) and the intensities are rank-equalised over the WHOLE cloud,
+as preprocess.cpp:464-473 does for a whole map: the culled subset's histogram columns are then far from equally full.
+Usage: culled_cloud_ab.py [points] [camera] [shift_m] [skew]"""
 import json
 import os
 import sys
@@ -20,6 +22,7 @@ from direct_visual_lidar_calibration_amd import nid, se3, synth  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 camera = sys.argv[2] if len(sys.argv) > 2 else "pinhole_1080p"
 shift = float(sys.argv[3]) if len(sys.argv) > 3 else 6.0
+skew = len(sys.argv) > 4 and sys.argv[4] == "skew"
 s = synth.make_scene(camera, num_points=n, seed=20250525, device="cuda:0")
 proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
 # a cloud that covers more than the view, so that culling removes a non-uniform part of every column: the scene's points
@@ -27,11 +30,17 @@ proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
 moved = (s.points + np.array([shift, 0.0, 0.0, 0.0])).astype(np.float32).astype(np.float64)
 pts = np.concatenate([s.points, moved])
 ints = np.concatenate([s.intensities, s.intensities[::-1]])
+if skew:
+    raw = np.concatenate([s.intensities, s.intensities[::-1] ** 2])
+    order = np.argsort(raw, kind="stable")
+    ranks = np.empty(raw.shape[0], dtype=np.int64)
+    ranks[order] = np.arange(raw.shape[0])
+    ints = np.floor(256.0 * ranks / raw.shape[0]) / 256.0
 cloud = nid.Cloud(pts, ints)
 T = se3.to_matrix(s.T_camera_lidar_init)
 rng = np.random.default_rng(5)
 poses = np.ascontiguousarray([synth.random_pose_near(s.T_camera_lidar_true, rng) for _ in range(40)])
-out = {"camera": camera, "input_points": int(pts.shape[0])}
+out = {"camera": camera, "input_points": int(pts.shape[0]), "skew": bool(skew)}
 ref = None
 for label, env in (("one_group_per_chunk", "1"), ("chunks_across_groups", None)):
     if env:
