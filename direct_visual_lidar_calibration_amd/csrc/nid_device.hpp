@@ -655,6 +655,32 @@ __device__ __forceinline__ void load_rec(const Rec64* p, real& x, real& y, real&
   bin = uint32_t(__double_as_longlong(b.y));
 }
 
+// kUnroll-deep batch of RAW records: what the loads return, not yet converted -- so that a batch can be in flight across a
+// workgroup's prologue (tile zeroing, entropy tail, G tile) without the conversion forcing the wait (nid_kernels.hpp)
+template <typename Rec, int N>
+struct RawBatch;
+template <int N>
+struct RawBatch<Rec32, N> {
+  float4 v[N];
+  __device__ __forceinline__ void load(const char* rec_base, uint32_t byte_off, int k) { v[k] = *reinterpret_cast<const float4*>(rec_base + size_t(byte_off)); }
+  template <typename real>
+  __device__ __forceinline__ void get(int k, real& x, real& y, real& z, uint32_t& bin) const {
+    x = real(v[k].x), y = real(v[k].y), z = real(v[k].z), bin = __float_as_uint(v[k].w);
+  }
+};
+template <int N>
+struct RawBatch<Rec64, N> {
+  double2 a[N], b[N];
+  __device__ __forceinline__ void load(const char* rec_base, uint32_t byte_off, int k) {
+    a[k] = reinterpret_cast<const double2*>(rec_base + size_t(byte_off))[0];
+    b[k] = reinterpret_cast<const double2*>(rec_base + size_t(byte_off))[1];
+  }
+  template <typename real>
+  __device__ __forceinline__ void get(int k, real& x, real& y, real& z, uint32_t& bin) const {
+    x = real(a[k].x), y = real(a[k].y), z = real(b[k].x), bin = uint32_t(__double_as_longlong(b[k].y));
+  }
+};
+
 struct Chunk {  // one workgroup's slice of the bucketed cloud
   uint32_t start;
   uint32_t count;

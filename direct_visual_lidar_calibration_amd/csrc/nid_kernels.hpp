@@ -377,6 +377,20 @@ __device__ __forceinline__ void spline_hist_body(
   const BsplineScale KU = bspline_scale(dn_scale);  // uniform: the x-weight polynomial's constants in fixed-point units
 
   Segments seg(gend, ch);
+  // the chunk's first batch of records is requested BEFORE the tile is zeroed: its HBM latency (~2 us) runs under the 64 KB of
+  // LDS stores and the barrier instead of after them (raw records: nothing touches the loaded registers until the point loop)
+  RawBatch<Rec, kUnroll> rb;
+#ifndef NID_NO_PREFETCH0
+  if constexpr (!SEG) {  // (the looped instantiations have no registers to spare for it)
+    const uint32_t cnt0 = seg.end - seg.pos;
+    const char* rec_base0 = reinterpret_cast<const char*>(pts + seg.pos);
+#pragma unroll
+    for (int k = 0; k < kUnroll; k++) rb.load(rec_base0, min(uint32_t(k) * kT + tid, cnt0 - 1u) * uint32_t(sizeof(Rec)), k);
+  }
+  bool have_batch = !SEG;
+#else
+  bool have_batch = false;
+#endif
   for (;;) {
     // a zeroed tile for every segment (coalesced stores; zeroing inside the flush below -- 32 more LDS addresses per thread in the
     // WIDE kernel -- took the looped kernel from 93 to 161 VGPRs)
@@ -430,11 +444,13 @@ __device__ __forceinline__ void spline_hist_body(
       set_progress_priority(prio, seg.pos - ch.start + base, ch.count);
       real xs[kUnroll], ys[kUnroll], zs[kUnroll];
       uint32_t bins_[kUnroll];
+      if (!have_batch) {  // uniform (false only for a chunk's very first batch)
 #pragma unroll
-      for (int k = 0; k < kUnroll; k++) {
-        const uint32_t ii = min(base + uint32_t(k) * kT + tid, cnt - 1u);
-        load_rec<real>(reinterpret_cast<const Rec*>(rec_base + size_t(ii * uint32_t(sizeof(Rec)))), xs[k], ys[k], zs[k], bins_[k]);
+        for (int k = 0; k < kUnroll; k++) rb.load(rec_base, min(base + uint32_t(k) * kT + tid, cnt - 1u) * uint32_t(sizeof(Rec)), k);
       }
+      have_batch = false;
+#pragma unroll
+      for (int k = 0; k < kUnroll; k++) rb.template get<real>(k, xs[k], ys[k], zs[k], bins_[k]);
       real us[kUnroll], vs[kUnroll];
       bool ins[kUnroll];
       bool all_in = true;
@@ -792,8 +808,16 @@ __device__ __forceinline__ void entropy_final_body(
 // thread does 4 loads and 4 logs instead of 16 (with one 256-thread workgroup per CU the 16 dependent log chains of a
 // wave ran at single-wave latency: 13.8 -> see DESIGN.md section 6) and four waves per SIMD overlap them; the four
 // quarter-row partials meet in LDS.
-constexpr int kEntropyColsMax = 16;
-constexpr int kEntropyThreads = 1024;
+// (NID_ENTROPY_COLS / NID_ENTROPY_THREADS: A/B builds with more, smaller workgroups -- 4 / 256 = 64 workgroups at B = 256)
+#ifndef NID_ENTROPY_COLS
+#define NID_ENTROPY_COLS 16
+#endif
+#ifndef NID_ENTROPY_THREADS
+#define NID_ENTROPY_THREADS 1024
+#endif
+constexpr int kEntropyColsMax = NID_ENTROPY_COLS;
+constexpr int kEntropyThreads = NID_ENTROPY_THREADS;
+static_assert(kEntropyThreads % 256 == 0 && kEntropyThreads <= 1024 && kEntropyColsMax % (kEntropyThreads / 256) == 0, "k_entropy: thread (r, q) takes row r of columns q kPer ... q kPer + kPer - 1");
 constexpr int kEntropyWaves = kEntropyThreads / 64;
 template <bool MULTI>
 __global__ __launch_bounds__(kEntropyThreads) void k_entropy(
@@ -862,7 +886,9 @@ __global__ __launch_bounds__(kEntropyThreads) void k_entropy(
   // Whoever runs the tail (this kernel's last workgroup, or every workgroup of k_spline_grad) reads B + 1 finished words
   // instead of summing NEB x B partials (the gradient prologue read 32 KB per workgroup, 32 MB over the grid, before).
   if (q == 0 && r < B) {
-    const u64 t = row + s_row[0][r] + s_row[1][r] + s_row[2][r];
+    u64 t = row;
+#pragma unroll
+    for (int i = 0; i < kEntropyThreads / 256 - 1; i++) t += s_row[i][r];
     if (t) atomicAdd(&hist[hist_row_sums_at(B) + size_t(r)], t);
   }
   if (tid < 64) {  // the sixteen wave partials, summed by one wave instead of a serial loop of LDS reads
@@ -961,7 +987,12 @@ __global__ __launch_bounds__(kEntropyThreads) void k_entropy_owned(
   acc = wave_sum(acc);
   if ((tid & 63) == 0) s_red[tid >> 6] = acc;
   __syncthreads();
-  if (q == 0 && r < B) row_part[size_t(j) * size_t(B) + r] = row + s_row[0][r] + s_row[1][r] + s_row[2][r];
+  if (q == 0 && r < B) {
+    u64 t = row;
+#pragma unroll
+    for (int i = 0; i < kEntropyThreads / 256 - 1; i++) t += s_row[i][r];
+    row_part[size_t(j) * size_t(B) + r] = t;
+  }
   if (tid < 64) {
     const long long t = wave_sum(tid < kEntropyWaves ? s_red[tid] : 0ll);
     if (tid == 0) part_hj[j] = t;
@@ -1048,7 +1079,7 @@ enum { TAP_COPIES = 0,   // gtile[(cell << cshift) + lane copy]: lane-private co
 template <int MODEL, typename Rec, typename real, int TAP, int kT>
 __device__ __forceinline__ void spline_grad_loop(
   const Rec* __restrict__ recs, uint32_t cnt, uint32_t col0, uint32_t done, uint32_t total, const uint8_t* __restrict__ img, int pitch, int W, int H, const PoseParams<real>& pose,
-  const CamParams<real>& cam, int B, int cshift, const double* gtile, double* acc, bool prio) {
+  const CamParams<real>& cam, int B, int cshift, const double* gtile, double* acc, bool prio, RawBatch<Rec, kUnroll>& rb, bool have_batch) {
   const int tid = threadIdx.x;
   if (TAP == TAP_SINGLE) cshift = 0;
   const uint32_t cmask = (1u << cshift) - 1u;
@@ -1060,11 +1091,13 @@ __device__ __forceinline__ void spline_grad_loop(
     set_progress_priority(prio, done + base, total);
     real xs[kUnroll], ys[kUnroll], zs[kUnroll];
     uint32_t bins_[kUnroll];
+    if (!have_batch) {  // uniform (false only for a chunk's very first batch, requested ahead of the kernel's prologue)
 #pragma unroll
-    for (int k = 0; k < kUnroll; k++) {
-      const uint32_t ii = min(base + uint32_t(k) * kT + tid, cnt - 1u);
-      load_rec<real>(reinterpret_cast<const Rec*>(rec_base + size_t(ii * uint32_t(sizeof(Rec)))), xs[k], ys[k], zs[k], bins_[k]);
+      for (int k = 0; k < kUnroll; k++) rb.load(rec_base, min(base + uint32_t(k) * kT + tid, cnt - 1u) * uint32_t(sizeof(Rec)), k);
     }
+    have_batch = false;
+#pragma unroll
+    for (int k = 0; k < kUnroll; k++) rb.template get<real>(k, xs[k], ys[k], zs[k], bins_[k]);
 #pragma unroll
     for (int k = 0; k < kUnroll; k++) {
       // (a branch-free body like k_spline_hist's was measured 15 % slower here: 173 VGPRs, 2 waves/SIMD)
@@ -1282,6 +1315,21 @@ __global__ __launch_bounds__(kThreads, grad_min_waves(MODEL, SEG, sizeof(Rec) ==
     gt.hist_points = as_global(e.hist_points);
     gt.scal = as_global(e.scal);
   }
+  // the chunk's first batch of records is requested before the prologue (entropy tail, G tile: two dependent trips to L2 and a
+  // few hundred instructions): its HBM latency runs under them
+  RawBatch<Rec, kUnroll> rb;
+#ifndef NID_NO_PREFETCH0
+  if constexpr (!SEG) {  // (the looped instantiations have no registers to spare for it)
+    Segments s0(gend, ch);
+    const uint32_t cnt0 = s0.end - s0.pos;
+    const char* rec_base0 = reinterpret_cast<const char*>(pts + s0.pos);
+#pragma unroll
+    for (int k = 0; k < kUnroll; k++) rb.load(rec_base0, min(uint32_t(k) * kThreads + tid, cnt0 - 1u) * uint32_t(sizeof(Rec)), k);
+  }
+  bool have_batch = !SEG;
+#else
+  bool have_batch = false;
+#endif
   {
     double coefA, coefB, S;
     if (gt.from_partials) {
@@ -1318,7 +1366,8 @@ __global__ __launch_bounds__(kThreads, grad_min_waves(MODEL, SEG, sizeof(Rec) ==
     }
     const uint32_t seg_end = SEG ? seg.seg_end() : seg.end;
     spline_grad_loop<MODEL, Rec, real, GW1 ? TAP_SINGLE : TAP_COPIES, kThreads>(pts + seg.pos, seg_end - seg.pos, seg.g * uint32_t(GW), seg.pos - ch.start, ch.count, img, pitch, W, H, pose,
-                                                                               cam, B, cshift, gtile, acc, prio != 0);
+                                                                               cam, B, cshift, gtile, acc, prio != 0, rb, have_batch);
+    have_batch = false;
     grad_reduce_store<kThreads>(acc, s_red, partials, slot, nslots);
     if (!SEG || !seg.advance(seg_end)) break;
     slot++;

@@ -54,7 +54,7 @@ inline int cast_int(double d) {
   return static_cast<int>(d);
 }
 
-constexpr int kEntropyCols = 16;  // histogram columns per k_entropy_partial workgroup
+constexpr int kEntropyCols = kEntropyColsMax;  // histogram columns per k_entropy workgroup (nid_kernels.hpp)
 const int kNumIntr[6] = {4, 4, 5, 2, 4, 4};
 const int kNumDist[6] = {5, 4, 4, 0, 1, 8};
 
