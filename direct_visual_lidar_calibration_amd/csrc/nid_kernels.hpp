@@ -377,10 +377,12 @@ __device__ __forceinline__ void spline_hist_body(
   const BsplineScale KU = bspline_scale(dn_scale);  // uniform: the x-weight polynomial's constants in fixed-point units
 
   Segments seg(gend, ch);
-  // the chunk's first batch of records is requested BEFORE the tile is zeroed: its HBM latency (~2 us) runs under the 64 KB of
-  // LDS stores and the barrier instead of after them (raw records: nothing touches the loaded registers until the point loop)
+  // -DNID_PREFETCH0 (experiment, off): the chunk's first batch of records requested BEFORE the tile is zeroed, so that its HBM
+  // latency runs under the 64 KB of LDS stores and the barrier (raw records: nothing touches the loaded registers until the
+  // point loop).  Measured on cfg 2 (profiles/r04d_variants.txt): histogram kernel unchanged (51.5-51.9 us either way), the
+  // gradient kernel +2 us with its counterpart (the compiler peels the first iteration: 3963 instead of 2960 instructions).
   RawBatch<Rec, kUnroll> rb;
-#ifndef NID_NO_PREFETCH0
+#ifdef NID_PREFETCH0
   if constexpr (!SEG) {  // (the looped instantiations have no registers to spare for it)
     const uint32_t cnt0 = seg.end - seg.pos;
     const char* rec_base0 = reinterpret_cast<const char*>(pts + seg.pos);
@@ -804,16 +806,16 @@ __device__ __forceinline__ void entropy_final_body(
   }
 }
 
-// 16 columns per workgroup, 1024 threads: thread (r = tid & 255, q = tid >> 8) takes row r of columns 4q .. 4q+3, so a
-// thread does 4 loads and 4 logs instead of 16 (with one 256-thread workgroup per CU the 16 dependent log chains of a
-// wave ran at single-wave latency: 13.8 -> see DESIGN.md section 6) and four waves per SIMD overlap them; the four
-// quarter-row partials meet in LDS.
-// (NID_ENTROPY_COLS / NID_ENTROPY_THREADS: A/B builds with more, smaller workgroups -- 4 / 256 = 64 workgroups at B = 256)
+// NID_ENTROPY_COLS columns per workgroup of NID_ENTROPY_THREADS threads: thread (r = tid & 255, q = tid >> 8) takes row r of
+// columns 4q .. 4q+3, i.e. 4 loads and 4 logs per thread (with one 256-thread workgroup per 16 columns the 16 dependent log
+// chains of a wave ran at single-wave latency: 13.8 us); the quarter-row partials meet in LDS.
+// Round 4: 8 columns x 512 threads (32 workgroups at B = 256) instead of 16 x 1024 (16 workgroups): 8.8 -> 7.2 us event-timed
+// on cfg 2, 4 x 256 (64 workgroups) the same (profiles/r04d_variants.txt).
 #ifndef NID_ENTROPY_COLS
-#define NID_ENTROPY_COLS 16
+#define NID_ENTROPY_COLS 8
 #endif
 #ifndef NID_ENTROPY_THREADS
-#define NID_ENTROPY_THREADS 1024
+#define NID_ENTROPY_THREADS 512
 #endif
 constexpr int kEntropyColsMax = NID_ENTROPY_COLS;
 constexpr int kEntropyThreads = NID_ENTROPY_THREADS;
@@ -1315,10 +1317,11 @@ __global__ __launch_bounds__(kThreads, grad_min_waves(MODEL, SEG, sizeof(Rec) ==
     gt.hist_points = as_global(e.hist_points);
     gt.scal = as_global(e.scal);
   }
-  // the chunk's first batch of records is requested before the prologue (entropy tail, G tile: two dependent trips to L2 and a
-  // few hundred instructions): its HBM latency runs under them
+  // -DNID_PREFETCH0 (experiment, off; see spline_hist_body): the chunk's first batch of records requested before the prologue
+  // (entropy tail, G tile: two dependent trips to L2 and a few hundred instructions) -- measured 2 us SLOWER (75.6-76.2 ->
+  // 77.5-78.4 us, profiles/r04d_variants.txt)
   RawBatch<Rec, kUnroll> rb;
-#ifndef NID_NO_PREFETCH0
+#ifdef NID_PREFETCH0
   if constexpr (!SEG) {  // (the looped instantiations have no registers to spare for it)
     Segments s0(gend, ch);
     const uint32_t cnt0 = s0.end - s0.pos;
