@@ -3,8 +3,8 @@ seeded inputs.  Run with ``pytest -m gpu`` on an MI355X.
 
 Tolerances (ours; the reference defines none -- SURVEY.md section 7):
   * NEAREST (CostCalculatorNID): integer joint histogram BIT-EXACT; NID abs <= 1e-12.
-  * SPLINE  (NIDCost), fp64: raw joint histogram abs <= 1e-9 per bin (fixed point 2^-39..2^-40
-    per tap); NID abs <= 1e-10; 7-gradient rel <= 1e-7 (+ abs 1e-10).
+  * SPLINE  (NIDCost), fp64: the bars of tests/parity.py, set from the margins the suite observes (raw joint histogram abs
+    <= 1e-9 per bin -- fixed point 2^-39..2^-40 per tap --, NID abs <= 1e-11, 7-gradient rel <= 2e-9 + abs 1e-11).
   * SPLINE fp32 geometry: NID abs <= 2e-5, gradient rel <= 2e-2 of its norm.
 """
 import numpy as np
@@ -274,7 +274,7 @@ def test_multi_nid_cost_sum_and_trust_gate():
     ok, c, g = multi(x)
     rok, rc, rg = oracle_lib.multi_nid_cost(s1.model, s1.intrinsics, s1.distortion, pairs, 16, init, x)
     assert ok and rok
-    parity.check_cost(c, rc, atol=2e-10)
+    parity.check_cost(c, rc, atol=4 * parity.COST_ATOL)  # a sum over the set's pairs
     parity.check_grad(g, rg)
     # outside the 0.2 m / 2 deg gate -> false without evaluating
     for delta in ([0.25, 0, 0, 0, 0, 0], [0, 0, 0, 0, np.radians(2.5), 0]):
@@ -497,7 +497,7 @@ def test_headline_workload_10m_points_matches_oracle():
     joint, hi, hp = cost.histograms()
     # 2^-38 per tap, <= ~2500 taps in the fullest bin; the oracle's own double sums round at ~1e-12 there
     assert np.array_equal(hp, ref["hist_points"])
-    parity.check_hist(joint, ref["hist"], atol=1e-8, what="10M points")
+    parity.check_hist(joint, ref["hist"], atol=parity.hist_atol_for(ref["hist"], info["frac_bits"]), what="10M points")
     assert hp.sum() == ref["hist_points"].sum()
     cost.close()
 
@@ -542,7 +542,7 @@ def test_dense_map_50m_points_4k_image_matches_oracle():
     joint, hi, hp = cost.histograms()
     # 2^-36 per tap, <= ~12 000 taps in the fullest bin
     assert np.array_equal(hp, ref["hist_points"])
-    parity.check_hist(joint, ref["hist"], atol=1e-7, what="50M points")
+    parity.check_hist(joint, ref["hist"], atol=parity.hist_atol_for(ref["hist"], info["frac_bits"]), what="50M points")
     assert hp.sum() == ref["hist_points"].sum()
     ok2, c2, g2 = cost(x, want_grad=False)
     assert ok2 and c2 == c
