@@ -73,6 +73,8 @@ struct nidreg_handle {
   int nchunks = 0;       // gradient pass / generic histogram kernels
   int nslots = 0;        // segments in that table = 12-double partials of the gradient pass (>= nchunks)
   int seg = 0, seg_hist = 0;  // the table (d_chunks / d_chunks_hist) has chunks that run across column groups: SEG kernels
+  size_t chunks_cap = 0, chunks_hist_cap = 0;  // entries allocated behind d_chunks / d_chunks_hist
+  struct Cohort* cohort = nullptr;  // NIDREG_COHORT=1: the handles created together for one MultiNIDCost share ONE round of workgroups
   int nchunks_hist = 0;  // WIDE histogram kernel's own table (0 = shares d_chunks)
   double intr[5] = {0}, dist[8] = {0};
   double max_fov = 0.0;
@@ -141,6 +143,14 @@ struct nidreg_handle {
   double last_t[3] = {0, 0, 0};
 };
 
+// the handles created together for one MultiNIDCost (NIDREG_COHORT=1; see "cohorts" below)
+struct Cohort {
+  std::mutex mu;
+  std::vector<nidreg_handle*> members;
+  std::atomic<bool> sealed{false};
+  int device = 0;
+};
+
 // One LiDAR-camera pair spread over several GPUs (BASELINE north_star: "disjoint point slices with a final all-reduce of the
 // 2D histogram over xGMI"), driven by ONE host process.  The slices are cut along the pose-independent histogram column
 // ("shard by histogram column"): shard g holds the points of a contiguous range of column groups, chosen from
@@ -180,6 +190,7 @@ namespace {
 
 void free_shard_set(ShardSet* set);
 void drop_groups_of(const nidreg_handle* h);
+void cohort_leave(nidreg_handle* h);
 
 void free_handle(nidreg_handle* h) {
   if (!h) return;
@@ -188,6 +199,7 @@ void free_handle(nidreg_handle* h) {
     h->set = nullptr;
   }
   drop_groups_of(h);
+  cohort_leave(h);
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->d_pts) (void)hipFree(h->d_pts);
@@ -989,14 +1001,16 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
     h->nchunks = int(chunks.size());
     h->seg = h->nslots > h->nchunks ? 1 : 0;
     if (h->seg && GW == 1) h->lds_grad = spline_grad_lds_bytes(B, GW, cshift, true);
-    CREATE_TRY(hipMalloc(&h->d_chunks, std::max<size_t>(chunks.size(), 1) * sizeof(Chunk)));
+    h->chunks_cap = std::max<size_t>(chunks.size(), 1);
+    CREATE_TRY(hipMalloc(&h->d_chunks, h->chunks_cap * sizeof(Chunk)));
     if (!chunks.empty()) CREATE_TRY(hipMemcpy(h->d_chunks, chunks.data(), chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice));
     if (h->wide) {
       std::vector<Chunk> wide_chunks;
       const int64_t wide_slots = build_chunks(d->target_blocks > 0 ? d->target_blocks : per_cu_hist * num_cus, true, wide_chunks);
       h->nchunks_hist = int(wide_chunks.size());
       h->seg_hist = wide_slots > int64_t(wide_chunks.size()) ? 1 : 0;
-      CREATE_TRY(hipMalloc(&h->d_chunks_hist, std::max<size_t>(wide_chunks.size(), 1) * sizeof(Chunk)));
+      h->chunks_hist_cap = std::max<size_t>(wide_chunks.size(), 1);
+      CREATE_TRY(hipMalloc(&h->d_chunks_hist, h->chunks_hist_cap * sizeof(Chunk)));
       if (!wide_chunks.empty()) CREATE_TRY(hipMemcpy(h->d_chunks_hist, wide_chunks.data(), wide_chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice));
     }
   }
@@ -1148,6 +1162,124 @@ bool groupable(const nidreg_handle* a, const nidreg_handle* b) {
 // chunks of one pair for a share `target` of the round (same rule as create_impl's tables: split_groups)
 int64_t pair_chunks(const nidreg_handle* h, int pair, int64_t target, bool wide_hist, std::vector<Chunk>& chunks) {
   return split_groups(h->gcount.data(), h->NG, target, segment_overhead(wide_hist), max_segments(h->mode, h->GW), pair, chunks);
+}
+
+// ---- cohorts (NIDREG_COHORT=1): the unchanged reference caller and ONE round of workgroups ------------------------------
+// MultiNIDCost evaluates its pairs from an OpenMP loop (visual_camera_calibration.cpp:147-173): k threads, each calling its own
+// NIDCost at the same pose.  Every handle's chunk tables are sized for a whole round of co-resident workgroups, so k
+// concurrent callers queue k rounds of small chunks and pay every workgroup's prologue k times (8 x 1.25M points: 282 us
+// against 172 us for nidreg_eval_multi's single grid).  A cohort gives the unchanged caller the
+// single grid's geometry: the handles created one after the other on a device, compatible (same camera, image size, bins,
+// precision), BEFORE any of them is evaluated -- visual_camera_calibration.cpp:199-208 builds all pairs' cost objects, then
+// solves -- form a cohort; the first evaluation of any member seals it and rebuilds every member's chunk tables as its SHARE
+// of one round (in proportion to its points, like the single grid's table).  The k callers' kernels then fill the GPU
+// together.  Deterministic by construction: a member's table -- hence the order of its gradient partials -- is a function of
+// the cohort (which handles were created together), never of timing; cost and histogram bits do not depend on tables at all.
+// Opt-in, because a caller that evaluates the members ONE AT A TIME (OMP_NUM_THREADS=1) gets 1/k of the GPU per evaluation.
+std::mutex g_cohort_mu;
+Cohort* g_open_cohort[NIDREG_MAX_DEVICES];
+
+bool cohorts_enabled() {
+  const char* e = std::getenv("NIDREG_COHORT");
+  return e && *e && *e != '0';
+}
+
+// the member's tables as its share of one round (called once per member, before its first evaluation, under the cohort's lock)
+int cohort_reshape(nidreg_handle* h, int64_t total_points) {
+  HIP_TRY(hipSetDevice(h->device));
+  const int64_t mine = std::max<int64_t>(h->num_points, 1);
+  auto rebuild = [&](int per_cu, bool wide_hist, Chunk*& d_tab, size_t& cap, int& n_out, int64_t* slots_out) -> int {
+    std::vector<Chunk> chunks;
+    const int64_t share = std::max<int64_t>(1, int64_t(per_cu) * h->num_cus * mine / total_points);
+    const int64_t slots = split_groups(h->gcount.data(), h->NG, share, segment_overhead(wide_hist), max_segments(h->mode, h->GW), -1, chunks);
+    if (chunks.size() > cap) {
+      if (d_tab) HIP_TRY(hipFree(d_tab));
+      d_tab = nullptr;
+      cap = chunks.size();
+      HIP_TRY(hipMalloc(&d_tab, cap * sizeof(Chunk)));
+    }
+    if (!chunks.empty()) HIP_TRY(hipMemcpy(d_tab, chunks.data(), chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice));
+    n_out = int(chunks.size());
+    if (slots_out) *slots_out = slots;
+    return NIDREG_OK;
+  };
+  int64_t slots = 0;
+  int rc = rebuild(h->per_cu_grad, false, h->d_chunks, h->chunks_cap, h->nchunks, &slots);
+  if (rc) return rc;
+  if (int(slots) > partial_slots(h)) return fail(NIDREG_ERR_INVALID, "cohort: a member's share table needs more gradient-partial slots than its scratch holds");
+  h->nslots = int(slots);
+  h->seg = h->nslots > h->nchunks ? 1 : 0;
+  h->lds_grad = spline_grad_lds_bytes(h->bins, h->GW, h->cshift, h->seg != 0);
+  if (h->wide && h->d_chunks_hist) {
+    int64_t wslots = 0;
+    rc = rebuild(h->per_cu_hist, true, h->d_chunks_hist, h->chunks_hist_cap, h->nchunks_hist, &wslots);
+    if (rc) return rc;
+    h->seg_hist = wslots > h->nchunks_hist ? 1 : 0;
+  }
+  return NIDREG_OK;
+}
+
+void cohort_seal(Cohort* c) {
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->sealed.load(std::memory_order_acquire)) return;
+    if (c->members.size() >= 2) {
+      int64_t total = 0;
+      for (const nidreg_handle* m : c->members) total += std::max<int64_t>(m->num_points, 1);
+      for (nidreg_handle* m : c->members)
+        if (cohort_reshape(m, total) != NIDREG_OK) std::fprintf(stderr, "nidreg: cohort member keeps its own chunk tables (%s)\n", g_last_error.c_str());
+    }
+    c->sealed.store(true, std::memory_order_release);
+  }
+  std::lock_guard<std::mutex> gl(g_cohort_mu);
+  if (c->device >= 0 && c->device < NIDREG_MAX_DEVICES && g_open_cohort[c->device] == c) g_open_cohort[c->device] = nullptr;
+}
+// every evaluation entry point, before it reads the handle's tables
+inline void cohort_check(nidreg_handle* h) {
+  if (h->cohort && !h->cohort->sealed.load(std::memory_order_acquire)) cohort_seal(h->cohort);
+}
+
+bool groupable(const nidreg_handle* a, const nidreg_handle* b);
+void cohort_join(nidreg_handle* h) {
+  if (!cohorts_enabled() || h->set || h->is_shard || !h->own_hist || !h->d_out_host || !h->own_stream || h->device < 0 || h->device >= NIDREG_MAX_DEVICES) return;
+  Cohort* to_seal = nullptr;
+  {
+    std::lock_guard<std::mutex> gl(g_cohort_mu);
+    Cohort*& open = g_open_cohort[h->device];
+    if (open) {
+      std::lock_guard<std::mutex> lk(open->mu);
+      if (!open->sealed.load(std::memory_order_acquire) && !open->members.empty() && open->members.size() < size_t(kMaxMulti) && groupable(open->members[0], h)) {
+        open->members.push_back(h);
+        h->cohort = open;
+        return;
+      }
+    }
+    to_seal = open;  // a handle of another kind ends the cohort that was forming
+    open = new Cohort();
+    open->device = h->device;
+    open->members.push_back(h);
+    h->cohort = open;
+  }
+  if (to_seal) cohort_seal(to_seal);
+}
+
+void cohort_leave(nidreg_handle* h) {
+  Cohort* c = h->cohort;
+  if (!c) return;
+  h->cohort = nullptr;
+  bool empty = false;
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->members.erase(std::remove(c->members.begin(), c->members.end(), h), c->members.end());
+    empty = c->members.empty();
+  }
+  if (empty) {
+    {
+      std::lock_guard<std::mutex> gl(g_cohort_mu);
+      if (c->device >= 0 && c->device < NIDREG_MAX_DEVICES && g_open_cohort[c->device] == c) g_open_cohort[c->device] = nullptr;
+    }
+    delete c;
+  }
 }
 
 // returns the group with its use count raised (release_group when the evaluation is over), or nullptr
@@ -1784,9 +1916,14 @@ int create_sharded(const nidreg_desc* d, const nidreg_cloud* cloud, const double
 
 extern "C" {
 
+static int create_done(int rc, nidreg_handle** out) {
+  if (rc == NIDREG_OK && out && *out) cohort_join(*out);
+  return rc;
+}
+
 int nidreg_create(const nidreg_desc* d, nidreg_handle** out) {
   if (d && out && d->struct_size == int32_t(sizeof(nidreg_desc)) && wants_shards(d)) return create_sharded(d, nullptr, nullptr, 0.0, 0, out);
-  return create_impl(d, nullptr, nullptr, 0.0, 0, CreateOpts(), out);
+  return create_done(create_impl(d, nullptr, nullptr, 0.0, 0, CreateOpts(), out), out);
 }
 
 int nidreg_cloud_create(int device_id, const double* points, int64_t point_stride, const double* intensities, int64_t num_points, nidreg_cloud** out) {
@@ -1834,7 +1971,7 @@ int nidreg_create_from_cloud(const nidreg_desc* d, const nidreg_cloud* cloud, co
   // desc.device_ids / NIDREG_DEVICES: cull + bucket + sort on the cloud's GPU, then every shard takes its column groups
   // device to device -- the per-outer-iteration `cull -> new NIDCost` stays on the GPUs
   if (d && out && d->struct_size == int32_t(sizeof(nidreg_desc)) && wants_shards(d)) return create_sharded(d, cloud, T_camera_lidar, min_z, enable_depth_buffer_culling, out);
-  return create_impl(d, cloud, T_camera_lidar, min_z, enable_depth_buffer_culling, CreateOpts(), out);
+  return create_done(create_impl(d, cloud, T_camera_lidar, min_z, enable_depth_buffer_culling, CreateOpts(), out), out);
 }
 
 void nidreg_destroy(nidreg_handle* h) { free_handle(h); }
@@ -1842,6 +1979,7 @@ void nidreg_destroy(nidreg_handle* h) { free_handle(h); }
 int nidreg_eval(nidreg_handle* h, const double* se3, double* cost, double* grad7) {
   if (!h || !se3) return fail(NIDREG_ERR_INVALID, "nidreg_eval: null argument");
   if (h->set) return set_eval(h->set, NIDREG_MODE_SPLINE, se3, cost, grad7);
+  cohort_check(h);
   InflightGuard guard(h->device);
   const int rc = eval_launch(h, se3, grad7 != nullptr, guard.alone);
   if (rc) return rc;
@@ -1879,6 +2017,7 @@ static int async_submit(nidreg_handle* h, int mode, const double* pose, bool wan
     *ticket = t;
     return NIDREG_OK;
   }
+  cohort_check(h);
   HIP_TRY(hipSetDevice(h->device));
   if (!h->h_ring) {
     HIP_TRY(hipHostMalloc(&h->h_ring, size_t(kAsyncDepth) * NIDREG_OUT_DOUBLES * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
@@ -1983,6 +2122,7 @@ int nidreg_eval_pipelined(nidreg_handle* h, const double* se3s, int n, double* c
 int nidreg_eval_iso(nidreg_handle* h, const double* T, double* cost) {
   if (!h || !T) return fail(NIDREG_ERR_INVALID, "nidreg_eval_iso: null argument");
   if (h->set) return set_eval(h->set, NIDREG_MODE_NEAREST, T, cost, nullptr) < 0 ? NIDREG_ERR_HIP : NIDREG_OK;
+  cohort_check(h);
   const int rc = iso_launch(h, T);
   if (rc) return rc;
   return eval_finish(h, cost, nullptr) < 0 ? NIDREG_ERR_HIP : NIDREG_OK;  // CostCalculatorNID has no finite check
@@ -1993,6 +2133,7 @@ int nidreg_eval_multi(nidreg_handle* const* handles, int n, const double* init_s
   if (init_se3 && !trust_gate_ok(init_se3, se3)) return NIDREG_FALSE;
   for (int i = 0; i < n; i++)
     if (!handles[i]) return fail(NIDREG_ERR_INVALID, "nidreg_eval_multi: null handle");
+  for (int i = 0; i < n; i++) cohort_check(handles[i]);
   // several compatible pairs on ONE GPU: a single grid per pass over all pairs (group_eval)
   if (handles[0]->mode == NIDREG_MODE_SPLINE) {
     if (can_group(handles, n)) {
@@ -2057,6 +2198,7 @@ int nidreg_eval_iso_multi(nidreg_handle* const* handles, int n, const double* T,
   if (!handles || n <= 0 || !T) return fail(NIDREG_ERR_INVALID, "nidreg_eval_iso_multi: bad argument");
   for (int i = 0; i < n; i++)
     if (!handles[i]) return fail(NIDREG_ERR_INVALID, "nidreg_eval_iso_multi: null handle");
+  for (int i = 0; i < n; i++) cohort_check(handles[i]);
   if (handles[0]->mode == NIDREG_MODE_NEAREST && can_group(handles, n)) {  // several pairs on one GPU: one grid per pass
     MultiGroup* g = find_or_make_group(handles, n);
     if (g) {

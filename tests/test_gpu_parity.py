@@ -1115,3 +1115,74 @@ def test_nearest_fast_tier_decides_like_the_reference_around_every_boundary(pose
     wide = nid.CostCalculatorNID(proj, s.image_u8, pts32, ints, nid.NIDCostParams(256), max_fov=1.5)
     assert wide.info()["nearest_fast"] == 0
     wide.close()
+
+
+def test_cohort_gives_concurrent_callers_one_round_of_workgroups(monkeypatch):
+    """NIDREG_COHORT=1 (round 4): handles created one after the other for one MultiNIDCost -- compatible, before any of them is
+    evaluated -- get chunk tables that are their SHARE of one round of workgroups, so that the reference's unchanged OpenMP loop
+    over pairs (one caller per pair, visual_camera_calibration.cpp:161) fills the GPU once instead of k times.  The tables are a
+    function of the cohort, never of timing: every member's results are the same bits whether the members are evaluated one
+    by one, from concurrent threads, or in any order; cost and histogram equal those of a handle outside any cohort bit for
+    bit, the gradient to rounding."""
+    import threading
+
+    sizes = [30000, 12000, 7000, 21000]
+    scenes = [scene_for("plumb_bob", n=n, seed=170 + k) for k, n in enumerate(sizes)]
+    proj = nid.create_camera(scenes[0].model, scenes[0].intrinsics, scenes[0].distortion)
+    solo = [nid.NIDCost(proj, s.image_f64, s.points, s.intensities, 256) for s in scenes]  # no cohort
+    rng = np.random.default_rng(4)
+    poses = [scenes[0].T_camera_lidar_init] + [synth.random_pose_near(scenes[0].T_camera_lidar_true, rng) for _ in range(5)]
+    ref = [[c(x) for c in solo] for x in poses]
+    monkeypatch.setenv("NIDREG_COHORT", "1")
+    runs = []
+    for mode in ("serial", "threads", "reverse"):
+        members = [nid.NIDCost(proj, s.image_f64, s.points, s.intensities, 256) for s in scenes]
+        full = [m.info()["num_chunks"] for m in members]  # (still every member's own full round: nothing has been evaluated)
+        other = nid.NIDCost(proj, scenes[0].image_f64, scenes[0].points, scenes[0].intensities, 16)  # another bin count: not of this cohort (and it ends it)
+        out = [[None] * len(members) for _ in poses]
+        if mode == "threads":
+            bar = threading.Barrier(len(members))
+
+            def work(i):
+                for j, x in enumerate(poses):
+                    bar.wait()
+                    out[j][i] = members[i](x)
+
+            th = [threading.Thread(target=work, args=(i,)) for i in range(len(members))]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+        else:
+            order = range(len(members)) if mode == "serial" else reversed(range(len(members)))
+            for i in order:
+                for j, x in enumerate(poses):
+                    out[j][i] = members[i](x)
+        share = [m.info()["num_chunks"] for m in members]
+        assert sum(share) <= max(full) + len(members) and all(a < b for a, b in zip(share, full)), (share, full)  # together: one round
+        assert other.info()["num_chunks"] >= 1 and other(poses[0])[0]
+        for j in range(len(poses)):
+            for i in range(len(members)):
+                ok, c, g = out[j][i]
+                rok, rc, rg = ref[j][i]
+                assert ok and rok and c == rc and np.allclose(g, rg, rtol=1e-11, atol=1e-14)
+        for i, m in enumerate(members):
+            m(poses[-1])
+            solo[i](poses[-1])
+            assert np.array_equal(m.histogram_fixed()[0], solo[i].histogram_fixed()[0])
+        runs.append(out)
+        for m in members + [other]:
+            m.close()
+    for j in range(len(poses)):  # run-to-run, order-to-order, threads or not: the same bits (gradient included)
+        for i in range(len(sizes)):
+            assert runs[0][j][i][1] == runs[1][j][i][1] == runs[2][j][i][1]
+            assert np.array_equal(runs[0][j][i][2], runs[1][j][i][2]) and np.array_equal(runs[0][j][i][2], runs[2][j][i][2])
+    # the single grid of nidreg_eval_multi over a cohort still agrees
+    members = [nid.NIDCost(proj, s.image_f64, s.points, s.intensities, 256) for s in scenes]
+    multi = nid.MultiNIDCost(None)
+    for m in members:
+        multi.add(m)
+    ok, c, g = multi(poses[1])
+    assert ok and c == sum(r[1] for r in ref[1]) and np.allclose(g, sum(r[2] for r in ref[1]), rtol=1e-11, atol=1e-14)
+    for m in members + solo:
+        m.close()
