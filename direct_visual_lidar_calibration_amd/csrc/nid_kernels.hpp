@@ -941,6 +941,33 @@ __global__ void k_shard_announce(const ShardTable* tab, u64 seq) {
   for (int q = 0; q < n; q++) store_sys(&tab->flags[q][0 * kMaxShards + me], seq);
 }
 
+// NIDREG_SHARD_SELFTEST=1 (creation-time check of a set's exchange paths, before the first evaluation could hang on them):
+// one ordered pair of shards at a time.  `ping` (on shard a's device) writes a pattern into b's gather block, releases, raises
+// b's flag [0][a] and waits for b's answer in its own flag [1][b]; `pong` (on b's device) waits for the flag, checks that the
+// pattern is visible behind it, answers.  out[0] = 1 ok / 2 flag wait timed out / 3 payload not visible behind the flag;
+// out[1] (ping) = round trip in ticks of the 100 MHz wall clock.
+__global__ void k_shard_selftest_ping(const ShardTable* tab, int peer, u64 seq, u64 pattern, u64* out, unsigned long long timeout_ticks) {
+  if (threadIdx.x != 0) return;
+  const int me = tab->me;
+  const unsigned long long t0 = wall_clock64();
+  store_sys(tab->gather[peer] + kGatherHj + me, pattern);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  store_sys(&tab->flags[peer][0 * kMaxShards + me], seq);
+  const bool ok = wait_flag(&tab->flags[me][1 * kMaxShards + peer], seq, timeout_ticks);
+  out[1] = wall_clock64() - t0;
+  out[0] = ok ? 1 : 2;
+}
+__global__ void k_shard_selftest_pong(const ShardTable* tab, int peer, u64 seq, u64 pattern, u64* out, unsigned long long timeout_ticks) {
+  if (threadIdx.x != 0) return;
+  const int me = tab->me;
+  const bool ok = wait_flag(&tab->flags[me][0 * kMaxShards + peer], seq, timeout_ticks);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  const u64 seen = load_sys(tab->gather[me] + kGatherHj + peer);
+  store_sys(&tab->flags[peer][1 * kMaxShards + me], seq);
+  out[0] = !ok ? 2 : (seen == pattern ? 1 : 3);
+}
+
 // entropy partials over the OWNED columns (k_entropy's thread layout: 16 columns per 1024-thread workgroup), pushed to
 // every shard by the last workgroup.  err_out / err_host: set to `seq` when a flag wait times out.
 __global__ __launch_bounds__(kEntropyThreads) void k_entropy_owned(

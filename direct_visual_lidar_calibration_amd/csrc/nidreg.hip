@@ -1904,6 +1904,52 @@ int create_sharded(const nidreg_desc* d, const nidreg_cloud* cloud, const double
   }
   free_handle(master);
   master = nullptr;
+  // NIDREG_SHARD_SELFTEST=1: every ordered pair of shards exchanges a flag and a payload once, now, with a short timeout -- a
+  // set whose peer mappings, flag ordering or queues do not work fails HERE, with the pair named, instead of timing out in
+  // the middle of the first evaluation.  Shards on the same device (a 1-GPU box exercising the protocol) are skipped: their
+  // two kernels may share an in-order hardware queue.
+  if (const char* st = std::getenv("NIDREG_SHARD_SELFTEST"); st && *st && *st != '0') {
+    const unsigned long long ticks = 20000000ull;  // 200 ms of the 100 MHz wall clock
+    std::string report;
+    u64 seq = 1;
+    for (int a = 0; a < n; a++)
+      for (int b = 0; b < n; b++) {
+        nidreg_handle *ha = set->shards[size_t(a)], *hb = set->shards[size_t(b)];
+        if (a == b || ha->device == hb->device) continue;
+        u64 *oa = nullptr, *ob = nullptr;  // host-mapped result words
+        hipError_t e = hipHostMalloc(&oa, 2 * sizeof(u64), hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostMalloc(&ob, 2 * sizeof(u64), hipHostMallocMapped);
+        if (e != hipSuccess) return bail(fail(NIDREG_ERR_HIP, std::string("shard self-test: ") + hipGetErrorString(e)));
+        oa[0] = oa[1] = ob[0] = ob[1] = 0;
+        const u64 pattern = 0x5e1f7e5700000000ull | (u64(a) << 8) | u64(b);
+        (void)hipSetDevice(hb->device);
+        hipLaunchKernelGGL(k_shard_selftest_pong, dim3(1), dim3(64), 0, hb->stream, hb->d_shard_tab, a, seq, pattern, ob, ticks);
+        (void)hipSetDevice(ha->device);
+        hipLaunchKernelGGL(k_shard_selftest_ping, dim3(1), dim3(64), 0, ha->stream, ha->d_shard_tab, b, seq, pattern, oa, ticks);
+        e = hipStreamSynchronize(ha->stream);
+        (void)hipSetDevice(hb->device);
+        if (e == hipSuccess) e = hipStreamSynchronize(hb->stream);
+        const u64 ra = oa[0], rb = ob[0], rtt = oa[1];
+        (void)hipHostFree(oa);
+        (void)hipHostFree(ob);
+        char line[200];
+        std::snprintf(line, sizeof(line), "nidreg shard self-test: device %d -> device %d: %s%s, round trip %.1f us\n", ha->device, hb->device,
+                      rb == 1 ? "flag and payload visible" : (rb == 3 ? "PAYLOAD NOT VISIBLE BEHIND THE FLAG" : "FLAG NEVER ARRIVED"), ra == 1 ? ", answer seen" : ", NO ANSWER", double(rtt) * 0.01);
+        report += line;
+        if (e != hipSuccess || ra != 1 || rb != 1) {
+          std::fputs(report.c_str(), stderr);
+          return bail(fail(NIDREG_ERR_HIP, std::string("sharded handle: self-test of the GPU-to-GPU exchange failed: ") + line));
+        }
+        seq++;
+      }
+    std::fputs(report.empty() ? "nidreg shard self-test: no pair of shards on different devices (nothing to test)\n" : report.c_str(), stderr);
+    // flags and payload words back to zero: the evaluations' sequence numbers start at 1
+    for (int g = 0; g < n; g++) {
+      (void)hipSetDevice(set->shards[size_t(g)]->device);
+      (void)hipMemset(set->flags[size_t(g)], 0, 2 * kMaxShards * sizeof(u64));
+      (void)hipMemset(set->gather[size_t(g)], 0, gw * sizeof(u64));
+    }
+  }
   if (!set->colocated)
     for (int g = 1; g < n; g++) set->workers.emplace_back(shard_worker, set, g);
   nidreg_handle* lead = set->shards[0];
