@@ -75,6 +75,9 @@ struct nidreg_handle {
   int seg = 0, seg_hist = 0;  // the table (d_chunks / d_chunks_hist) has chunks that run across column groups: SEG kernels
   size_t chunks_cap = 0, chunks_hist_cap = 0;  // entries allocated behind d_chunks / d_chunks_hist
   struct Cohort* cohort = nullptr;  // NIDREG_COHORT=1: the handles created together for one MultiNIDCost share ONE round of workgroups
+  std::vector<Chunk> cohort_chunks, cohort_chunks_hist;  // host copies of a sealed cohort member's share tables (the single grid concatenates them)
+  std::atomic<int> rv_done{0};  // rendezvous: the round's leader has stored this member's results
+  int rv_rc = 0;
   int nchunks_hist = 0;  // WIDE histogram kernel's own table (0 = shares d_chunks)
   double intr[5] = {0}, dist[8] = {0};
   double max_fov = 0.0;
@@ -149,6 +152,17 @@ struct Cohort {
   std::vector<nidreg_handle*> members;
   std::atomic<bool> sealed{false};
   int device = 0;
+  // rendezvous of concurrent callers (cohort_eval): the round that is collecting arrivals
+  std::mutex rv_mu;
+  bool round_open = false;
+  double round_pose[7] = {0};
+  bool round_grad = false;
+  std::atomic<int> n_arrived{0};
+  struct Arrival {
+    nidreg_handle* h;
+    double* cost;
+    double* grad7;
+  } arrivals[16];
 };
 
 // One LiDAR-camera pair spread over several GPUs (BASELINE north_star: "disjoint point slices with a final all-reduce of the
@@ -1201,6 +1215,7 @@ int cohort_reshape(nidreg_handle* h, int64_t total_points) {
     if (!chunks.empty()) HIP_TRY(hipMemcpy(d_tab, chunks.data(), chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice));
     n_out = int(chunks.size());
     if (slots_out) *slots_out = slots;
+    (wide_hist ? h->cohort_chunks_hist : h->cohort_chunks) = std::move(chunks);
     return NIDREG_OK;
   };
   int64_t slots = 0;
@@ -1241,7 +1256,7 @@ inline void cohort_check(nidreg_handle* h) {
 
 bool groupable(const nidreg_handle* a, const nidreg_handle* b);
 void cohort_join(nidreg_handle* h) {
-  if (!cohorts_enabled() || h->set || h->is_shard || !h->own_hist || !h->d_out_host || !h->own_stream || h->device < 0 || h->device >= NIDREG_MAX_DEVICES) return;
+  if (!cohorts_enabled() || h->mode != NIDREG_MODE_SPLINE || h->set || h->is_shard || !h->own_hist || !h->d_out_host || !h->own_stream || h->device < 0 || h->device >= NIDREG_MAX_DEVICES) return;
   Cohort* to_seal = nullptr;
   {
     std::lock_guard<std::mutex> gl(g_cohort_mu);
@@ -1301,14 +1316,33 @@ MultiGroup* find_or_make_group(nidreg_handle* const* handles, int n) {
   std::vector<std::vector<Chunk>> pair_grad(static_cast<size_t>(n)), pair_hist(static_cast<size_t>(n));
   std::vector<MultiEntry> table(static_cast<size_t>(n));
   const nidreg_handle* h0 = handles[0];
+  // members of ONE sealed cohort bring their fixed share tables (cohort_reshape): a pair's chunks -- hence the order of its
+  // gradient partials -- are then the same whether it is evaluated alone, in this group, or in a group of any other subset
+  bool fixed_tables = true;
+  for (int i = 0; i < n; i++)
+    fixed_tables = fixed_tables && handles[i]->cohort && handles[i]->cohort == handles[0]->cohort && handles[i]->cohort->sealed.load(std::memory_order_acquire) &&
+                   (!handles[i]->cohort_chunks.empty() || handles[i]->num_points == 0);
   for (int i = 0; i < n; i++) {
     nidreg_handle* h = handles[i];
-    const int64_t share_grad = std::max<int64_t>(1, int64_t(h0->per_cu_grad) * h0->num_cus * std::max<int64_t>(h->num_points, 1) / total);
-    const int64_t pair_slots = pair_chunks(h, i, share_grad, false, pair_grad[size_t(i)]);
-    if (pair_slots > int64_t(pair_grad[size_t(i)].size())) g->seg = 1;
-    if (h0->wide) {
-      const int64_t share_hist = std::max<int64_t>(1, int64_t(h0->per_cu_hist) * h0->num_cus * std::max<int64_t>(h->num_points, 1) / total);
-      if (pair_chunks(h, i, share_hist, true, pair_hist[size_t(i)]) > int64_t(pair_hist[size_t(i)].size())) g->seg_hist = 1;
+    int64_t pair_slots = 0;
+    if (fixed_tables) {
+      pair_grad[size_t(i)] = h->cohort_chunks;
+      for (Chunk& c : pair_grad[size_t(i)]) c.pad = (c.pad & ~0xffu) | uint32_t(i);
+      pair_slots = h->nslots;
+      if (h->seg) g->seg = 1;
+      if (h0->wide) {
+        pair_hist[size_t(i)] = h->cohort_chunks_hist;
+        for (Chunk& c : pair_hist[size_t(i)]) c.pad = (c.pad & ~0xffu) | uint32_t(i);
+        if (h->seg_hist) g->seg_hist = 1;
+      }
+    } else {
+      const int64_t share_grad = std::max<int64_t>(1, int64_t(h0->per_cu_grad) * h0->num_cus * std::max<int64_t>(h->num_points, 1) / total);
+      pair_slots = pair_chunks(h, i, share_grad, false, pair_grad[size_t(i)]);
+      if (pair_slots > int64_t(pair_grad[size_t(i)].size())) g->seg = 1;
+      if (h0->wide) {
+        const int64_t share_hist = std::max<int64_t>(1, int64_t(h0->per_cu_hist) * h0->num_cus * std::max<int64_t>(h->num_points, 1) / total);
+        if (pair_chunks(h, i, share_hist, true, pair_hist[size_t(i)]) > int64_t(pair_hist[size_t(i)].size())) g->seg_hist = 1;
+      }
     }
     MultiEntry& e = table[size_t(i)];
     e.pts = h->d_pts;
@@ -1458,6 +1492,124 @@ int group_eval(MultiGroup* g, const double* se3, bool want_grad, double* costs, 
     if (rcs) rcs[i] = rc;
   }
   return NIDREG_OK;
+}
+
+// Rendezvous of a cohort's concurrent callers (NIDREG_COHORT=1).  The reference's MultiNIDCost calls its pairs' functors from an
+// OpenMP loop at ONE pose (visual_camera_calibration.cpp:161-165); the members of a sealed cohort that arrive in nidreg_eval
+// at that pose within NIDREG_COHORT_WAIT_US (default 100) of the first are evaluated as ONE grid per pass -- three launches
+// for all of them -- by the first arriver, the others wait for their results.  Which callers make it into a round depends on
+// timing; what they get does not: every member's chunk table is fixed by the cohort (cohort_reshape), and the single grid
+// of any subset concatenates those tables, so a member's cost, histogram AND gradient are the same bits whether it ran
+// alone, with all of its siblings or with some of them (tests/test_gpu_parity.py test_cohort_...).
+// Returns kNotJoined when the caller should evaluate by itself (another pose is collecting, or the handle is in the round).
+constexpr int kNotJoined = -1000;
+int cohort_eval(nidreg_handle* h, const double* se3, bool want_grad, double* cost, double* grad7) {
+  Cohort* c = h->cohort;
+  const int k = int(c->members.size());  // (fixed once sealed, except for members being destroyed -- not while their siblings evaluate)
+  static const double wait_us = [] {
+    const char* e = std::getenv("NIDREG_COHORT_WAIT_US");
+    return e ? std::max(0.0, std::strtod(e, nullptr)) : 100.0;
+  }();
+  bool leader = false;
+  {
+    std::lock_guard<std::mutex> lk(c->rv_mu);
+    if (c->round_open) {
+      if (std::memcmp(c->round_pose, se3, sizeof(c->round_pose)) != 0 || c->round_grad != want_grad) return kNotJoined;
+      const int n = c->n_arrived.load(std::memory_order_relaxed);
+      for (int i = 0; i < n; i++)
+        if (c->arrivals[i].h == h) return kNotJoined;
+      if (n >= 16) return kNotJoined;
+    } else {
+      c->round_open = true;
+      std::memcpy(c->round_pose, se3, sizeof(c->round_pose));
+      c->round_grad = want_grad;
+      c->n_arrived.store(0, std::memory_order_relaxed);
+      leader = true;
+    }
+    const int me = c->n_arrived.load(std::memory_order_relaxed);
+    c->arrivals[me] = Cohort::Arrival{h, cost, grad7};
+    h->rv_done.store(0, std::memory_order_relaxed);
+    c->n_arrived.store(me + 1, std::memory_order_release);
+  }
+  if (!leader) {  // the round's leader evaluates; spin (an evaluation takes 100-300 us), then yield
+    unsigned spins = 0;
+    while (h->rv_done.load(std::memory_order_acquire) == 0) {
+      if (++spins < 200000) {
+        __builtin_ia32_pause();
+      } else {
+        std::this_thread::yield();
+      }
+    }
+    return h->rv_rc;
+  }
+  // leader: wait for the siblings, close the round
+  struct timespec t0;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  while (c->n_arrived.load(std::memory_order_acquire) < k) {
+    for (int i = 0; i < 16; i++) __builtin_ia32_pause();
+    struct timespec t1;
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if ((t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3 > wait_us) break;
+  }
+  Cohort::Arrival arr[16];
+  int n = 0;
+  {
+    std::lock_guard<std::mutex> lk(c->rv_mu);
+    n = c->n_arrived.load(std::memory_order_acquire);
+    for (int i = 0; i < n; i++) arr[i] = c->arrivals[i];
+    c->round_open = false;  // later arrivals open the next round
+  }
+  // member order (not arrival order): the same subset is the same group, whoever came first
+  std::sort(arr, arr + n, [c](const Cohort::Arrival& a, const Cohort::Arrival& b) {
+    return std::find(c->members.begin(), c->members.end(), a.h) < std::find(c->members.begin(), c->members.end(), b.h);
+  });
+  int my_rc = NIDREG_OK;
+  bool done = false;
+  if (n >= 2) {
+    nidreg_handle* hs[16];
+    for (int i = 0; i < n; i++) hs[i] = arr[i].h;
+    MultiGroup* g = find_or_make_group(hs, n);
+    if (g) {
+      double costs[kMaxMulti], grads[kMaxMulti * 7];
+      int rcs[kMaxMulti];
+      for (int i = 0; i < n; i++) rcs[i] = NIDREG_OK;
+      bool all_ok = true;
+      const int rc = group_eval(g, se3, want_grad, costs, want_grad ? grads : nullptr, &all_ok, rcs);
+      release_group(g);
+      const std::string err = rc < 0 ? g_last_error : std::string();
+      for (int i = 0; i < n; i++) {
+        if (rc >= 0) {
+          if (arr[i].cost) *arr[i].cost = costs[i];
+          if (want_grad && arr[i].grad7)
+            for (int q = 0; q < 7; q++) arr[i].grad7[q] = grads[7 * i + q];
+        }
+        const int r = rc < 0 ? rc : rcs[i];
+        if (arr[i].h == h) {
+          my_rc = r;
+        } else {
+          arr[i].h->rv_rc = r;
+          arr[i].h->rv_done.store(1, std::memory_order_release);
+        }
+      }
+      if (rc < 0) g_last_error = err;
+      done = true;
+    }
+  }
+  if (!done) {  // alone in the round (or the group could not be built): everybody evaluates by itself, the leader for all
+    for (int i = 0; i < n; i++) {
+      nidreg_handle* m = arr[i].h;
+      InflightGuard guard(m->device);
+      int rc = eval_launch(m, se3, want_grad, guard.alone && n == 1);
+      if (!rc) rc = eval_finish(m, arr[i].cost, want_grad ? arr[i].grad7 : nullptr);
+      if (m == h) {
+        my_rc = rc;
+      } else {
+        m->rv_rc = rc;
+        m->rv_done.store(1, std::memory_order_release);
+      }
+    }
+  }
+  return my_rc;
 }
 
 // the Nelder-Mead objective's sum over pairs (visual_camera_calibration.cpp:103-119) the same way: two launches in all
@@ -2026,6 +2178,10 @@ int nidreg_eval(nidreg_handle* h, const double* se3, double* cost, double* grad7
   if (!h || !se3) return fail(NIDREG_ERR_INVALID, "nidreg_eval: null argument");
   if (h->set) return set_eval(h->set, NIDREG_MODE_SPLINE, se3, cost, grad7);
   cohort_check(h);
+  if (h->cohort && h->cohort->members.size() >= 2 && h->mode == NIDREG_MODE_SPLINE && !h->timing && h->async_outstanding == 0) {
+    const int rc = cohort_eval(h, se3, grad7 != nullptr, cost, grad7);
+    if (rc != kNotJoined) return rc;
+  }
   InflightGuard guard(h->device);
   const int rc = eval_launch(h, se3, grad7 != nullptr, guard.alone);
   if (rc) return rc;
