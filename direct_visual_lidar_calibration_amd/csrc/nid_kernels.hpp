@@ -377,22 +377,10 @@ __device__ __forceinline__ void spline_hist_body(
   const BsplineScale KU = bspline_scale(dn_scale);  // uniform: the x-weight polynomial's constants in fixed-point units
 
   Segments seg(gend, ch);
-  // -DNID_PREFETCH0 (experiment, off): the chunk's first batch of records requested BEFORE the tile is zeroed, so that its HBM
-  // latency runs under the 64 KB of LDS stores and the barrier (raw records: nothing touches the loaded registers until the
-  // point loop).  Measured on cfg 2 (profiles/r04d_variants.txt): histogram kernel unchanged (51.5-51.9 us either way), the
-  // gradient kernel +2 us with its counterpart (the compiler peels the first iteration: 3963 instead of 2960 instructions).
+  // (Requesting the chunk's first batch of records before the tile is zeroed -- and, in the gradient kernel, before the
+  // entropy tail / G tile -- was measured in round 4: histogram kernel unchanged, gradient kernel +2 us (the compiler peels
+  // the first iteration: 3963 instead of 2960 instructions); profiles/r04d_variants.txt.  Not kept.)
   RawBatch<Rec, kUnroll> rb;
-#ifdef NID_PREFETCH0
-  if constexpr (!SEG) {  // (the looped instantiations have no registers to spare for it)
-    const uint32_t cnt0 = seg.end - seg.pos;
-    const char* rec_base0 = reinterpret_cast<const char*>(pts + seg.pos);
-#pragma unroll
-    for (int k = 0; k < kUnroll; k++) rb.load(rec_base0, min(uint32_t(k) * kT + tid, cnt0 - 1u) * uint32_t(sizeof(Rec)), k);
-  }
-  bool have_batch = !SEG;
-#else
-  bool have_batch = false;
-#endif
   for (;;) {
     // a zeroed tile for every segment (coalesced stores; zeroing inside the flush below -- 32 more LDS addresses per thread in the
     // WIDE kernel -- took the looped kernel from 93 to 161 VGPRs)
@@ -442,15 +430,15 @@ __device__ __forceinline__ void spline_hist_body(
     // kUnroll records per thread are fetched before any of them is processed (memory-level parallelism); the
     // geometry of all of them comes first, then -- wave-uniform choice -- the tap code with uniform or per-lane
     // constants.  Both are branch-free per point, so the scheduler interleaves the kUnroll independent points.
-    for (uint32_t base = 0; base < cnt; base += kT * kUnroll) {
+    // GUARDED = the batch may reach past the end of the segment (clamped loads, per-slot validity); -DNID_EXP_NOCLAMP runs
+    // every full batch without the checks and only the last one with them (experiment: profiles/r04g_variants.txt)
+    auto batch = [&](uint32_t base, auto guarded) {
+      constexpr bool GUARDED = decltype(guarded)::value;
       set_progress_priority(prio, seg.pos - ch.start + base, ch.count);
       real xs[kUnroll], ys[kUnroll], zs[kUnroll];
       uint32_t bins_[kUnroll];
-      if (!have_batch) {  // uniform (false only for a chunk's very first batch)
 #pragma unroll
-        for (int k = 0; k < kUnroll; k++) rb.load(rec_base, min(base + uint32_t(k) * kT + tid, cnt - 1u) * uint32_t(sizeof(Rec)), k);
-      }
-      have_batch = false;
+      for (int k = 0; k < kUnroll; k++) rb.load(rec_base, (GUARDED ? min(base + uint32_t(k) * kT + tid, cnt - 1u) : base + uint32_t(k) * kT + tid) * uint32_t(sizeof(Rec)), k);
 #pragma unroll
       for (int k = 0; k < kUnroll; k++) rb.template get<real>(k, xs[k], ys[k], zs[k], bins_[k]);
       real us[kUnroll], vs[kUnroll];
@@ -458,7 +446,7 @@ __device__ __forceinline__ void spline_hist_body(
       bool all_in = true;
 #pragma unroll
       for (int k = 0; k < kUnroll; k++) {
-        const bool valid = base + uint32_t(k) * kT + tid < cnt;
+        const bool valid = !GUARDED || base + uint32_t(k) * kT + tid < cnt;
         real cx, cy, cz;
         transform_fma<real>(pose, xs[k], ys[k], zs[k], cx, cy, cz);
         project<MODEL, real, real, true>(cam, cx, cy, cz, us[k], vs[k]);
@@ -485,7 +473,16 @@ __device__ __forceinline__ void spline_hist_body(
           taps(in ? us[k] : real(0), in ? vs[k] : real(0), bins_[k], KL);
         }
       }
+    };
+#ifdef NID_EXP_NOCLAMP
+    {
+      uint32_t base = 0;
+      for (; base + uint32_t(kT * kUnroll) <= cnt; base += kT * kUnroll) batch(base, std::false_type());
+      if (base < cnt) batch(base, std::true_type());
     }
+#else
+    for (uint32_t base = 0; base < cnt; base += kT * kUnroll) batch(base, std::true_type());
+#endif
     __syncthreads();
 
     // flush the tile: contiguous in the [bin_points][bin_image] device layout
@@ -1108,7 +1105,7 @@ enum { TAP_COPIES = 0,   // gtile[(cell << cshift) + lane copy]: lane-private co
 template <int MODEL, typename Rec, typename real, int TAP, int kT>
 __device__ __forceinline__ void spline_grad_loop(
   const Rec* __restrict__ recs, uint32_t cnt, uint32_t col0, uint32_t done, uint32_t total, const uint8_t* __restrict__ img, int pitch, int W, int H, const PoseParams<real>& pose,
-  const CamParams<real>& cam, int B, int cshift, const double* gtile, double* acc, bool prio, RawBatch<Rec, kUnroll>& rb, bool have_batch) {
+  const CamParams<real>& cam, int B, int cshift, const double* gtile, double* acc, bool prio) {
   const int tid = threadIdx.x;
   if (TAP == TAP_SINGLE) cshift = 0;
   const uint32_t cmask = (1u << cshift) - 1u;
@@ -1116,21 +1113,20 @@ __device__ __forceinline__ void spline_grad_loop(
   const uint32_t lane_copy = uint32_t(tid) & cmask;
 
   const char* rec_base = reinterpret_cast<const char*>(recs);  // uniform base + 32-bit byte offsets per lane
-  for (uint32_t base = 0; base < cnt; base += kT * kUnroll) {
+  auto batch = [&](uint32_t base, auto guarded) {  // GUARDED: see spline_hist_body
+    constexpr bool GUARDED = decltype(guarded)::value;
     set_progress_priority(prio, done + base, total);
     real xs[kUnroll], ys[kUnroll], zs[kUnroll];
     uint32_t bins_[kUnroll];
-    if (!have_batch) {  // uniform (false only for a chunk's very first batch, requested ahead of the kernel's prologue)
+    RawBatch<Rec, kUnroll> rb;
 #pragma unroll
-      for (int k = 0; k < kUnroll; k++) rb.load(rec_base, min(base + uint32_t(k) * kT + tid, cnt - 1u) * uint32_t(sizeof(Rec)), k);
-    }
-    have_batch = false;
+    for (int k = 0; k < kUnroll; k++) rb.load(rec_base, (GUARDED ? min(base + uint32_t(k) * kT + tid, cnt - 1u) : base + uint32_t(k) * kT + tid) * uint32_t(sizeof(Rec)), k);
 #pragma unroll
     for (int k = 0; k < kUnroll; k++) rb.template get<real>(k, xs[k], ys[k], zs[k], bins_[k]);
 #pragma unroll
     for (int k = 0; k < kUnroll; k++) {
       // (a branch-free body like k_spline_hist's was measured 15 % slower here: 173 VGPRs, 2 waves/SIMD)
-      if (base + uint32_t(k) * kT + tid >= cnt) break;
+      if (GUARDED && base + uint32_t(k) * kT + tid >= cnt) break;
       const real x = xs[k], y = ys[k], z = zs[k];
       real cx, cy, cz;
       transform_fma<real>(pose, x, y, z, cx, cy, cz);
@@ -1196,7 +1192,14 @@ __device__ __forceinline__ void spline_grad_loop(
         acc[11] += gp2;
       }
     }
-  }
+  };
+#ifdef NID_EXP_NOCLAMP
+  uint32_t base = 0;
+  for (; base + uint32_t(kT * kUnroll) <= cnt; base += kT * kUnroll) batch(base, std::false_type());
+  if (base < cnt) batch(base, std::true_type());
+#else
+  for (uint32_t base = 0; base < cnt; base += kT * kUnroll) batch(base, std::true_type());
+#endif
 }
 
 // the workgroup's 12 sums -> partials[k][my_block] ([12][nchunks]: coalesced for the final reduction), stored write-through
@@ -1344,22 +1347,6 @@ __global__ __launch_bounds__(kThreads, grad_min_waves(MODEL, SEG, sizeof(Rec) ==
     gt.hist_points = as_global(e.hist_points);
     gt.scal = as_global(e.scal);
   }
-  // -DNID_PREFETCH0 (experiment, off; see spline_hist_body): the chunk's first batch of records requested before the prologue
-  // (entropy tail, G tile: two dependent trips to L2 and a few hundred instructions) -- measured 2 us SLOWER (75.6-76.2 ->
-  // 77.5-78.4 us, profiles/r04d_variants.txt)
-  RawBatch<Rec, kUnroll> rb;
-#ifdef NID_PREFETCH0
-  if constexpr (!SEG) {  // (the looped instantiations have no registers to spare for it)
-    Segments s0(gend, ch);
-    const uint32_t cnt0 = s0.end - s0.pos;
-    const char* rec_base0 = reinterpret_cast<const char*>(pts + s0.pos);
-#pragma unroll
-    for (int k = 0; k < kUnroll; k++) rb.load(rec_base0, min(uint32_t(k) * kThreads + tid, cnt0 - 1u) * uint32_t(sizeof(Rec)), k);
-  }
-  bool have_batch = !SEG;
-#else
-  bool have_batch = false;
-#endif
   {
     double coefA, coefB, S;
     if (gt.from_partials) {
@@ -1396,8 +1383,7 @@ __global__ __launch_bounds__(kThreads, grad_min_waves(MODEL, SEG, sizeof(Rec) ==
     }
     const uint32_t seg_end = SEG ? seg.seg_end() : seg.end;
     spline_grad_loop<MODEL, Rec, real, GW1 ? TAP_SINGLE : TAP_COPIES, kThreads>(pts + seg.pos, seg_end - seg.pos, seg.g * uint32_t(GW), seg.pos - ch.start, ch.count, img, pitch, W, H, pose,
-                                                                               cam, B, cshift, gtile, acc, prio != 0, rb, have_batch);
-    have_batch = false;
+                                                                               cam, B, cshift, gtile, acc, prio != 0);
     grad_reduce_store<kThreads>(acc, s_red, partials, slot, nslots);
     if (!SEG || !seg.advance(seg_end)) break;
     slot++;

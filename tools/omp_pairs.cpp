@@ -115,7 +115,22 @@ int main(int argc, char** argv) {
         if (r >= 0) (phase == 0 ? t_omp : t_multi) += dt;
       }
     }
-    std::printf(", \"pairs_%d\": {\"points_per_pair\": %ld, \"omp_us\": %.1f, \"eval_multi_us\": %.1f, \"cost0\": %.12f}", k, n, t_omp / reps, t_multi / reps, cost[0]);
+    // what the caller's own pattern costs without any evaluation: one parallel region of k threads whose body spins ~1 us
+    // (fork, the threads' arrival skew, join) -- the part of the omp column no library can take out
+    double t_region = 0;
+    for (int r = -10; r < reps; r++) {
+      const auto t0 = std::chrono::steady_clock::now();
+#pragma omp parallel for num_threads(k) schedule(static, 1)
+      for (int p = 0; p < k; p++) {
+        const auto s0 = std::chrono::steady_clock::now();
+        while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - s0).count() < 1.0) {
+        }
+      }
+      const double dt = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+      if (r >= 0) t_region += dt;
+    }
+    std::printf(", \"pairs_%d\": {\"points_per_pair\": %ld, \"omp_us\": %.1f, \"eval_multi_us\": %.1f, \"empty_omp_region_us\": %.1f, \"cohort\": \"%s\", \"cost0\": %.12f}", k, n, t_omp / reps, t_multi / reps,
+                t_region / reps - 1.0, std::getenv("NIDREG_COHORT") ? std::getenv("NIDREG_COHORT") : "", cost[0]);
     for (nidreg_handle* h : hs) nidreg_destroy(h);
   }
   std::printf("}\n");
