@@ -430,8 +430,10 @@ __device__ __forceinline__ void spline_hist_body(
     // kUnroll records per thread are fetched before any of them is processed (memory-level parallelism); the
     // geometry of all of them comes first, then -- wave-uniform choice -- the tap code with uniform or per-lane
     // constants.  Both are branch-free per point, so the scheduler interleaves the kUnroll independent points.
-    // GUARDED = the batch may reach past the end of the segment (clamped loads, per-slot validity); -DNID_EXP_NOCLAMP runs
-    // every full batch without the checks and only the last one with them (experiment: profiles/r04g_variants.txt)
+    // GUARDED = the batch may reach past the end of the segment (clamped loads, per-slot validity).  -DNID_EXP_NOCLAMP runs
+    // every full batch without the checks and only the last one with them, as the gradient loop does: no gain HERE (the
+    // compiler restructures the two tap paths: 927 against 887 instructions per batch; 51.2-52.1 us either way,
+    // profiles/r04g_variants.txt)
     auto batch = [&](uint32_t base, auto guarded) {
       constexpr bool GUARDED = decltype(guarded)::value;
       set_progress_priority(prio, seg.pos - ch.start + base, ch.count);
@@ -1193,7 +1195,9 @@ __device__ __forceinline__ void spline_grad_loop(
       }
     }
   };
-#ifdef NID_EXP_NOCLAMP
+  // every full batch without the bounds checks, the last one with them: 18 of ~920 instructions per batch less, 75.3-75.8 ->
+  // 74.8-75.0 us on cfg 2 (profiles/r04g_variants.txt; -DNID_GRAD_ALWAYS_GUARDED: the single loop)
+#ifndef NID_GRAD_ALWAYS_GUARDED
   uint32_t base = 0;
   for (; base + uint32_t(kT * kUnroll) <= cnt; base += kT * kUnroll) batch(base, std::false_type());
   if (base < cnt) batch(base, std::true_type());

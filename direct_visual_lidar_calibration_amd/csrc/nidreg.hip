@@ -1503,6 +1503,27 @@ int group_eval(MultiGroup* g, const double* se3, bool want_grad, double* costs, 
 // alone, with all of its siblings or with some of them (tests/test_gpu_parity.py test_cohort_...).
 // Returns kNotJoined when the caller should evaluate by itself (another pose is collecting, or the handle is in the round).
 constexpr int kNotJoined = -1000;
+// NIDREG_COHORT_TRACE=1: where a round's time goes (leader's clock), printed when the process ends
+struct CohortTrace {
+  std::atomic<long long> rounds{0}, full{0}, wait_ns{0}, eval_ns{0}, tail_ns{0};
+  bool on = false;
+  CohortTrace() {
+    const char* e = std::getenv("NIDREG_COHORT_TRACE");
+    on = e && *e && *e != '0';
+  }
+  ~CohortTrace() {
+    const long long r = rounds.load();
+    if (on && r > 0)
+      std::fprintf(stderr, "nidreg cohort trace: %lld rounds (%lld with every member), per round: waiting for the siblings %.1f us, evaluation %.1f us, handing the results out %.1f us\n", r, full.load(),
+                   1e-3 * double(wait_ns.load()) / double(r), 1e-3 * double(eval_ns.load()) / double(r), 1e-3 * double(tail_ns.load()) / double(r));
+  }
+};
+CohortTrace g_cohort_trace;
+inline long long mono_ns() {
+  struct timespec t;
+  clock_gettime(CLOCK_MONOTONIC, &t);
+  return (long long)t.tv_sec * 1000000000ll + t.tv_nsec;
+}
 int cohort_eval(nidreg_handle* h, const double* se3, bool want_grad, double* cost, double* grad7) {
   Cohort* c = h->cohort;
   const int k = int(c->members.size());  // (fixed once sealed, except for members being destroyed -- not while their siblings evaluate)
@@ -1543,6 +1564,7 @@ int cohort_eval(nidreg_handle* h, const double* se3, bool want_grad, double* cos
     return h->rv_rc;
   }
   // leader: wait for the siblings, close the round
+  const long long tr0 = g_cohort_trace.on ? mono_ns() : 0;
   struct timespec t0;
   clock_gettime(CLOCK_MONOTONIC, &t0);
   while (c->n_arrived.load(std::memory_order_acquire) < k) {
@@ -1565,6 +1587,8 @@ int cohort_eval(nidreg_handle* h, const double* se3, bool want_grad, double* cos
   });
   int my_rc = NIDREG_OK;
   bool done = false;
+  const long long tr1 = g_cohort_trace.on ? mono_ns() : 0;
+  long long tr2 = 0;
   if (n >= 2) {
     nidreg_handle* hs[16];
     for (int i = 0; i < n; i++) hs[i] = arr[i].h;
@@ -1576,6 +1600,7 @@ int cohort_eval(nidreg_handle* h, const double* se3, bool want_grad, double* cos
       bool all_ok = true;
       const int rc = group_eval(g, se3, want_grad, costs, want_grad ? grads : nullptr, &all_ok, rcs);
       release_group(g);
+      tr2 = g_cohort_trace.on ? mono_ns() : 0;
       const std::string err = rc < 0 ? g_last_error : std::string();
       for (int i = 0; i < n; i++) {
         if (rc >= 0) {
@@ -1608,6 +1633,14 @@ int cohort_eval(nidreg_handle* h, const double* se3, bool want_grad, double* cos
         m->rv_done.store(1, std::memory_order_release);
       }
     }
+  }
+  if (g_cohort_trace.on) {
+    const long long tr3 = mono_ns();
+    g_cohort_trace.rounds.fetch_add(1);
+    if (n == k) g_cohort_trace.full.fetch_add(1);
+    g_cohort_trace.wait_ns.fetch_add(tr1 - tr0);
+    g_cohort_trace.eval_ns.fetch_add((tr2 ? tr2 : tr3) - tr1);
+    g_cohort_trace.tail_ns.fetch_add(tr2 ? tr3 - tr2 : 0);
   }
   return my_rc;
 }

@@ -21,8 +21,7 @@ for line in open(f"{src}/summary.txt"):
     if cur is None:
         continue
     f = line.split()
-    if f[0] in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"):
-        kernels.setdefault(cur, {})[f[0]] = float(f[2])
+    kernels.setdefault(cur, {})[f[0]] = float(f[2])  # every counter of the passes (per-launch means)
 out = {}
 for k, v in kernels.items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
@@ -34,6 +33,8 @@ for k, v in kernels.items():
                           ("SQ_LDS_IDX_ACTIVE", "lds_idx_active_cycles")):
             if name in v:
                 out[k][key] = v[name]
+        # the stall counters of the same build: waiting / busy wave-cycles, LDS and L2 behaviour
+        out[k]["counters"] = {n: v[n] for n in sorted(v) if n not in ("FETCH_SIZE", "WRITE_SIZE")}
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from direct_visual_lidar_calibration_amd import _lib  # noqa: E402
 
