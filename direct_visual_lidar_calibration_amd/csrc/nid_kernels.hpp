@@ -1104,7 +1104,7 @@ enum { TAP_COPIES = 0,   // gtile[(cell << cshift) + lane copy]: lane-private co
 // The point loop of the pass over ONE segment of the workgroup's chunk (`cnt` records from `recs`, all of column group
 // col0 / GW, whose G columns sit in gtile): accumulates M += gp p^T, gt += gp into acc[12].  `done` / `total`: the chunk's
 // progress (issue priority).
-template <int MODEL, typename Rec, typename real, int TAP, int kT>
+template <int MODEL, typename Rec, typename real, int TAP, int kT, bool SPLIT>
 __device__ __forceinline__ void spline_grad_loop(
   const Rec* __restrict__ recs, uint32_t cnt, uint32_t col0, uint32_t done, uint32_t total, const uint8_t* __restrict__ img, int pitch, int W, int H, const PoseParams<real>& pose,
   const CamParams<real>& cam, int B, int cshift, const double* gtile, double* acc, bool prio) {
@@ -1197,13 +1197,16 @@ __device__ __forceinline__ void spline_grad_loop(
   };
   // every full batch without the bounds checks, the last one with them: 18 of ~920 instructions per batch less, 75.3-75.8 ->
   // 74.8-75.0 us on cfg 2 (profiles/r04g_variants.txt; -DNID_GRAD_ALWAYS_GUARDED: the single loop)
-#ifndef NID_GRAD_ALWAYS_GUARDED
-  uint32_t base = 0;
-  for (; base + uint32_t(kT * kUnroll) <= cnt; base += kT * kUnroll) batch(base, std::false_type());
-  if (base < cnt) batch(base, std::true_type());
+  // (SPLIT = false: the looped kernel instantiations, which have no registers to spare for a second copy of the body)
+#ifdef NID_GRAD_ALWAYS_GUARDED
+  constexpr bool kSplit = false;
 #else
-  for (uint32_t base = 0; base < cnt; base += kT * kUnroll) batch(base, std::true_type());
+  constexpr bool kSplit = SPLIT;
 #endif
+  uint32_t base = 0;
+  if constexpr (kSplit)
+    for (; base + uint32_t(kT * kUnroll) <= cnt; base += kT * kUnroll) batch(base, std::false_type());
+  for (; base < cnt; base += kT * kUnroll) batch(base, std::true_type());
 }
 
 // the workgroup's 12 sums -> partials[k][my_block] ([12][nchunks]: coalesced for the final reduction), stored write-through
@@ -1386,7 +1389,7 @@ __global__ __launch_bounds__(kThreads, grad_min_waves(MODEL, SEG, sizeof(Rec) ==
       acc[k] = zero;
     }
     const uint32_t seg_end = SEG ? seg.seg_end() : seg.end;
-    spline_grad_loop<MODEL, Rec, real, GW1 ? TAP_SINGLE : TAP_COPIES, kThreads>(pts + seg.pos, seg_end - seg.pos, seg.g * uint32_t(GW), seg.pos - ch.start, ch.count, img, pitch, W, H, pose,
+    spline_grad_loop<MODEL, Rec, real, GW1 ? TAP_SINGLE : TAP_COPIES, kThreads, !SEG>(pts + seg.pos, seg_end - seg.pos, seg.g * uint32_t(GW), seg.pos - ch.start, ch.count, img, pitch, W, H, pose,
                                                                                cam, B, cshift, gtile, acc, prio != 0);
     grad_reduce_store<kThreads>(acc, s_red, partials, slot, nslots);
     if (!SEG || !seg.advance(seg_end)) break;
