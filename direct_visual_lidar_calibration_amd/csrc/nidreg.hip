@@ -84,6 +84,7 @@ struct nidreg_handle {
 
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  hipStream_t last_stream = nullptr;  // the stream the most recent evaluation's kernels ran on (a multi-pair group's, else `stream`): what the histogram getters drain
   void* d_pts = nullptr;
   Chunk* d_chunks = nullptr;
   Chunk* d_chunks_hist = nullptr;
@@ -293,6 +294,7 @@ void fill_pass_args(const nidreg_handle* h, PassArgs& a) {
 }
 
 inline void bump_seq(nidreg_handle* h) {
+  h->last_stream = h->stream;  // (a multi-pair group overrides this after the call)
   h->seq += 1.0;
   std::memcpy(&h->seq_bits, &h->seq, sizeof(h->seq_bits));
 }
@@ -1431,6 +1433,7 @@ int group_eval(MultiGroup* g, const double* se3, bool want_grad, double* costs, 
     HIP_TRY(begin_histogram(h, g->stream));
     a.dyn.cur[i] = h->hist_cur;
     a.dyn.tag[i] = h->seq;
+    h->last_stream = g->stream;
     for (int k = 0; k < 4; k++) h->last_q[k] = se3[k];
     std::memcpy(h->last_R, a.R, sizeof(a.R));
     std::memcpy(h->last_t, a.t, sizeof(a.t));
@@ -1664,6 +1667,7 @@ int group_eval_iso(MultiGroup* g, const double* T, double* costs) {
     HIP_TRY(begin_histogram(h, g->stream));
     a.dyn.cur[i] = h->hist_cur;
     a.dyn.tag[i] = h->seq;
+    h->last_stream = g->stream;
     h->ev_grad = false;
   }
   a.chunks = g->d_chunks;
@@ -2485,7 +2489,9 @@ int nidreg_get_hist_fixed(nidreg_handle* h, int64_t* joint, int64_t* inliers, in
     return NIDREG_OK;
   }
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  // the marginals / scalars are plain stores of a gradient workgroup: the host sees the completion tag before the kernel has
+  // ended, so drain the stream the evaluation really ran on (a multi-pair group's stream is not the handle's)
+  HIP_TRY(hipStreamSynchronize(h->last_stream ? h->last_stream : h->stream));
   const int B = h->bins;
   std::vector<u64> tmp(size_t(h->hist_words));
   HIP_TRY(hipMemcpy(tmp.data(), h->d_hist, tmp.size() * sizeof(u64), hipMemcpyDeviceToHost));
@@ -2510,7 +2516,7 @@ int nidreg_get_hist(nidreg_handle* h, double* joint, double* hist_image, double*
     for (size_t k = 0; k < fx.size(); k++) joint[k] = double(fx[k]) * inv_unit;
   }
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipStreamSynchronize(h->last_stream ? h->last_stream : h->stream));  // (see nidreg_get_hist_fixed)
   if (hist_image) HIP_TRY(hipMemcpy(hist_image, h->d_hist_image, size_t(B) * sizeof(double), hipMemcpyDeviceToHost));
   if (hist_points) HIP_TRY(hipMemcpy(hist_points, h->d_hist_points, size_t(B) * sizeof(double), hipMemcpyDeviceToHost));
   return NIDREG_OK;

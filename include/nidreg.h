@@ -275,7 +275,10 @@ int nidreg_equalize_intensities(int device_id, double* intensities, int64_t num_
  *          <caller: all-reduce(sum, f64) of out[1..7]>
  *          nidreg_shard_finish(h, ...)    stream sync + read back
  * All shard calls are asynchronous on the handle's stream except nidreg_shard_finish. */
-int64_t nidreg_hist_words(int bins); /* 64-bit words in the histogram buffer (bins*bins + 8 tail words + column sums) */
+/* 64-bit words in a histogram buffer (desc.ext_hist must hold this many): bins*bins joint cells [bin_points][bin_image], 8 tail
+ * words (0: inlier count, 1: fixed-point joint entropy), roundup8(bins) column sums (added by the histogram kernels' flush) and
+ * roundup8(bins) row sums (added by k_entropy) -- bins*bins + 8 + 2*roundup8(bins) */
+int64_t nidreg_hist_words(int bins);
 int nidreg_shard_hist(nidreg_handle* h, const double* se3);
 int nidreg_shard_entropy(nidreg_handle* h);
 int nidreg_shard_grad(nidreg_handle* h);

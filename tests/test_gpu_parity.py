@@ -4,7 +4,7 @@ seeded inputs.  Run with ``pytest -m gpu`` on an MI355X.
 Tolerances (ours; the reference defines none -- SURVEY.md section 7):
   * NEAREST (CostCalculatorNID): integer joint histogram BIT-EXACT; NID abs <= 1e-12.
   * SPLINE  (NIDCost), fp64: the bars of tests/parity.py, set from the margins the suite observes (raw joint histogram abs
-    <= 1e-9 per bin -- fixed point 2^-39..2^-40 per tap --, NID abs <= 1e-11, 7-gradient rel <= 2e-9 + abs 1e-11).
+    <= 1e-9 per bin -- fixed point 2^-39..2^-40 per tap --, NID abs <= 1e-11, 7-gradient rel <= 5e-10 + abs 1e-11).
   * SPLINE fp32 geometry: NID abs <= 2e-5, gradient rel <= 2e-2 of its norm.
 """
 import numpy as np

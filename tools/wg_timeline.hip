@@ -71,9 +71,14 @@ int main(int argc, char** argv) {
 
   Rec32* d_recs;
   Chunk* d_chunks;
+  uint32_t* d_gend;  // end offsets of the column groups (nid_kernels.hpp Segments; every chunk here lies inside one group)
+  std::vector<uint32_t> gend(static_cast<size_t>(B));
+  for (int g = 0; g < B; g++) gend[size_t(g)] = uint32_t((g + 1) * per);
+  CK(hipMalloc(&d_gend, gend.size() * sizeof(uint32_t)));
+  CK(hipMemcpy(d_gend, gend.data(), gend.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   uint8_t* d_img;
   u64* d_hist;
-  const size_t hist_words = size_t(B) * B + 8 + B;
+  const size_t hist_words = size_t(B) * B + 8 + 2 * size_t((B + 7) & ~7);  // nidreg_hist_words(B): joint cells, tail, column sums, row sums
   CK(hipMalloc(&d_recs, recs.size() * sizeof(Rec32) + 64));
   CK(hipMalloc(&d_chunks, chunks.size() * sizeof(Chunk)));
   CK(hipMalloc(&d_img, img.size()));
@@ -89,7 +94,7 @@ int main(int argc, char** argv) {
   cam.dist[0] = -0.04, cam.dist[1] = 0.08, cam.dist[2] = 1e-4, cam.dist[3] = -3e-4, cam.dist[4] = -0.04;
   const int frac = 38;
   const double dn = std::ldexp(1.0, frac - 1074);
-  auto k = k_spline_hist<MODEL_PLUMB_BOB, Rec32, double, true, false>;
+  auto k = k_spline_hist<MODEL_PLUMB_BOB, Rec32, double, true, false, false>;
   const size_t lds = (size_t(B) * 8 << kWideShift) + 8 + 16;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
   hipEvent_t e0, e1;
@@ -99,7 +104,8 @@ int main(int argc, char** argv) {
   for (int it = 0; it < 6; it++) {
     CK(hipMemset(d_hist, 0, hist_words * 8));
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL(k, dim3(unsigned(chunks.size())), dim3(kWideThreads), lds, 0, d_recs, d_chunks, d_img, pitch, W, H, pose, cam, B, 1, kWideShift, dn, d_hist, static_cast<const MultiEntry*>(nullptr), NoMultiDyn());
+    hipLaunchKernelGGL(k, dim3(unsigned(chunks.size())), dim3(kWideThreads), lds, 0, d_recs, d_chunks, d_gend, d_img, pitch, W, H, pose, cam, B, 1, kWideShift, dn, d_hist, 1, static_cast<const ShardTable*>(nullptr), u64(0),
+                       static_cast<unsigned int*>(nullptr), static_cast<const MultiEntry*>(nullptr), NoMultiDyn());
     CK(hipEventRecord(e1));
     CK(hipDeviceSynchronize());
     CK(hipEventElapsedTime(&ms, e0, e1));
