@@ -206,6 +206,7 @@ namespace {
 void free_shard_set(ShardSet* set);
 void drop_groups_of(const nidreg_handle* h);
 void cohort_leave(nidreg_handle* h);
+std::atomic<int> g_inflight[NIDREG_MAX_DEVICES];  // evaluations in flight per device (InflightGuard below)
 
 void free_handle(nidreg_handle* h) {
   if (!h) return;
@@ -217,6 +218,8 @@ void free_handle(nidreg_handle* h) {
   cohort_leave(h);
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (auto& p : h->pending)  // tickets never collected: give their in-flight counts back to the device
+    if (p.seq != 0.0 && p.counted && h->device >= 0 && h->device < NIDREG_MAX_DEVICES) g_inflight[h->device].fetch_sub(1, std::memory_order_acq_rel);
   if (h->d_pts) (void)hipFree(h->d_pts);
   if (h->d_chunks) (void)hipFree(h->d_chunks);
   if (h->d_chunks_hist) (void)hipFree(h->d_chunks_hist);
@@ -303,7 +306,6 @@ inline void bump_seq(nidreg_handle* h) {
 // priority in the spline passes; with several callers on one GPU (the reference's OpenMP loop over pairs,
 // visual_camera_calibration.cpp:161) it is off: the rule made competing kernels 5-16 % slower
 // (profiles/r02h_multi_pair_threads.txt).
-std::atomic<int> g_inflight[NIDREG_MAX_DEVICES];
 struct InflightGuard {
   int dev;
   bool alone;
@@ -615,7 +617,7 @@ bool trust_gate_ok(const double* init, const double* se3) {
 extern "C" {
 
 const char* nidreg_last_error(void) { return g_last_error.c_str(); }
-const char* nidreg_version(void) { return "nidreg 0.3 (gfx950, hand-written HIP)"; }
+const char* nidreg_version(void) { return "nidreg 0.4 (gfx950, hand-written HIP)"; }
 
 int nidreg_model_from_name(const char* name, int* num_intrinsics, int* num_distortion) {
   if (!name) return -1;
