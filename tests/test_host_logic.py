@@ -79,6 +79,37 @@ def test_nelder_mead_minimises_and_counts_like_the_reference():
     assert r.num_evaluations >= 3 + 2 * r.num_iterations
 
 
+def test_nelder_mead_batch_function_changes_nothing_but_the_grouping():
+    """dfo.NelderMead.optimize(batch_function=...) hands the vertices that do not depend on each other -- the n + 1 of the
+    initial simplex (nelder_mead.hpp:37-45), the n of a shrink step (:88-92) -- to the objective in one call (a GPU objective
+    then has them all in flight: nidreg_submit / nidreg_wait); every probe, its order, the result and the evaluation count
+    must equal the vertex-by-vertex run.  A Rosenbrock-like valley forces shrink steps."""
+    def f(x):
+        return float(100.0 * (x[1] - x[0] ** 2) ** 2 + (1.0 - x[0]) ** 2 + 0.3 * np.sin(7 * x[2]) ** 2 + x[2] ** 2)
+
+    seq_a, seq_b, batches = [], [], []
+
+    def fa(x):
+        seq_a.append(x.copy())
+        return f(x)
+
+    def fb(x):
+        seq_b.append(x.copy())
+        return f(x)
+
+    def fb_many(xs):
+        batches.append(len(xs))
+        return [fb(x) for x in xs]
+
+    params = NelderMeadParams(init_step=0.7, convergence_var_thresh=1e-14, max_iterations=400)
+    ra = NelderMead(params).optimize(fa, np.array([-1.2, 1.0, 0.5]))
+    rb = NelderMead(params).optimize(fb, np.array([-1.2, 1.0, 0.5]), batch_function=fb_many)
+    assert ra.num_evaluations == rb.num_evaluations == len(seq_a) == len(seq_b)
+    assert all(np.array_equal(a, b) for a, b in zip(seq_a, seq_b))
+    assert np.array_equal(ra.x, rb.x) and ra.y == rb.y and ra.num_iterations == rb.num_iterations
+    assert batches[0] == 4 and all(b == 3 for b in batches[1:]) and len(batches) >= 2  # the initial simplex, then shrink steps
+
+
 def test_bench_helpers_algorithmic_bytes_labels_and_committed_traffic():
     """bench.py's bookkeeping (no GPU): SURVEY 8(d) byte formula, BASELINE config labels, and the PMC traffic
     figure it reports is the one committed under profiles/ for the default workload."""
