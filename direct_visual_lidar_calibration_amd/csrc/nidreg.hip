@@ -788,6 +788,39 @@ int64_t segment_overhead(bool wide_hist) {
   return wide_hist ? 1024 : 384;
 }
 
+// How many chunks (= workgroups) a pass over `points` records gets.  A FULL round -- every co-resident slot of the GPU, per_cu
+// workgroups on each CU -- is right for the 10M-point headline and wrong for the clouds `calibrate` usually sees: a workgroup
+// costs a fixed prologue + epilogue (tile zeroing, the G columns' logarithms, the flush's atomics on the cells every other
+// workgroup flushes too, the partial reduction), and the workgroups of a CU share its issue slots, so a pass costs about
+//     a x chunks / CUs  +  b x points / chunks          (prologues on the busiest CU + the sweeps of one workgroup's slice),
+// smallest at chunks ~ sqrt(points).  Measured (profiles/r04i_small_cloud_sweep.jsonl, synchronous cost+Jacobian evaluation,
+// best chunk count against the full round's): 30k points 64-128 chunks, 28 us against 37; 100k 128, 29 against 48; 300k
+// 192-256, 35 against 51; 1M 384-512, 45 against 54; 3M 512-768, 71 against 76; 10M 1024 (the full round).  The rule is the
+// square root through those points -- CUs/2 chunks at 100k points --, capped by the full round (reached at 6.4M points).
+// NIDREG_FULL_ROUND=1 restores the full round at every size (A/B runs).
+int64_t round_chunks(int per_cu, int num_cus, int64_t points) {
+  const int64_t full = std::max<int64_t>(1, int64_t(per_cu) * num_cus);
+  static const bool always_full = [] {
+    const char* e = std::getenv("NIDREG_FULL_ROUND");
+    return e && *e && *e != '0';
+  }();
+  if (always_full) return full;
+  const double t = 0.5 * double(num_cus) * std::sqrt(double(std::max<int64_t>(points, 1)) / 1.0e5);
+  return std::max<int64_t>(1, std::min<int64_t>(full, int64_t(t + 0.5)));
+}
+// ... for a handle's own tables, in whole multiples of its non-empty column groups where it has several: a target between
+// two multiples splits SOME groups once more and leaves the longest chunk as it was (B = 256, 1M points: 384 chunks 53 us,
+// 256 chunks 47 us, 512 chunks 47 us), and a target below the group count would put several groups into every chunk --
+// the looped kernels, 60 us against 34 us for 256 one-group chunks at 30k points.
+int64_t snap_to_groups(int64_t target, const int64_t* gcount, int NG, int64_t cap) {
+  int64_t nonempty = 0;
+  for (int g = 0; g < NG; g++) nonempty += gcount[g + 1] > gcount[g] ? 1 : 0;
+  if (nonempty <= 1) return target;
+  int64_t per_group = std::max<int64_t>(1, (target + nonempty / 2) / nonempty);
+  while (per_group > 1 && per_group * nonempty > cap) per_group--;
+  return per_group * nonempty;
+}
+
 struct CreateOpts {
   // one shard of a ShardSet: built from the column groups [group_lo, group_hi) of `master` (a complete handle of the pair
   // on the owner device) -- its bin image and that slice of its bucketed records are copied device to device
@@ -1015,7 +1048,12 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
     h->per_cu_grad = h->wide ? per_cu_grad : std::min(per_cu_grad, per_cu_hist);
     h->per_cu_hist = per_cu_hist;
     std::vector<Chunk> chunks;
-    h->nslots = int(build_chunks(d->target_blocks > 0 ? d->target_blocks : (h->wide ? per_cu_grad : std::min(per_cu_grad, per_cu_hist)) * num_cus, false, chunks));
+    auto own_target = [&](int per_cu) {
+      if (d->target_blocks > 0) return int(d->target_blocks);
+      const int64_t full = int64_t(per_cu) * num_cus;
+      return int(snap_to_groups(round_chunks(per_cu, num_cus, N), gcount.data(), h->NG, full));
+    };
+    h->nslots = int(build_chunks(own_target(h->per_cu_grad), false, chunks));
     h->nchunks = int(chunks.size());
     h->seg = h->nslots > h->nchunks ? 1 : 0;
     if (h->seg && GW == 1) h->lds_grad = spline_grad_lds_bytes(B, GW, cshift, true);
@@ -1024,7 +1062,7 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
     if (!chunks.empty()) CREATE_TRY(hipMemcpy(h->d_chunks, chunks.data(), chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice));
     if (h->wide) {
       std::vector<Chunk> wide_chunks;
-      const int64_t wide_slots = build_chunks(d->target_blocks > 0 ? d->target_blocks : per_cu_hist * num_cus, true, wide_chunks);
+      const int64_t wide_slots = build_chunks(own_target(per_cu_hist), true, wide_chunks);
       h->nchunks_hist = int(wide_chunks.size());
       h->seg_hist = wide_slots > int64_t(wide_chunks.size()) ? 1 : 0;
       h->chunks_hist_cap = std::max<size_t>(wide_chunks.size(), 1);
@@ -1208,7 +1246,7 @@ int cohort_reshape(nidreg_handle* h, int64_t total_points) {
   const int64_t mine = std::max<int64_t>(h->num_points, 1);
   auto rebuild = [&](int per_cu, bool wide_hist, Chunk*& d_tab, size_t& cap, int& n_out, int64_t* slots_out) -> int {
     std::vector<Chunk> chunks;
-    const int64_t share = std::max<int64_t>(1, int64_t(per_cu) * h->num_cus * mine / total_points);
+    const int64_t share = std::max<int64_t>(1, round_chunks(per_cu, h->num_cus, total_points) * mine / total_points);
     const int64_t slots = split_groups(h->gcount.data(), h->NG, share, segment_overhead(wide_hist), max_segments(h->mode, h->GW), -1, chunks);
     if (chunks.size() > cap) {
       if (d_tab) HIP_TRY(hipFree(d_tab));
@@ -1340,11 +1378,11 @@ MultiGroup* find_or_make_group(nidreg_handle* const* handles, int n) {
         if (h->seg_hist) g->seg_hist = 1;
       }
     } else {
-      const int64_t share_grad = std::max<int64_t>(1, int64_t(h0->per_cu_grad) * h0->num_cus * std::max<int64_t>(h->num_points, 1) / total);
+      const int64_t share_grad = std::max<int64_t>(1, round_chunks(h0->per_cu_grad, h0->num_cus, total) * std::max<int64_t>(h->num_points, 1) / total);
       pair_slots = pair_chunks(h, i, share_grad, false, pair_grad[size_t(i)]);
       if (pair_slots > int64_t(pair_grad[size_t(i)].size())) g->seg = 1;
       if (h0->wide) {
-        const int64_t share_hist = std::max<int64_t>(1, int64_t(h0->per_cu_hist) * h0->num_cus * std::max<int64_t>(h->num_points, 1) / total);
+        const int64_t share_hist = std::max<int64_t>(1, round_chunks(h0->per_cu_hist, h0->num_cus, total) * std::max<int64_t>(h->num_points, 1) / total);
         if (pair_chunks(h, i, share_hist, true, pair_hist[size_t(i)]) > int64_t(pair_hist[size_t(i)].size())) g->seg_hist = 1;
       }
     }
@@ -2684,6 +2722,13 @@ int nidreg_debug_chunk_table(const int64_t* gcount, int NG, int target, int over
     rows_out[4 * k] = chunks[k].start, rows_out[4 * k + 1] = chunks[k].count, rows_out[4 * k + 2] = chunks[k].group, rows_out[4 * k + 3] = chunks[k].pad;
   }
   return int(chunks.size());
+}
+
+/* test hook (tests/test_host_logic.py; not part of the drop-in surface): the number of chunks a handle's own table of a pass
+ * gets -- round_chunks (the square-root rule) snapped to whole multiples of the non-empty column groups, as create_impl does */
+int nidreg_debug_round_chunks(int per_cu, int num_cus, const int64_t* gcount, int NG) {
+  if (!gcount || NG < 1 || per_cu < 1 || num_cus < 1) return NIDREG_ERR_INVALID;
+  return int(snap_to_groups(round_chunks(per_cu, num_cus, gcount[NG] - gcount[0]), gcount, NG, int64_t(per_cu) * num_cus));
 }
 
 void nidreg_trim(void) {

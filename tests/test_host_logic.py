@@ -254,3 +254,34 @@ def test_chunk_tables_fit_one_round_of_workgroups():
     # groups win by more than the threshold and are used
     rows, g = table(culled, 512, 1024)
     assert (rows[-1, 3] >> 8) + 1 > len(rows) and rows[:, 1].max() <= 1.08 * culled.sum() / 512 + 64
+
+
+def test_small_clouds_get_fewer_chunks_than_a_full_round():
+    """The number of chunks of a pass (csrc/nidreg.hip round_chunks / snap_to_groups, through a test hook): CUs/2 at 100k points,
+    growing with the square root of the cloud, the full round of co-resident workgroups from 6.4M points on; whole multiples of
+    the non-empty column groups and never fewer chunks than groups (profiles/r04i_small_cloud_sweep.jsonl: what each of
+    these choices was measured against)."""
+    import ctypes
+
+    from direct_visual_lidar_calibration_amd import _lib
+
+    lib = _lib.load()
+    lib.nidreg_debug_round_chunks.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.c_int]
+
+    def chunks(counts, per_cu=4, cus=256):
+        g = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        return lib.nidreg_debug_round_chunks(per_cu, cus, g.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), len(counts))
+
+    one = [chunks([n]) for n in (1, 30_000, 100_000, 300_000, 1_000_000, 3_000_000, 6_400_000, 10_000_000, 50_000_000)]
+    assert one == [1, 70, 128, 222, 405, 701, 1024, 1024, 1024]
+    assert chunks([10_000_000], per_cu=2) == 512 and chunks([10_000_000], per_cu=3) == 768  # the WIDE histogram kernel / the fisheye gradient kernel
+    for bins_groups in (16, 64, 256):  # B = 64 / 128 / 256
+        for n in (30_000, 100_000, 1_000_000, 3_000_000, 10_000_000):
+            c = chunks(np.full(bins_groups, n // bins_groups))
+            assert c % bins_groups == 0 and bins_groups <= c <= 1024 and abs(c - max(bins_groups, min(1024, chunks([n])))) <= bins_groups // 2 + (1024 % bins_groups)
+    assert chunks(np.full(256, 117)) == 256 and chunks(np.full(256, 3906)) == 512 and chunks(np.full(256, 39062)) == 1024
+    assert chunks(np.full(256, 39062), per_cu=2) == 512 and chunks(np.full(256, 39062), per_cu=3) == 768
+    culled = np.full(256, 400)
+    culled[::2] = 0  # half of the columns empty: multiples of the 128 that hold points
+    assert chunks(culled) % 128 == 0
+    assert chunks(np.zeros(16, dtype=np.int64)) >= 1
