@@ -1234,21 +1234,60 @@ struct GradTail {
   double* hist_points;
   EntropyScalars* scal;
   int from_partials;         // 1: run the tail on the row sums / Hj k_entropy left behind the histogram; 0: read scal / phi_q
-                             // as k_entropy's own tail (or k_entropy_gather) wrote them
+                             // as k_entropy's own tail (or k_entropy_gather) wrote them; 2: no k_entropy ran at all -- the
+                             // workgroup sums the B x B cells itself (small tables only, grad_entropy_partials)
+  u64* zero_buf;             // from_partials == 2: the histogram buffer of the NEXT evaluation, cleared here (k_entropy's other duty)
+  long long zero_words;
 };
+// Tables of at most this many cells (B <= 32; the reference's default is 16 bins) need no entropy kernel in a cost+Jacobian
+// evaluation: every gradient workgroup reads the whole table -- 1 to 4 cells per thread, about what its G tile costs it
+// anyway -- and gets the same integers k_entropy would have left behind the histogram (sums of ent_fixed terms and of
+// fixed-point cells: the order does not matter).  One launch and one kernel boundary less per evaluation.
+constexpr int kSelfEntropyCells = 1024;
+
+// row sums (into s_rows[B], LDS) and the fixed-point sum of p log(p + eps) over ALL cells of a small table, by every thread of
+// the workgroup; s_redk: kT / 64 words.  The caller's next barrier publishes both.
+template <int kT>
+__device__ __forceinline__ void grad_entropy_partials(const u64* __restrict__ hist, int B, double inv_unit, unsigned long long* s_rows, long long* s_redk) {
+  const int tid = threadIdx.x;
+  for (int r = tid; r < B; r += kT) s_rows[r] = 0;
+  __syncthreads();
+  const double S = double(hist[size_t(B) * size_t(B) + kTailInliers]);
+  const double scale = inv_unit / S;  // the same two operations as k_entropy: identical terms
+  long long acc = 0;
+  for (int k = tid; k < B * B; k += kT) {
+    const u64 v = hist[k];
+    if (v) {
+      const double p = double(v) * scale;
+      acc += ent_fixed(p * log(p + 1e-6));
+      atomicAdd(&s_rows[k % B], (unsigned long long)v);  // device layout [bin_points][bin_image]: k % B = the image bin
+    }
+  }
+  acc = wave_sum(acc);
+  if ((tid & 63) == 0) s_redk[tid >> 6] = acc;
+}
 
 // The entropy tail in the gradient kernel's prologue: every workgroup computes the three entropies from the sums k_entropy
 // left behind the histogram (integers: identical bits everywhere), NID, coefA / coefB, and phi(q_r) into s_phi.  `writer` (one
 // workgroup per pair) publishes hist_image / hist_points / phi_q / scal and -- at agent scope, read by grad_final_body in
 // another workgroup -- cost, status and inlier count.  s_redk: 3 * (kT / 64) words of LDS.
-template <int kT>
+template <int kT, bool SELF>
 __device__ __forceinline__ EntropyScalars grad_scalars_from_partials(const u64* hist, int B, double inv_unit, const GradTail& gt, double* s_phi, long long* s_redk, bool writer, double* out) {
   const int tid = threadIdx.x;
   const double S = double(hist[size_t(B) * size_t(B) + kTailInliers]);
   const u64* col_sum = hist + size_t(B) * size_t(B) + kTailWords;
   const u64* row_sum = hist + hist_row_sums_at(B);
   long long hi_k = 0, hp_k = 0;
-  const long long hj_all = (long long)hist[size_t(B) * size_t(B) + kTailHj];
+  long long hj_all = 0;
+  if constexpr (SELF) {  // no k_entropy ran: row sums in LDS (behind phi: B <= 32), wave partials of Hj in s_redk[2 kT/64 ...]
+    unsigned long long* s_rows = reinterpret_cast<unsigned long long*>(s_phi + 128);
+    grad_entropy_partials<kT>(hist, B, inv_unit, s_rows, s_redk + 2 * (kT / 64));
+    __syncthreads();
+    row_sum = reinterpret_cast<const u64*>(s_rows);
+    for (int w = 0; w < kT / 64; w++) hj_all += s_redk[2 * (kT / 64) + w];
+  } else {
+    hj_all = (long long)hist[size_t(B) * size_t(B) + kTailHj];
+  }
   for (int r = tid; r < B; r += kT) {
     const double raw = double(row_sum[r]) * inv_unit;  // raw (un-normalised) hist_image[r]
     const double qv = raw / S;
@@ -1355,9 +1394,26 @@ __global__ __launch_bounds__(kThreads, grad_min_waves(MODEL, SEG, sizeof(Rec) ==
     gt.scal = as_global(e.scal);
   }
   {
-    double coefA, coefB, S;
-    if (gt.from_partials) {
-      const EntropyScalars es = grad_scalars_from_partials<kThreads>(hist, B, inv_unit, gt, s_phi, reinterpret_cast<long long*>(s_red), my_block == 0, out);
+    double coefA = 0.0, coefB = 0.0, S = 1.0;
+    bool self = false;
+    if constexpr (!GW1) self = gt.from_partials == 2;  // (small tables: always several columns per workgroup)
+    if (self) {
+      if constexpr (!GW1) {
+        u64* zero_buf = gt.zero_buf;
+        long long zero_words = gt.zero_words;
+        if constexpr (MULTI) {
+          const MultiEntry& e = multi[ch.pad & 0xffu];
+          zero_buf = as_global(e.hist_buf[dyn.cur[ch.pad & 0xffu] ^ 1]);
+          zero_words = e.zero_words;
+        }
+        if (zero_buf)
+          for (long long k = (long long)my_block * kThreads + tid; k < zero_words; k += (long long)my_blocks * kThreads) zero_buf[k] = 0;
+        const EntropyScalars es = grad_scalars_from_partials<kThreads, true>(hist, B, inv_unit, gt, s_phi, reinterpret_cast<long long*>(s_red), my_block == 0, out);
+        coefA = es.coefA, coefB = es.coefB, S = es.S;
+        phi_q = s_phi;
+      }
+    } else if (gt.from_partials) {
+      const EntropyScalars es = grad_scalars_from_partials<kThreads, false>(hist, B, inv_unit, gt, s_phi, reinterpret_cast<long long*>(s_red), my_block == 0, out);
       coefA = es.coefA, coefB = es.coefB, S = es.S;
       phi_q = s_phi;  // LDS through a generic pointer: B reads per tile
     } else {

@@ -65,6 +65,8 @@ struct PassArgs {
   double* gt_hist_points;
   EntropyScalars* gt_scal;
   int gt_from_partials;
+  void* gt_zero_buf;       // gt_from_partials == 2 (GradTail): the next evaluation's histogram buffer, cleared by the gradient kernel
+  long long gt_zero_words;
   int prio;  // progress priority (s_setprio) in the spline passes: set when the evaluation has its device to itself
 };
 

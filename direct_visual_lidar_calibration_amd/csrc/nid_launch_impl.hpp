@@ -114,6 +114,8 @@ static hipError_t launch_spline_grad_rec(const PassArgs& a) {
   gt.hist_points = a.gt_hist_points;
   gt.scal = a.gt_scal;
   gt.from_partials = a.gt_from_partials;
+  gt.zero_buf = static_cast<u64*>(a.gt_zero_buf);
+  gt.zero_words = a.gt_zero_words;
   if (a.seg && a.GW != 1) return hipErrorInvalidValue;  // multi-segment tables are built for the single-column kernels only
 #define NID_LAUNCH_G(M, GW1, SEG)                                                                                                                      \
   if (a.multi) {                                                                                                                                       \

@@ -67,6 +67,7 @@ struct nidreg_handle {
   int GW = 0, NG = 0, cshift = 0;
   int wide = 0;  // k_spline_hist<.., WIDE>: B = 256, GW = 1, 32 copies, 512 threads
   int NEB = 0;  // entropy column blocks
+  int self_entropy = -1;  // 1: cost+Jacobian evaluations launch no entropy kernel (grad_sums_table); -1: not decided yet
   int frac_bits = 0;
   int rec64 = 0;
   int64_t num_points = 0;
@@ -452,11 +453,27 @@ int launch_entropy(nidreg_handle* h, double tag, bool tail = true) {
   return NIDREG_OK;
 }
 
-int launch_grad(nidreg_handle* h, bool alone = false, bool from_partials = false) {
+// small tables (B <= 32): a cost+Jacobian evaluation launches no entropy kernel, the gradient workgroups sum the table
+// themselves (nid_kernels.hpp kSelfEntropyCells).  NIDREG_NO_SELF_ENTROPY=1: always k_entropy (A/B runs)
+bool grad_sums_table(const nidreg_handle* h) {
+  if (h->self_entropy < 0) {  // decided at the handle's first cost+Jacobian evaluation
+    const char* e = std::getenv("NIDREG_NO_SELF_ENTROPY");
+    const bool off = e && *e && *e != '0';
+    const_cast<nidreg_handle*>(h)->self_entropy = (!off && h->mode == NIDREG_MODE_SPLINE && h->GW != 1 && h->bins * h->bins <= kSelfEntropyCells && !h->is_shard && !h->set) ? 1 : 0;
+  }
+  return h->self_entropy == 1;
+}
+
+int launch_grad(nidreg_handle* h, bool alone = false, int from_partials = 0) {
   PassArgs a;
   fill_pass_args(h, a);
   a.prio = alone ? 1 : 0;
-  a.gt_from_partials = from_partials ? 1 : 0;
+  a.gt_from_partials = from_partials;
+  if (from_partials == 2) {
+    a.gt_zero_buf = h->own_hist ? h->d_hist_buf[h->hist_cur ^ 1] : nullptr;
+    a.gt_zero_words = h->hist_words;
+    if (h->own_hist) h->hist_zeroed[h->hist_cur ^ 1] = true;  // zeroed by this evaluation's gradient kernel for the next one
+  }
   a.hist = h->d_hist;  // the finished histogram (for a shard: its own columns)
   // same pose as the histogram pass of this evaluation
   std::memcpy(a.R, h->last_R, sizeof(a.R));
@@ -490,12 +507,13 @@ int eval_launch_rest(nidreg_handle* h, bool want_grad, bool alone = false) {
   HIP_TRY(hipSetDevice(h->device));
   // cost + Jacobian on a non-empty cloud: k_entropy stores its partials and ends; every gradient workgroup runs the tail
   const bool grad_runs_tail = want_grad && h->nchunks > 0;
-  int rc = launch_entropy(h, want_grad ? 0.0 : h->seq, !grad_runs_tail);
+  const bool no_entropy_kernel = grad_runs_tail && grad_sums_table(h);
+  int rc = no_entropy_kernel ? NIDREG_OK : launch_entropy(h, want_grad ? 0.0 : h->seq, !grad_runs_tail);
   if (rc) return rc;
   if (h->timing == 1) HIP_TRY(hipEventRecord(h->ev[3], h->stream));
   h->ev_grad = want_grad;
   if (want_grad) {
-    rc = launch_grad(h, alone, grad_runs_tail);
+    rc = launch_grad(h, alone, no_entropy_kernel ? 2 : (grad_runs_tail ? 1 : 0));
     if (rc) return rc;
   } else if (h->timing == 1) {
     HIP_TRY(hipEventRecord(h->ev[4], h->stream));
@@ -2760,7 +2778,7 @@ int nidreg_get_info(nidreg_handle* h, int64_t* info8) {
   }
   const double ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
   const int nfast = h->mode == NIDREG_MODE_NEAREST ? nearest_fast_args(h, ident).on : 0;
-  info8[7] = (h->rec64 ? 0 : 1) | (h->seg ? 2 : 0) | (h->seg_hist ? 4 : 0) | (nfast ? 8 : 0) | (int64_t(1 << h->cshift) << 8);
+  info8[7] = (h->rec64 ? 0 : 1) | (h->seg ? 2 : 0) | (h->seg_hist ? 4 : 0) | (nfast ? 8 : 0) | (grad_sums_table(h) ? 16 : 0) | (int64_t(1 << h->cshift) << 8);
   return NIDREG_OK;
 }
 

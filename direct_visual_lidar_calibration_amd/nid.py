@@ -253,6 +253,7 @@ class _Handle:
         out["segmented"] = (out["float32_records"] >> 1) & 1       # gradient-pass table: chunks run across column groups (looped kernels)
         out["segmented_hist"] = (out["float32_records"] >> 2) & 1  # the WIDE histogram kernel's table
         out["nearest_fast"] = (out["float32_records"] >> 3) & 1    # NEAREST: the fast decision tier is in use
+        out["grad_sums_table"] = (out["float32_records"] >> 4) & 1  # B <= 32: cost+Jacobian evaluations launch no entropy kernel
         out["float32_records"] &= 1
         return out
 

@@ -304,7 +304,8 @@ int nidreg_get_timing(nidreg_handle* h, float* ms6);
  * [5]=padded image pitch, [6]=points stored, [7]=bit0: float32 records, bit1: the gradient-pass chunk table has chunks that run
  * across column groups (the looped kernel instantiations, csrc/nid_kernels.hpp Segments), bit2: so has the WIDE histogram
  * kernel's table, bit3: NEAREST handle whose evaluations use the fast decision tier (plumb_bob, fp64, FoV cone below ~84 degrees;
- * csrc/nid_kernels.hpp NearestFast), bits 8..: LDS copies per histogram cell */
+ * csrc/nid_kernels.hpp NearestFast), bit4: cost+Jacobian evaluations launch no entropy kernel (bins <= 32: the gradient workgroups
+ * sum the table themselves, csrc/nid_kernels.hpp kSelfEntropyCells), bits 8..: LDS copies per histogram cell */
 int nidreg_get_info(nidreg_handle* h, int64_t* info8);
 
 const char* nidreg_last_error(void);

@@ -992,6 +992,42 @@ def test_chunks_across_column_groups_match_one_group_per_chunk(model, monkeypatc
         calc.close()
 
 
+def test_small_tables_need_no_entropy_kernel(monkeypatch):
+    """bins <= 32 (the reference's default is 16): a cost+Jacobian evaluation launches two kernels -- every gradient workgroup
+    sums the B x B table itself and clears the next evaluation's buffer (nid_kernels.hpp kSelfEntropyCells).  The sums are
+    integers, so cost, marginals and gradient are the SAME BITS as with k_entropy (NIDREG_NO_SELF_ENTROPY=1), also when
+    cost-only and cost+Jacobian evaluations alternate on the double-buffered histogram, for tables of several column groups,
+    and through submit / wait."""
+    s = scene_for("plumb_bob", n=60_000, seed=77)
+    proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
+    rng = np.random.default_rng(8)
+    poses = [s.T_camera_lidar_init] + [synth.random_pose_near(s.T_camera_lidar_true, rng) for _ in range(5)]
+    for bins, tuning in ((16, {}), (2, {}), (7, {}), (32, {}), (16, {"columns_per_group": 4}), (16, {"target_blocks": 3}), (33, {})):
+        monkeypatch.setenv("NIDREG_NO_SELF_ENTROPY", "1")
+        old = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, bins, **tuning)
+        ref = [old(x) for x in poses]
+        ref_marg = old.histograms()
+        assert old.info()["grad_sums_table"] == 0
+        monkeypatch.delenv("NIDREG_NO_SELF_ENTROPY")
+        new = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, bins, **tuning)
+        assert new.info()["grad_sums_table"] == (1 if bins <= 32 else 0)
+        for j, x in enumerate(poses):
+            if j % 2:
+                okc, cc, _ = new(x, want_grad=False)  # k_entropy with its tail, between two evaluations that launch none
+                assert okc and cc == ref[j][1]
+            ok, c, g = new(x)
+            assert ok == ref[j][0] and c == ref[j][1] and np.array_equal(g, ref[j][2]), (bins, tuning, j)
+        for a, b in zip(new.histograms(), ref_marg):
+            assert np.array_equal(a, b)
+        oks, cs, gs = new.eval_batch(np.ascontiguousarray(poses), pipelined=True)
+        assert oks and [float(v) for v in cs] == [r[1] for r in ref] and np.array_equal(gs, np.array([r[2] for r in ref]))
+        o = oracle_nid(s, bins, poses[1], want_hist=False)
+        parity.check_cost(ref[1][1], o["cost"])
+        parity.check_grad(ref[1][2], o["grad"])
+        old.close()
+        new.close()
+
+
 def test_submit_wait_matches_synchronous_evaluation():
     """nidreg_submit / nidreg_wait (round 4): up to eight evaluations of a handle in flight, each into its own result block;
     collected in any order they equal the synchronous calls bit for bit (cost AND gradient: same kernels, same chunk table,
