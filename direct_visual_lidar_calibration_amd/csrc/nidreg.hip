@@ -1506,12 +1506,17 @@ int group_eval(MultiGroup* g, const double* se3, bool want_grad, double* costs, 
   } else {
     HIP_TRY(launch_spline_hist<double>(a));
   }
-  // entropy: NEB workgroups per pair
-  hipLaunchKernelGGL(
-    k_entropy<true>, dim3(h0->NEB * n), dim3(kEntropyThreads), 0, g->stream, static_cast<u64*>(nullptr), h0->bins, kEntropyCols, 0.0, static_cast<long long*>(nullptr),
-    static_cast<u64*>(nullptr), static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<EntropyScalars*>(nullptr), static_cast<double*>(nullptr),
-    static_cast<double*>(nullptr), 0.0, static_cast<unsigned int*>(nullptr), static_cast<u64*>(nullptr), 0ll, 1, static_cast<const MultiEntry*>(g->d_table), a.dyn);
-  HIP_TRY(hipGetLastError());
+  // entropy: NEB workgroups per pair -- none for small tables when every pair has gradient workgroups (they sum the table
+  // themselves and clear the next evaluation's buffers, grad_sums_table)
+  bool no_entropy_kernel = want_grad && grad_sums_table(h0);
+  for (int i = 0; i < n && no_entropy_kernel; i++) no_entropy_kernel = g->hs[size_t(i)]->num_points > 0 && g->hs[size_t(i)]->own_hist;
+  if (!no_entropy_kernel) {
+    hipLaunchKernelGGL(
+      k_entropy<true>, dim3(h0->NEB * n), dim3(kEntropyThreads), 0, g->stream, static_cast<u64*>(nullptr), h0->bins, kEntropyCols, 0.0, static_cast<long long*>(nullptr),
+      static_cast<u64*>(nullptr), static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<EntropyScalars*>(nullptr), static_cast<double*>(nullptr),
+      static_cast<double*>(nullptr), 0.0, static_cast<unsigned int*>(nullptr), static_cast<u64*>(nullptr), 0ll, 1, static_cast<const MultiEntry*>(g->d_table), a.dyn);
+    HIP_TRY(hipGetLastError());
+  }
   for (int i = 0; i < n; i++) g->hs[size_t(i)]->hist_zeroed[g->hs[size_t(i)]->hist_cur ^ 1] = true;
   // pass B (k_entropy<true> ran without its tail for every pair that has gradient workgroups: they run it)
   if (want_grad) {
@@ -1519,7 +1524,7 @@ int group_eval(MultiGroup* g, const double* se3, bool want_grad, double* costs, 
     a.nchunks = g->nchunks;
     a.seg = g->seg;
     a.lds_grad = g->lds_grad;
-    a.gt_from_partials = 1;
+    a.gt_from_partials = no_entropy_kernel ? 2 : 1;
     if (h0->precision == NIDREG_PREC_FP32) {
       HIP_TRY(launch_spline_grad<float>(a));
     } else {

@@ -1026,6 +1026,24 @@ def test_small_tables_need_no_entropy_kernel(monkeypatch):
         parity.check_grad(ref[1][2], o["grad"])
         old.close()
         new.close()
+    # several pairs as ONE grid (nidreg_eval_multi): the same two launches, every pair's first workgroup publishes its own cost
+    scenes = [scene_for("plumb_bob", n=n, seed=90 + k) for k, n in enumerate((50_000, 20_000, 35_000))]
+    for bins in (16, 33):
+        singles = [nid.NIDCost(proj, sc.image_f64, sc.points, sc.intensities, bins) for sc in scenes]
+        multi = nid.MultiNIDCost(None)
+        for c in singles:
+            multi.add(c)
+        for x in poses[:3]:
+            parts = [c(x) for c in singles]
+            ok, c, g = multi(x)
+            tot = 0.0
+            for p in parts:
+                tot += p[1]
+            assert ok and c == tot and np.allclose(g, np.sum([p[2] for p in parts], axis=0), rtol=1e-11, atol=1e-14), (bins, c, tot)
+            okc, cc, _ = multi(x, want_grad=False)
+            assert okc and cc == tot
+        for c in singles:
+            c.close()
 
 
 def test_submit_wait_matches_synchronous_evaluation():
