@@ -209,6 +209,83 @@ void drop_groups_of(const nidreg_handle* h);
 void cohort_leave(nidreg_handle* h);
 std::atomic<int> g_inflight[NIDREG_MAX_DEVICES];  // evaluations in flight per device (InflightGuard below)
 
+// ---- streams and host-mapped result blocks are kept between handles ---------------------------------------------------------
+// The reference builds a new NIDCost per pair in every outer iteration (visual_camera_calibration.cpp:199-208).  Creating and
+// destroying a handle for a 100k-point cloud took 0.98 ms, of which hipStreamCreate + hipStreamDestroy 0.5 + 0.4 ms and
+// hipHostFree 0.2 ms (rocprofv3 --hip-trace, profiles/r04m_hip_api_stats.csv) -- thirty evaluations' worth.  A destroyed
+// handle's stream (idle: free_handle synchronises it) and result blocks go to a per-device free list and the next handle on
+// that device takes them; nidreg_trim() releases them.
+struct ResourcePool {
+  std::mutex mu;
+  std::vector<hipStream_t> streams;
+  std::vector<void*> out_blocks;   // NIDREG_OUT_DOUBLES doubles, mapped + coherent
+  std::vector<void*> ring_blocks;  // kAsyncDepth of them
+};
+ResourcePool g_pool[NIDREG_MAX_DEVICES];
+constexpr size_t kPoolCap = 64;
+
+hipError_t pool_stream(int device, hipStream_t* out) {
+  if (device >= 0 && device < NIDREG_MAX_DEVICES) {
+    std::lock_guard<std::mutex> lk(g_pool[device].mu);
+    if (!g_pool[device].streams.empty()) {
+      *out = g_pool[device].streams.back();
+      g_pool[device].streams.pop_back();
+      return hipSuccess;
+    }
+  }
+  return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+// (the stream must be idle)
+void unpool_stream(int device, hipStream_t s) {
+  if (!s) return;
+  if (device >= 0 && device < NIDREG_MAX_DEVICES) {
+    std::lock_guard<std::mutex> lk(g_pool[device].mu);
+    if (g_pool[device].streams.size() < kPoolCap) {
+      g_pool[device].streams.push_back(s);
+      return;
+    }
+  }
+  (void)hipStreamDestroy(s);
+}
+hipError_t pool_host_block(int device, bool ring, size_t bytes, void** out) {
+  if (device >= 0 && device < NIDREG_MAX_DEVICES) {
+    std::lock_guard<std::mutex> lk(g_pool[device].mu);
+    std::vector<void*>& v = ring ? g_pool[device].ring_blocks : g_pool[device].out_blocks;
+    if (!v.empty()) {
+      *out = v.back();
+      v.pop_back();
+      return hipSuccess;
+    }
+  }
+  return hipHostMalloc(out, bytes, hipHostMallocMapped | hipHostMallocCoherent);
+}
+// (no kernel that writes the block may still be running)
+void unpool_host_block(int device, bool ring, void* p) {
+  if (!p) return;
+  if (device >= 0 && device < NIDREG_MAX_DEVICES) {
+    std::lock_guard<std::mutex> lk(g_pool[device].mu);
+    std::vector<void*>& v = ring ? g_pool[device].ring_blocks : g_pool[device].out_blocks;
+    if (v.size() < kPoolCap) {
+      v.push_back(p);
+      return;
+    }
+  }
+  (void)hipHostFree(p);
+}
+void pool_release(int device) {
+  std::vector<hipStream_t> streams;
+  std::vector<void*> blocks;
+  {
+    std::lock_guard<std::mutex> lk(g_pool[device].mu);
+    streams.swap(g_pool[device].streams);
+    blocks.swap(g_pool[device].out_blocks);
+    blocks.insert(blocks.end(), g_pool[device].ring_blocks.begin(), g_pool[device].ring_blocks.end());
+    g_pool[device].ring_blocks.clear();
+  }
+  for (hipStream_t st : streams) (void)hipStreamDestroy(st);
+  for (void* b : blocks) (void)hipHostFree(b);
+}
+
 void free_handle(nidreg_handle* h) {
   if (!h) return;
   if (h->set) {
@@ -233,11 +310,12 @@ void free_handle(nidreg_handle* h) {
   if (h->d_shard_tab) (void)hipFree(h->d_shard_tab);
   if (h->own_out && h->d_out) (void)hipFree(h->d_out);
   if (h->d_scratch) (void)hipFree(h->d_scratch);
-  if (h->h_out) (void)hipHostFree(h->h_out);
-  if (h->h_ring) (void)hipHostFree(h->h_ring);
+  // (a multi-pair group that evaluated this handle on its own stream was drained and freed by drop_groups_of above)
+  unpool_host_block(h->device, false, h->h_out);
+  unpool_host_block(h->device, true, h->h_ring);
   for (int i = 0; i < 6; i++)
     if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
-  if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+  if (h->own_stream && h->stream) unpool_stream(h->device, h->stream);
   delete h;
 }
 
@@ -1094,7 +1172,7 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
   if (d->ext_stream || (d->flags & NIDREG_FLAG_EXT_STREAM)) {
     h->stream = static_cast<hipStream_t>(d->ext_stream);
   } else {
-    CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CREATE_TRY(pool_stream(h->device, &h->stream));
     h->own_stream = true;
   }
   if (d->ext_hist) {
@@ -1145,7 +1223,11 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
     h->d_partials = reinterpret_cast<double*>(base + o_partials);
     h->d_counters = reinterpret_cast<unsigned int*>(base + o_counters);
   }
-  CREATE_TRY(hipHostMalloc(&h->h_out, NIDREG_OUT_DOUBLES * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+  {
+    void* blk = nullptr;
+    CREATE_TRY(pool_host_block(h->device, false, NIDREG_OUT_DOUBLES * sizeof(double), &blk));
+    h->h_out = static_cast<double*>(blk);
+  }
   std::memset(h->h_out, 0, NIDREG_OUT_DOUBLES * sizeof(double));
   if (!d->ext_out) {
     // results are written straight into host-mapped memory by the finalising workgroups: no D2H copy
@@ -1196,7 +1278,7 @@ void free_group(MultiGroup* g) {
   if (g->d_table) (void)hipFree(g->d_table);
   if (g->d_chunks) (void)hipFree(g->d_chunks);
   if (g->d_chunks_hist) (void)hipFree(g->d_chunks_hist);
-  if (g->stream) (void)hipStreamDestroy(g->stream);
+  if (g->stream) unpool_stream(g->device, g->stream);  // (synchronised above)
   delete g;
 }
 // called by free_handle: a group dies with any of its members
@@ -1439,7 +1521,7 @@ MultiGroup* find_or_make_group(nidreg_handle* const* handles, int n) {
   for (int i = 0; i < n; i++) chunks.insert(chunks.end(), pair_grad[size_t(i)].begin(), pair_grad[size_t(i)].end());
   for (int i = 0; i < n; i++) wide_chunks.insert(wide_chunks.end(), pair_hist[size_t(i)].begin(), pair_hist[size_t(i)].end());
   hipError_t err = hipSetDevice(g->device);
-  if (err == hipSuccess) err = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
+  if (err == hipSuccess) err = pool_stream(g->device, &g->stream);
   if (err == hipSuccess) err = hipMalloc(&g->d_table, table.size() * sizeof(MultiEntry));
   if (err == hipSuccess) err = hipMemcpy(g->d_table, table.data(), table.size() * sizeof(MultiEntry), hipMemcpyHostToDevice);
   if (err == hipSuccess) err = hipMalloc(&g->d_chunks, std::max<size_t>(chunks.size(), 1) * sizeof(Chunk));
@@ -2322,7 +2404,11 @@ static int async_submit(nidreg_handle* h, int mode, const double* pose, bool wan
   cohort_check(h);
   HIP_TRY(hipSetDevice(h->device));
   if (!h->h_ring) {
-    HIP_TRY(hipHostMalloc(&h->h_ring, size_t(kAsyncDepth) * NIDREG_OUT_DOUBLES * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+    {
+      void* blk = nullptr;
+      HIP_TRY(pool_host_block(h->device, true, size_t(kAsyncDepth) * NIDREG_OUT_DOUBLES * sizeof(double), &blk));
+      h->h_ring = static_cast<double*>(blk);
+    }
     std::memset(h->h_ring, 0, size_t(kAsyncDepth) * NIDREG_OUT_DOUBLES * sizeof(double));
     void* dp = nullptr;
     HIP_TRY(hipHostGetDevicePointer(&dp, h->h_ring, 0));
@@ -2764,6 +2850,7 @@ void nidreg_trim(void) {
     std::lock_guard<ScratchArena> guard(a);
     (void)hipSetDevice(dev);
     a.release();
+    if (dev < NIDREG_MAX_DEVICES) pool_release(dev);
   }
   (void)hipSetDevice(cur);
 }

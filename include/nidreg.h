@@ -288,7 +288,9 @@ int nidreg_shard_finish(nidreg_handle* h, double* cost, double* grad7);
 int nidreg_num_shards(nidreg_handle* h);
 int nidreg_shard_devices(nidreg_handle* h, int* device_ids, int capacity);
 
-/* release the per-device scratch arenas that handle construction keeps between calls (upload staging, sort keys) */
+/* release what the library keeps per device between handles: the scratch arenas of handle construction (upload staging, sort
+ * keys) and the streams / host-mapped result blocks of destroyed handles (the next handle takes them: the reference builds new
+ * cost objects in every outer iteration, visual_camera_calibration.cpp:199-208) */
 void nidreg_trim(void);
 
 /* device-side timing of the most recent nidreg_eval / nidreg_eval_iso in milliseconds (HIP events

@@ -992,6 +992,71 @@ def test_chunks_across_column_groups_match_one_group_per_chunk(model, monkeypatc
         calc.close()
 
 
+def test_destroyed_handles_leave_their_stream_and_result_blocks_to_the_next():
+    """The reference builds a new NIDCost per pair in every outer iteration (visual_camera_calibration.cpp:199-208): a destroyed
+    handle's stream and host-mapped result blocks are kept for the next handle on the device (nidreg.hip ResourcePool; creating
+    them anew cost 0.9 of the 1.0 ms a small handle took).  A recycled block must not leak its previous owner's results or
+    completion tags: handles of different clouds and bin counts created, evaluated (synchronously, through submit / wait and as
+    a multi-pair grid) and destroyed in an interleaved order give what fresh handles gave; nidreg_trim() empties the lists."""
+    from direct_visual_lidar_calibration_amd import _lib
+
+    lib = _lib.load()
+    scenes = [scene_for("plumb_bob", n=n, seed=300 + k) for k, n in enumerate((20_000, 33_000, 26_000))]
+    proj = nid.create_camera(scenes[0].model, scenes[0].intrinsics, scenes[0].distortion)
+    rng = np.random.default_rng(21)
+    poses = [synth.random_pose_near(scenes[0].T_camera_lidar_true, rng) for _ in range(6)]
+
+    def make(k, bins):
+        sc = scenes[k]
+        return nid.NIDCost(proj, sc.image_f64, sc.points, sc.intensities, bins)
+
+    lib.nidreg_trim()
+    ref = {}
+    for k in range(3):
+        for bins in (16, 256):
+            c = make(k, bins)
+            ref[k, bins] = [c(x) for x in poses]
+            c.close()
+            lib.nidreg_trim()  # every reference handle gets a new stream and new blocks
+    live = []
+    for rnd in range(4):
+        for k in range(3):
+            for bins in (16, 256):
+                c = make(k, bins)  # (from the second handle on: a recycled stream, recycled blocks)
+                j = (rnd + k) % len(poses)
+                if rnd % 2:
+                    t = [c.submit(poses[(j + i) % len(poses)]) for i in range(3)]
+                    got = [c.wait(tk) for tk in t]
+                    want = [ref[k, bins][(j + i) % len(poses)] for i in range(3)]
+                else:
+                    got, want = [c(poses[j])], [ref[k, bins][j]]
+                for a, b in zip(got, want):
+                    assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2]), (rnd, k, bins)
+                live.append((k, bins, c))
+                if len(live) > 2:  # destroyed out of creation order, two handles always alive
+                    kk, bb, old = live.pop(0)
+                    ok, cc, gg = old(poses[0])
+                    assert cc == ref[kk, bb][0][1]
+                    old.close()
+        multi = nid.MultiNIDCost(None)
+        group = [make(k, 256) for k in range(3)]
+        for c in group:
+            multi.add(c)
+        ok, cm, gm = multi(poses[rnd])
+        tot = 0.0
+        for k in range(3):
+            tot += ref[k, 256][rnd][1]
+        assert ok and cm == tot
+        for c in group:
+            c.close()
+    for _, _, c in live:
+        c.close()
+    lib.nidreg_trim()
+    c = make(0, 16)
+    assert c(poses[1])[1] == ref[0, 16][1][1]
+    c.close()
+
+
 def test_small_tables_need_no_entropy_kernel(monkeypatch):
     """bins <= 32 (the reference's default is 16): a cost+Jacobian evaluation launches two kernels -- every gradient workgroup
     sums the B x B table itself and clears the next evaluation's buffer (nid_kernels.hpp kSelfEntropyCells).  The sums are
