@@ -1275,6 +1275,8 @@ void release_group(MultiGroup* g) { g->users.fetch_sub(1, std::memory_order_acq_
 void free_group(MultiGroup* g) {
   (void)hipSetDevice(g->device);
   if (g->stream) (void)hipStreamSynchronize(g->stream);
+  for (nidreg_handle* m : g->hs)  // (ADVICE r3 made the getters drain the stream of the last evaluation: never a freed group's)
+    if (m->last_stream == g->stream) m->last_stream = m->stream;
   if (g->d_table) (void)hipFree(g->d_table);
   if (g->d_chunks) (void)hipFree(g->d_chunks);
   if (g->d_chunks_hist) (void)hipFree(g->d_chunks_hist);
