@@ -55,9 +55,15 @@ __device__ __forceinline__ void stamp_begin() {
 __device__ __forceinline__ void stamp_end() {
   if (threadIdx.x == 0) g_stamp[4 * blockIdx.x + 1] = wall_clock64();
 }
+// stage stamps of one workgroup (tools/stage_times.py): slot i of workgroup b = g_stage[8 b + i]
+__device__ unsigned long long g_stage[8 * 8192];
+__device__ __forceinline__ void stamp_stage(int i) {
+  if (threadIdx.x == 0 && blockIdx.x < 8192) g_stage[8 * blockIdx.x + i] = wall_clock64();
+}
 #else
 __device__ __forceinline__ void stamp_begin() {}
 __device__ __forceinline__ void stamp_end() {}
+__device__ __forceinline__ void stamp_stage(int) {}
 #endif
 
 // Sum over the 64 lanes of a wave, returned to every lane.  Cross-lane moves by DPP (v_mov_b32_dpp on the two halves of
@@ -216,13 +222,11 @@ __device__ __forceinline__ void grad_final_body(const double* partials, int nblo
     for (int k = 0; k < 7; k++) out[1 + k] = g[k];
     if (out_host) {
       for (int k = 0; k < 7; k++) out_host[1 + k] = g[k];
-      // cost / status / inlier count: k_entropy's own tail has mirrored them already; when the gradient kernel runs the tail
-      // (grad_scalars_from_partials) another workgroup of THIS kernel wrote them to `out` (agent scope, before its ticket)
-      // and this is their way to the host --
-      // every host-visible word of an evaluation is then written by one thread, in order, ahead of the tag
-      out_host[0] = __hip_atomic_load(&out[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      out_host[8] = __hip_atomic_load(&out[8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      out_host[9] = __hip_atomic_load(&out[9], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // cost / status / inlier count are in host memory already: written by whoever ran the entropy tail -- k_entropy's last
+      // workgroup in an earlier kernel, or the pair's first workgroup of THIS kernel (grad_scalars_from_partials), whose
+      // thread 0 waited for those stores (s_waitcnt vmcnt(0)) before it took its ticket; the ticket this workgroup drew
+      // last is ordered behind all of them.  (Until round 4 this thread re-read the three words from `out` at agent scope
+      // and mirrored them: one more dependent round trip in the 3 us this tail takes.)
       __threadfence_system();
       // completion tag of this evaluation: the host polls this word instead of synchronising the stream
       __hip_atomic_store(&out_host[15], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -369,6 +373,7 @@ __device__ __forceinline__ void spline_hist_body(
 
   const int tid = threadIdx.x;
   stamp_begin();
+  stamp_stage(0);
   if (tid == 0) *s_inl = 0;
 
   const real fW = real(W), fH = real(H);
@@ -387,6 +392,7 @@ __device__ __forceinline__ void spline_hist_body(
     for (int k = tid; k < tile_w; k += kT) tile[k] = 0;
     if (tid < GW) s_colsum[tid] = 0;
     __syncthreads();
+    stamp_stage(1);
     const uint32_t seg_end = SEG ? seg.seg_end() : seg.end;
     const uint32_t cnt = seg_end - seg.pos;  // >= 1
     const uint32_t col0 = seg.g * uint32_t(GW);
@@ -486,6 +492,7 @@ __device__ __forceinline__ void spline_hist_body(
     for (uint32_t base = 0; base < cnt; base += kT * kUnroll) batch(base, std::true_type());
 #endif
     __syncthreads();
+    stamp_stage(2);
 
     // flush the tile: contiguous in the [bin_points][bin_image] device layout
     u64* dst = hist + size_t(seg.g) * size_t(tile_n);
@@ -508,6 +515,7 @@ __device__ __forceinline__ void spline_hist_body(
   if ((tid & 63) == 0 && winl) atomicAdd(s_inl, winl);
   __syncthreads();
   if (tid == 0 && *s_inl) atomicAdd(&hist[size_t(B) * size_t(B) + kTailInliers], u64(*s_inl));
+  stamp_stage(3);
   stamp_end();
 }
 
@@ -1272,7 +1280,7 @@ __device__ __forceinline__ void grad_entropy_partials(const u64* __restrict__ hi
 // workgroup per pair) publishes hist_image / hist_points / phi_q / scal and -- at agent scope, read by grad_final_body in
 // another workgroup -- cost, status and inlier count.  s_redk: 3 * (kT / 64) words of LDS.
 template <int kT, bool SELF>
-__device__ __forceinline__ EntropyScalars grad_scalars_from_partials(const u64* hist, int B, double inv_unit, const GradTail& gt, double* s_phi, long long* s_redk, bool writer, double* out) {
+__device__ __forceinline__ EntropyScalars grad_scalars_from_partials(const u64* hist, int B, double inv_unit, const GradTail& gt, double* s_phi, long long* s_redk, bool writer, double* out, double* out_host) {
   const int tid = threadIdx.x;
   const double S = double(hist[size_t(B) * size_t(B) + kTailInliers]);
   const u64* col_sum = hist + size_t(B) * size_t(B) + kTailWords;
@@ -1322,6 +1330,11 @@ __device__ __forceinline__ EntropyScalars grad_scalars_from_partials(const u64* 
     __hip_atomic_store(&out[0], e.nid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&out[8], e.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&out[9], S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (out_host) {  // (see grad_final_body: this thread's ticket is taken after these stores have completed)
+      out_host[0] = e.nid;
+      out_host[8] = e.status;
+      out_host[9] = S;
+    }
   }
   return e;
 }
@@ -1368,6 +1381,7 @@ __global__ __launch_bounds__(kThreads, grad_min_waves(MODEL, SEG, sizeof(Rec) ==
   double* s_stage = reinterpret_cast<double*>(s_flag + 4);  // SEG: [kMaxSegs - 1][B] G columns of the chunk's later segments
 
   const int tid = threadIdx.x;
+  stamp_stage(0);
   const Chunk ch = chunks[blockIdx.x];
   unsigned int my_block = blockIdx.x, my_blocks = gridDim.x;
   if constexpr (MULTI) {
@@ -1408,18 +1422,22 @@ __global__ __launch_bounds__(kThreads, grad_min_waves(MODEL, SEG, sizeof(Rec) ==
         }
         if (zero_buf)
           for (long long k = (long long)my_block * kThreads + tid; k < zero_words; k += (long long)my_blocks * kThreads) zero_buf[k] = 0;
-        const EntropyScalars es = grad_scalars_from_partials<kThreads, true>(hist, B, inv_unit, gt, s_phi, reinterpret_cast<long long*>(s_red), my_block == 0, out);
+        // (Requesting everything the three prologue steps read -- the cells, S, the column sums, the G tile's cells -- at
+        // entry, in one round trip, changed nothing: stage stamps 2.8 + 0.9 us before, 3.4 + 0.2 us after.  The prologue is a
+        // chain of dependent fp64 logarithms / divisions at one wave per SIMD, not of loads; profiles/r04n_stage_times*.json.)
+        const EntropyScalars es = grad_scalars_from_partials<kThreads, true>(hist, B, inv_unit, gt, s_phi, reinterpret_cast<long long*>(s_red), my_block == 0, out, out_host);
         coefA = es.coefA, coefB = es.coefB, S = es.S;
         phi_q = s_phi;
       }
     } else if (gt.from_partials) {
-      const EntropyScalars es = grad_scalars_from_partials<kThreads, false>(hist, B, inv_unit, gt, s_phi, reinterpret_cast<long long*>(s_red), my_block == 0, out);
+      const EntropyScalars es = grad_scalars_from_partials<kThreads, false>(hist, B, inv_unit, gt, s_phi, reinterpret_cast<long long*>(s_red), my_block == 0, out, out_host);
       coefA = es.coefA, coefB = es.coefB, S = es.S;
       phi_q = s_phi;  // LDS through a generic pointer: B reads per tile
     } else {
       coefA = scal->coefA, coefB = scal->coefB, S = scal->S;
     }
     const double scale = inv_unit / S;
+    stamp_stage(1);
     // The G column(s) of EVERY segment of the chunk are built here, before the point loops: the first one in place, the others
     // into the staging area, from where a boundary costs one LDS copy.  (Rebuilding inside the segment loop let the compiler
     // hoist the logarithm's constants out of that loop and keep them through the point loop: 167 VGPRs; a call that is not
@@ -1431,6 +1449,7 @@ __global__ __launch_bounds__(kThreads, grad_min_waves(MODEL, SEG, sizeof(Rec) ==
     }
   }
   __syncthreads();
+  stamp_stage(2);
 
   // One 12-double partial PER SEGMENT (slot = the chunk's first slot, Chunk::pad >> 8, + the segment's ordinal): the final
   // reduction sums the slots in table order -- a fixed order, run to run.
@@ -1447,7 +1466,9 @@ __global__ __launch_bounds__(kThreads, grad_min_waves(MODEL, SEG, sizeof(Rec) ==
     const uint32_t seg_end = SEG ? seg.seg_end() : seg.end;
     spline_grad_loop<MODEL, Rec, real, GW1 ? TAP_SINGLE : TAP_COPIES, kThreads, !SEG>(pts + seg.pos, seg_end - seg.pos, seg.g * uint32_t(GW), seg.pos - ch.start, ch.count, img, pitch, W, H, pose,
                                                                                cam, B, cshift, gtile, acc, prio != 0);
+    stamp_stage(3);
     grad_reduce_store<kThreads>(acc, s_red, partials, slot, nslots);
+    stamp_stage(4);
     if (!SEG || !seg.advance(seg_end)) break;
     slot++;
     drain_vmem();
@@ -1455,7 +1476,12 @@ __global__ __launch_bounds__(kThreads, grad_min_waves(MODEL, SEG, sizeof(Rec) ==
     for (int k = tid; k < B; k += kThreads) gtile[k] = s_stage[s * B + k];
     __syncthreads();
   }
-  if (last_workgroup_arrives<true>(counter, my_blocks, s_flag)) grad_final_body<kThreads>(partials, int(nslots), qx, qy, qz, qw, out, out_host, tag, s_red);
+  const bool last = last_workgroup_arrives<true>(counter, my_blocks, s_flag);
+  stamp_stage(5);
+  if (last) {
+    grad_final_body<kThreads>(partials, int(nslots), qx, qy, qz, qw, out, out_host, tag, s_red);
+    stamp_stage(6);
+  }
 }
 
 #ifdef NID_COMMON_KERNELS

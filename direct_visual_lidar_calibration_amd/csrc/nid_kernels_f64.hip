@@ -28,3 +28,13 @@ template <> hipError_t launch_project<double>(int model, const double* intr, con
 
 }  // namespace nidreg
 
+
+#ifdef NID_STAMP
+// development aid (tools/stage_times.py, an instrumented build loaded through NIDREG_LIB): the stage stamps of the last launch
+extern "C" int nidreg_debug_stage_stamps(unsigned long long* out, int words) {
+  return int(hipMemcpyFromSymbol(out, HIP_SYMBOL(nidreg::g_stage), size_t(words) * sizeof(unsigned long long)));
+}
+extern "C" int nidreg_debug_wg_stamps(unsigned long long* out, int words) {
+  return int(hipMemcpyFromSymbol(out, HIP_SYMBOL(nidreg::g_stamp), size_t(words) * sizeof(unsigned long long)));
+}
+#endif
