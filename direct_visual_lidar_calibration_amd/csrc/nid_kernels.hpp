@@ -222,11 +222,17 @@ __device__ __forceinline__ void grad_final_body(const double* partials, int nblo
     for (int k = 0; k < 7; k++) out[1 + k] = g[k];
     if (out_host) {
       for (int k = 0; k < 7; k++) out_host[1 + k] = g[k];
-      // cost / status / inlier count are in host memory already: written by whoever ran the entropy tail -- k_entropy's last
-      // workgroup in an earlier kernel, or the pair's first workgroup of THIS kernel (grad_scalars_from_partials), whose
-      // thread 0 waited for those stores (s_waitcnt vmcnt(0)) before it took its ticket; the ticket this workgroup drew
-      // last is ordered behind all of them.  (Until round 4 this thread re-read the three words from `out` at agent scope
-      // and mirrored them: one more dependent round trip in the 3 us this tail takes.)
+      // cost / status / inlier count: k_entropy's own tail has mirrored them already; when the gradient kernel runs the tail
+      // (grad_scalars_from_partials) another workgroup of THIS kernel wrote them to `out` (agent scope, before its ticket)
+      // and this is their way to the host --
+      // every host-visible word of an evaluation is then written by ONE thread, in order, ahead of the tag.  (Round 4 let the
+      // pair's first workgroup write the three words to the host itself, ahead of its ticket, to save this dependent round
+      // trip -- 3.0 -> 2.7 us for the final stage: with five callers on the GPU a host saw the tag BEFORE the cost once in a
+      // full suite -- test_concurrent_callers, the previous pose's cost.  Writes of different workgroups (different XCDs) to
+      // one host block are not ordered on their way to the host by the writer's s_waitcnt + the ticket.  Reverted.)
+      out_host[0] = __hip_atomic_load(&out[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      out_host[8] = __hip_atomic_load(&out[8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      out_host[9] = __hip_atomic_load(&out[9], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __threadfence_system();
       // completion tag of this evaluation: the host polls this word instead of synchronising the stream
       __hip_atomic_store(&out_host[15], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1280,7 +1286,7 @@ __device__ __forceinline__ void grad_entropy_partials(const u64* __restrict__ hi
 // workgroup per pair) publishes hist_image / hist_points / phi_q / scal and -- at agent scope, read by grad_final_body in
 // another workgroup -- cost, status and inlier count.  s_redk: 3 * (kT / 64) words of LDS.
 template <int kT, bool SELF>
-__device__ __forceinline__ EntropyScalars grad_scalars_from_partials(const u64* hist, int B, double inv_unit, const GradTail& gt, double* s_phi, long long* s_redk, bool writer, double* out, double* out_host) {
+__device__ __forceinline__ EntropyScalars grad_scalars_from_partials(const u64* hist, int B, double inv_unit, const GradTail& gt, double* s_phi, long long* s_redk, bool writer, double* out) {
   const int tid = threadIdx.x;
   const double S = double(hist[size_t(B) * size_t(B) + kTailInliers]);
   const u64* col_sum = hist + size_t(B) * size_t(B) + kTailWords;
@@ -1330,11 +1336,6 @@ __device__ __forceinline__ EntropyScalars grad_scalars_from_partials(const u64* 
     __hip_atomic_store(&out[0], e.nid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&out[8], e.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&out[9], S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (out_host) {  // (see grad_final_body: this thread's ticket is taken after these stores have completed)
-      out_host[0] = e.nid;
-      out_host[8] = e.status;
-      out_host[9] = S;
-    }
   }
   return e;
 }
@@ -1425,12 +1426,12 @@ __global__ __launch_bounds__(kThreads, grad_min_waves(MODEL, SEG, sizeof(Rec) ==
         // (Requesting everything the three prologue steps read -- the cells, S, the column sums, the G tile's cells -- at
         // entry, in one round trip, changed nothing: stage stamps 2.8 + 0.9 us before, 3.4 + 0.2 us after.  The prologue is a
         // chain of dependent fp64 logarithms / divisions at one wave per SIMD, not of loads; profiles/r04n_stage_times*.json.)
-        const EntropyScalars es = grad_scalars_from_partials<kThreads, true>(hist, B, inv_unit, gt, s_phi, reinterpret_cast<long long*>(s_red), my_block == 0, out, out_host);
+        const EntropyScalars es = grad_scalars_from_partials<kThreads, true>(hist, B, inv_unit, gt, s_phi, reinterpret_cast<long long*>(s_red), my_block == 0, out);
         coefA = es.coefA, coefB = es.coefB, S = es.S;
         phi_q = s_phi;
       }
     } else if (gt.from_partials) {
-      const EntropyScalars es = grad_scalars_from_partials<kThreads, false>(hist, B, inv_unit, gt, s_phi, reinterpret_cast<long long*>(s_red), my_block == 0, out, out_host);
+      const EntropyScalars es = grad_scalars_from_partials<kThreads, false>(hist, B, inv_unit, gt, s_phi, reinterpret_cast<long long*>(s_red), my_block == 0, out);
       coefA = es.coefA, coefB = es.coefB, S = es.S;
       phi_q = s_phi;  // LDS through a generic pointer: B reads per tile
     } else {
