@@ -42,6 +42,6 @@ echo "== cohort trace"
 python tools/dump_scene_raw.py /tmp/scene.npz /tmp/scene.raw > /dev/null
 for K in 2 8; do NIDREG_COHORT_TRACE=1 NIDREG_COHORT=1 OMP_WAIT_POLICY=active timeout 60 tools/omp_pairs.bin 10000000 120 /tmp/scene.raw $K 2>&1 | tee -a $O/cohort_trace.txt; done
 el "end"
-echo "== concurrency tests, five more times"
-for i in 1 2 3 4 5; do timeout 300 python -m pytest tests/test_concurrent_callers.py tests/test_sharded_concurrent.py -q -m gpu -p no:cacheprovider 2>&1 | tail -n 1; done | tee $O/concurrency_repeats.txt
+echo "== concurrent callers, four more times"
+for i in 1 2 3 4; do timeout 300 python -m pytest tests/test_concurrent_callers.py -q -m gpu -p no:cacheprovider 2>&1 | tail -n 1; done | tee $O/concurrency_repeats.txt
 el "repeats done"
