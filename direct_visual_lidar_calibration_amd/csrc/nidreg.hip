@@ -272,6 +272,15 @@ void unpool_host_block(int device, bool ring, void* p) {
   }
   (void)hipHostFree(p);
 }
+// staging of nidreg_project for a handful of points: [3 n | 2 n | 6 n] doubles, host-mapped, one block per device
+constexpr int64_t kSmallProject = 64;
+struct SmallProject {
+  std::mutex mu;
+  double* host = nullptr;
+  double* dev = nullptr;
+};
+SmallProject g_small_project[NIDREG_MAX_DEVICES];
+
 void pool_release(int device) {
   std::vector<hipStream_t> streams;
   std::vector<void*> blocks;
@@ -284,6 +293,10 @@ void pool_release(int device) {
   }
   for (hipStream_t st : streams) (void)hipStreamDestroy(st);
   for (void* b : blocks) (void)hipHostFree(b);
+  SmallProject& sp = g_small_project[device];
+  std::lock_guard<std::mutex> lk(sp.mu);
+  if (sp.host) (void)hipHostFree(sp.host);
+  sp.host = sp.dev = nullptr;
 }
 
 void free_handle(nidreg_handle* h) {
@@ -2677,6 +2690,35 @@ int nidreg_project(nidreg_handle* h, const double* p3, int64_t n, double* uv, do
   if (!h || !p3 || !uv || n < 0) return fail(NIDREG_ERR_INVALID, "nidreg_project: bad argument");
   if (n == 0) return NIDREG_OK;
   HIP_TRY(hipSetDevice(h->device));
+  if (n <= kSmallProject && h->device >= 0 && h->device < NIDREG_MAX_DEVICES) {
+    // A handful of points (estimate_camera_fov inverts the projection at three pixels with NelderMead<2>: ~240 calls of ONE
+    // point, src/vlcal/common/estimate_fov.cpp:17-51): the same kernel on a host-mapped staging block kept per device -- no
+    // hipMalloc / hipMemcpy / hipFree per call (60 -> ~15 us; those calls were 16 of the 24 ms a whole configs[0] calibration
+    // took, profiles/r04q_profile_1bag_bfgs.txt).
+    SmallProject& sp = g_small_project[h->device];
+    std::lock_guard<std::mutex> lk(sp.mu);
+    if (!sp.host) {
+      void* blk = nullptr;
+      HIP_TRY(hipHostMalloc(&blk, size_t(kSmallProject) * 11 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+      void* dp = nullptr;
+      hipError_t e0 = hipHostGetDevicePointer(&dp, blk, 0);
+      if (e0 != hipSuccess) {
+        (void)hipHostFree(blk);
+        return fail(NIDREG_ERR_HIP, std::string("nidreg_project: ") + hipGetErrorString(e0));
+      }
+      sp.host = static_cast<double*>(blk);
+      sp.dev = static_cast<double*>(dp);
+    }
+    std::memcpy(sp.host, p3, size_t(n) * 3 * sizeof(double));
+    double* d_uv = sp.dev + 3 * kSmallProject;
+    double* d_j = jac ? sp.dev + 5 * kSmallProject : nullptr;
+    hipError_t e = h->precision == NIDREG_PREC_FP32 ? launch_project<float>(h->model, h->intr, h->dist, sp.dev, n, d_uv, d_j, h->stream) : launch_project<double>(h->model, h->intr, h->dist, sp.dev, n, d_uv, d_j, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) return fail(NIDREG_ERR_HIP, std::string("nidreg_project: ") + hipGetErrorString(e));
+    std::memcpy(uv, sp.host + 3 * kSmallProject, size_t(n) * 2 * sizeof(double));
+    if (jac) std::memcpy(jac, sp.host + 5 * kSmallProject, size_t(n) * 6 * sizeof(double));
+    return NIDREG_OK;
+  }
   double *d_p = nullptr, *d_uv = nullptr, *d_j = nullptr;
   hipError_t e = hipMalloc(&d_p, size_t(n) * 3 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&d_uv, size_t(n) * 2 * sizeof(double));

@@ -1,0 +1,63 @@
+"""BASELINE.json configs[0] end to end -- `calibrate <dir>` on a preprocessed directory of 100k-point bags, VGA pinhole, 16 bins:
+wall time of the whole calibration on the GPU engine against the same host driver on the CPU oracle (the reference's serial
+cost functors), and the final extrinsics within 1e-3 m / 1e-3 rad of each other.  Opt-in (the CPU side takes about a minute
+per case): NIDREG_TIME_TO_SOLUTION=1; writes gpurun_out/time_to_solution.json (committed as profiles/r04q_time_to_solution.json)."""
+import json
+import os
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(os.environ.get("NIDREG_TIME_TO_SOLUTION", "0") in ("", "0"), reason="opt-in: NIDREG_TIME_TO_SOLUTION=1 (about a minute of CPU oracle per case)")
+def test_configs0_time_to_solution(tmp_path):
+    import oracle_lib
+    from direct_visual_lidar_calibration_amd import calibrate, calibration, dataset, se3
+    from test_calibration import OracleNIDCost, OracleNearest, oracle_cull
+    from test_dataset import _write_synthetic_dir
+
+    out = {}
+    for label, bags_n, reg in (("1_bag_bfgs", 1, "nid_bfgs"), ("3_bags_bfgs", 3, "nid_bfgs"), ("1_bag_nelder_mead", 1, "nid_nelder_mead")):
+        d = str(tmp_path / label)
+        scenes, _ = _write_synthetic_dir(d, n=100_000, bags=bags_n, seed=61)
+        args = calibrate.build_parser().parse_args([d, "--registration_type", reg, "--auto_quit", "--background"])
+        gpu_s = []
+        for _ in range(3):  # the first run pays the process's first-use costs (code objects, scratch arenas)
+            t0 = time.perf_counter()
+            config, init_x, x_gpu = calibrate.run(args, log=lambda *_: None)
+            gpu_s.append(time.perf_counter() - t0)
+        _, bags = dataset.load_dataset(d)
+        s = scenes[0]
+        max_fov = oracle_lib.estimate_camera_fov(s.model, s.intrinsics, s.distortion, s.width, s.height)
+        p = calibration.VisualCameraCalibrationParams(nid_bins=16, registration_type=reg)
+        evals = {"nid": 0, "nearest": 0}
+
+        class CountedNID(OracleNIDCost):
+            def __call__(self, x, want_grad=True):
+                evals["nid"] += 1
+                return super().__call__(x, want_grad)
+
+        class CountedNearest(OracleNearest):
+            def calculate(self, T):
+                evals["nearest"] += 1
+                return super().calculate(T)
+
+        cal = calibration.VisualCameraCalibration(
+            [(b.image, b.points, b.intensities) for b in bags], p, nid_cost_factory=lambda i, pt, it, b: CountedNID(s, i, pt, it, b),
+            nearest_cost_factory=lambda i, pt, it, b: CountedNearest(s, i, pt, it, b, max_fov), cull=oracle_cull(s))
+        t0 = time.perf_counter()
+        x_ref = cal.calibrate(init_x)
+        cpu_s = time.perf_counter() - t0
+        dt, dr = se3.delta_trans_rot(x_ref, x_gpu)
+        dt0, dr0 = se3.delta_trans_rot(s.T_camera_lidar_true, init_x)
+        dt1, dr1 = se3.delta_trans_rot(s.T_camera_lidar_true, x_gpu)
+        out[label] = {"bags": bags_n, "points_per_bag": 100_000, "bins": 16, "registration_type": reg, "gpu_wall_s": [round(v, 4) for v in gpu_s], "cpu_oracle_wall_s": round(cpu_s, 2),
+                      "cpu_cost_evaluations": dict(evals), "speedup_second_run": round(cpu_s / gpu_s[1], 1), "delta_T_gpu_vs_cpu": [dt, dr], "error_vs_truth_before": [dt0, dr0],
+                      "error_vs_truth_after": [dt1, dr1]}
+        assert dt <= 1e-3 and dr <= 1e-3, (label, dt, dr)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "time_to_solution.json"), "w") as f:
+        json.dump(out, f, indent=1)
