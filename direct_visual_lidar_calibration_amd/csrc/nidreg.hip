@@ -1249,6 +1249,10 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
     h->d_out_host = static_cast<double*>(dp);
   }
   for (int i = 0; i < 6; i++) CREATE_TRY(hipEventCreate(&h->ev[i]));
+  // The clears above (result block, histogram buffers, scratch incl. the ticket counters) are hipMemset calls on the null
+  // stream, which return before they have run (2.9 us per call in the API trace, profiles/r04m_hip_api_stats.csv), and the
+  // handle's own stream is non-blocking: the first evaluation must not be able to overtake them.
+  CREATE_TRY(hipStreamSynchronize(nullptr));
 #undef CREATE_TRY
   *out = h;
   return NIDREG_OK;
