@@ -205,30 +205,46 @@ NID_HD double fast_rsq(double z) {
 }
 NID_HD float fast_rsq(float z) { return 1.0f / sqrtf(z); }
 
-// atan2 for the SPLINE kernels' fisheye / equirectangular projections.  Octant reduction to t in [0,1] with one fast
-// reciprocal, then a 257-entry table: atan(t) = atan(t0) + atan(d), t0 = round(256 t) / 256, d = (t - t0) / (1 + t t0),
-// |d| <= 1/512, atan(d) = d (1 - d^2/3 + d^4/5) (next term d^7/7 < 2e-20).  The table (nid_atan_table.hpp: correctly
-// rounded) is 2 KB and read through the vector L1, where it stays resident.  Against the 20-term polynomial of rounds
-// 1-2 (its coefficients had to be re-materialised with v_mov pairs inside the Horner chain, and the fisheye /
-// equirectangular gradient kernels held 154-161 VGPRs) this is ~7 fp64 and ~10 other VALU operations less per call and two
-// constants instead of twenty.  Max abs error 1.1e-16 with exact divisions (tools/gen_atan_table.py), ~1e-15 with the
-// one-Newton-step reciprocals (test_device_math).  atan2(0, 0) = 0 like libm (equirectangular.hpp:21 relies on it for
-// points on the vertical axis).
+// atan2 for the SPLINE kernels' fisheye / equirectangular projections: octant reduction to mn / mx in [0, 1], then a
+// 257-entry table (nid_atan_table.hpp: atan(i / 256) correctly rounded; 2 KB, read through the vector L1, where it stays
+// resident) and the addition theorem on the UN-DIVIDED pair,
+//   atan(mn / mx) = atan(t0) + atan(d),   d = (mn - t0 mx) / (mx + t0 mn),   t0 = i / 256 the table point next to mn / mx.
+// Round 5: ONE double-precision reciprocal per call instead of two.  Until round 4 the quotient t = mn / mx was formed first
+// (fast_rcp) and d = (t - t0) / (1 + t t0) needed a second one; but t is only used to PICK i -- any table point within 1/256
+// of it will do -- so a single-precision quotient (v_rcp_f32: 1 ulp) picks it, and the one remaining fp64 division acts on d,
+// which is <= 1/511: its 2^-46 relative error (one Newton step) is 3e-17 absolute in the angle, where the old form carried the
+// reciprocal's 1.4e-14 into t itself (7e-15 in the angle).  The numerator is ONE fma of exact operands (t0 has 9 significant
+// bits): rounded once.  atan(d) = d (1 - d^2/3 + d^4/5) (next term d^7/7 < 2e-20).  Max abs error 2.3e-16 on the host
+// (test_device_math).  atan2(0, 0) = 0 like libm (equirectangular.hpp:21 relies on it for points on the vertical axis): the
+// denominator is held above 1e-30 (lengths in metres; v_max_f64 returns the non-NaN operand, so a NaN reaches the result through the numerator).
 #if defined(__HIP_DEVICE_COMPILE__)
 static __device__ const double g_atan_tab[kAtanTableN + 1] = {NID_ATAN_TABLE_VALUES};
 #else
 static const double g_atan_tab[kAtanTableN + 1] = {NID_ATAN_TABLE_VALUES};
 #endif
+NID_HD float rcp_f32(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rcpf(x);
+#else
+  return 1.0f / x;
+#endif
+}
 NID_HD double fast_atan2(double y, double x) {
   const double ax = fabs(x), ay = fabs(y);
   const bool swap = ay > ax;
   const double mx = swap ? ay : ax, mn = swap ? ax : ay;  // NaN operands propagate (no maxNum semantics)
-  const double t = mn * fast_rcp(mx < 1e-30 ? 1e-30 : mx);  // 0/0 -> 0; a NaN mx stays NaN
-  const double ti = rint(t * double(kAtanTableN));
-  int i = int(ti);  // NaN -> 0 (v_cvt_i32_f64) / INT_MIN (x86): clamped below, the result is NaN through d either way
+  // table point: single precision is plenty (|256 t - i| <= 0.5 + 2^-15); 0/0, inf/inf, NaN -> some i in range after the clamp
+  const float ti = rintf((float(mn) * float(kAtanTableN)) * rcp_f32(float(mx)));
+#if defined(__HIP_DEVICE_COMPILE__)
+  int i = int(ti);  // NaN -> 0 (v_cvt_i32_f32): the result is NaN through `num`
+#else
+  int i = ti == ti ? int(ti) : 0;  // (a NaN conversion is undefined behaviour in the host build)
+#endif
   i = i < 0 ? 0 : (i > kAtanTableN ? kAtanTableN : i);
-  const double t0 = ti * (1.0 / double(kAtanTableN));
-  const double d = (t - t0) * fast_rcp(fma(t, t0, 1.0));
+  const double t0 = double(i) * (1.0 / double(kAtanTableN));
+  const double num = fma(-t0, mx, mn);
+  const double den = fmax(fma(t0, mn, mx), 1e-30);
+  const double d = num * fast_rcp(den);
   const double d2 = d * d;
   double a = fma(d, fma(d2, fma(d2, 0.2, -1.0 / 3.0), 1.0), g_atan_tab[i]);
   a = swap ? 1.57079632679489661923 - a : a;
@@ -280,6 +296,73 @@ NID_HD void radtan_partials(real p1, real p2, real px, real py, real x2, real y2
   a11 = fma(y2, rc2, fma(real(3) * p1, py, i1));
 }
 
+// ---- the FAST (SPLINE-kernel) forms of the three wide-angle models, each as ONE core shared by the histogram pass
+// (project<..., FAST>), the gradient pass (project_fwd) and the Jacobian utility (project_jac): the projected point is the
+// same expression everywhere, so every pass agrees on every knot.
+//
+// fisheye.hpp:14-36:  (u, v) = f .* s (x, y) + c,  s = theta_d(theta) / r,  theta = atan2(r, |z|),  r = |(x, y)|.
+// 1/r from one rsqrt (r = r2 / r), atan2 without an IEEE division, theta_d / r as a multiply.  r2 = 0 gives 1/r = NaN,
+// hence a NaN projection, like the reference's 0/0 (fisheye.hpp:31-33).
+template <typename real>
+struct FisheyeCore {
+  real r2, ir, az, th2, s;
+};
+template <typename real>
+NID_HD FisheyeCore<real> fisheye_core(const CamParams<real>& c, real x, real y, real z) {
+  FisheyeCore<real> k;
+  k.r2 = fma(x, x, y * y);
+  k.ir = fast_rsq(k.r2);
+  k.az = m_abs(z);
+  const real theta = fast_atan2(k.r2 * k.ir, k.az);
+  k.th2 = theta * theta;
+  const real theta_d = theta * fma(k.th2, fma(k.th2, fma(k.th2, fma(k.th2, c.dist[3], c.dist[2]), c.dist[1]), c.dist[0]), real(1));
+  k.s = theta_d * k.ir;
+  return k;
+}
+// omnidir.hpp:14-41:  m = s_xy / (s_z + xi) with s = p / |p|, i.e. m = p_xy / (p_z + xi |p|): ONE rsqrt for |p| = n2 rsq(n2) and
+// ONE reciprocal of the un-normalised denominator (round 5; rounds 1-4 normalised the bearing first: three more multiplies and
+// two more values alive in the gradient pass).  |p| = 0 (omnidir.hpp:19 skips the normalisation): den = xi, m = 0 -- n = 1 there.
+template <typename real>
+struct OmnidirCore {
+  real in, n, iden, ux, uy;
+};
+template <typename real>
+NID_HD OmnidirCore<real> omnidir_core(const CamParams<real>& c, real x, real y, real z) {
+  OmnidirCore<real> k;
+  const real n2 = fma(z, z, fma(y, y, x * x));
+  const bool pos = n2 > real(0);
+  k.in = pos ? fast_rsq(n2) : real(1);
+  k.n = pos ? n2 * k.in : real(1);
+  k.iden = fast_rcp(fma(c.intr[4], k.n, z));
+  k.ux = x * k.iden;
+  k.uy = y * k.iden;
+  return k;
+}
+// equirectangular.hpp:14-28:  lat = -asin(y / |p|) = -atan2(y, rho), rho = |(x, z)|: no normalisation of the bearing is needed
+// at all, and both angles share the division-free atan2.  |p|^2 < 1e-3 -> the image centre (:16-18).
+template <typename real>
+struct EquirectCore {
+  real rho2, irho;
+  bool tiny;
+};
+template <typename real>
+NID_HD EquirectCore<real> equirect_core(const CamParams<real>& c, real x, real y, real z, real& u, real& v) {
+  EquirectCore<real> k;
+  const real n2 = fma(z, z, fma(y, y, x * x));
+  k.rho2 = fma(x, x, z * z);
+  const bool rpos = k.rho2 > real(0);
+  k.irho = rpos ? fast_rsq(k.rho2) : real(0);
+  const real rho = k.rho2 * k.irho;
+  const real lon = fast_atan2(x, z);
+  const real nlat = fast_atan2(y, rho);  // = -lat
+  k.tiny = n2 < real(1e-3);
+  const real uu = fma(c.intr[0] * real(0.15915494309189533577), lon, c.intr[0] * real(0.5));
+  const real vv = fma(c.intr[1] * real(0.31830988618379067154), nlat, c.intr[1] * real(0.5));
+  u = k.tiny ? c.intr[0] * real(0.5) : uu;
+  v = k.tiny ? c.intr[1] * real(0.5) : vv;
+  return k;
+}
+
 // projection models (reference: include/camera/{pinhole,fisheye,omnidir,equirectangular,atan,
 // rational_polynomial}.hpp), T = real or Dual3<real>.
 template <int MODEL, typename T, typename real, bool FAST = false>
@@ -308,16 +391,9 @@ NID_HD void project(const CamParams<real>& c, const T& x, const T& y, const T& z
   } else if (MODEL == MODEL_FISHEYE) {  // fisheye.hpp:14-36 (abs(z) at :16)
     const real k1 = c.dist[0], k2 = c.dist[1], k3 = c.dist[2], k4 = c.dist[3];
     if constexpr (FAST && std::is_floating_point<T>::value) {
-      // 1/r from one rsqrt (r = r2 / r), atan2 without the IEEE division, theta_d / r as a multiply.
-      // r2 = 0 gives 1/r = NaN, hence a NaN projection, like the reference's 0/0 (fisheye.hpp:31-33).
-      const T r2 = fma(x, x, y * y);
-      const T ir = fast_rsq(r2);
-      const T theta = fast_atan2(r2 * ir, m_abs(z));
-      const T th2 = theta * theta;
-      const T theta_d = theta * fma(th2, fma(th2, fma(th2, fma(th2, k4, k3), k2), k1), real(1));
-      const T s = theta_d * ir;
-      u = fma(c.intr[0], s * x, c.intr[2]);
-      v = fma(c.intr[1], s * y, c.intr[3]);
+      const FisheyeCore<T> k = fisheye_core<T>(c, x, y, z);
+      u = fma(c.intr[0], k.s * x, c.intr[2]);
+      v = fma(c.intr[1], k.s * y, c.intr[3]);
     } else {
       const T r = m_sqrt(mad<FAST>(x, x, y * y));
       const T theta = m_atan2(r, m_abs(z));
@@ -333,15 +409,13 @@ NID_HD void project(const CamParams<real>& c, const T& x, const T& y, const T& z
   } else if (MODEL == MODEL_OMNIDIR) {  // omnidir.hpp:14-41
     const real xi = c.intr[4];
     const real k1 = c.dist[0], k2 = c.dist[1], p1 = c.dist[2], p2 = c.dist[3];
-    const T n2 = mad<FAST>(z, z, mad<FAST>(y, y, x * x));                 // x x + y y + z z
     T ux, uy;
     if constexpr (FAST && std::is_floating_point<T>::value) {
-      // unit-sphere normalisation by one rsqrt, mirror division by one reciprocal
-      const T in = n2 > real(0) ? fast_rsq(n2) : real(1);
-      const T iden = fast_rcp(fma(z, in, xi));
-      ux = (x * in) * iden;
-      uy = (y * in) * iden;
+      const OmnidirCore<T> k = omnidir_core<T>(c, x, y, z);
+      ux = k.ux;
+      uy = k.uy;
     } else {
+      const T n2 = mad<FAST>(z, z, mad<FAST>(y, y, x * x));               // x x + y y + z z
       T sx = x, sy = y, sz = z;
       if (n2 > real(0)) {
         const T n = m_sqrt(n2);
@@ -367,29 +441,21 @@ NID_HD void project(const CamParams<real>& c, const T& x, const T& y, const T& z
     u = mad<FAST>(c.intr[0], nx, c.intr[2]);
     v = mad<FAST>(c.intr[1], ny, c.intr[3]);
   } else if (MODEL == MODEL_EQUIRECT) {  // equirectangular.hpp:14-28, intr = [W H]
-    const T n2 = mad<FAST>(z, z, mad<FAST>(y, y, x * x));
     if constexpr (FAST && std::is_floating_point<T>::value) {
-      // asin(y / |p|) = atan2(y, rho) with rho = sqrt(x^2 + z^2): no normalisation of the bearing is
-      // needed at all, and both angles share the division-free atan2
-      const T rho2 = fma(x, x, z * z);
-      const T rho = rho2 > real(0) ? rho2 * fast_rsq(rho2) : real(0);
-      const T lon = fast_atan2(x, z);
-      const T nlat = fast_atan2(y, rho);  // = -lat
-      const bool tiny = n2 < real(1e-3);
-      const T uu = fma(c.intr[0] * real(0.15915494309189533577), lon, c.intr[0] * real(0.5));
-      const T vv = fma(c.intr[1] * real(0.31830988618379067154), nlat, c.intr[1] * real(0.5));
-      u = tiny ? c.intr[0] * real(0.5) : uu;
-      v = tiny ? c.intr[1] * real(0.5) : vv;
-    } else if (n2 < real(1e-3)) {
-      u = T(c.intr[0] / real(2));
-      v = T(c.intr[1] / real(2));
+      (void)equirect_core<T>(c, x, y, z, u, v);
     } else {
-      const T n = m_sqrt(n2);
-      const T bx = x / n, by = y / n, bz = z / n;
-      const T lat = -m_asin(by);
-      const T lon = m_atan2(bx, bz);
-      u = c.intr[0] * (real(0.5) + lon / real(2.0 * 3.14159265358979323846));
-      v = c.intr[1] * (real(0.5) - lat / real(3.14159265358979323846));
+      const T n2 = mad<FAST>(z, z, mad<FAST>(y, y, x * x));
+      if (n2 < real(1e-3)) {
+        u = T(c.intr[0] / real(2));
+        v = T(c.intr[1] / real(2));
+      } else {
+        const T n = m_sqrt(n2);
+        const T bx = x / n, by = y / n, bz = z / n;
+        const T lat = -m_asin(by);
+        const T lon = m_atan2(bx, bz);
+        u = c.intr[0] * (real(0.5) + lon / real(2.0 * 3.14159265358979323846));
+        v = c.intr[1] * (real(0.5) - lat / real(3.14159265358979323846));
+      }
     }
   } else if (MODEL == MODEL_ATAN) {  // atan.hpp:14-39
     const real d0 = c.dist[0];
@@ -431,6 +497,27 @@ NID_HD void project(const CamParams<real>& c, const T& x, const T& y, const T& z
     u = mad<FAST>(c.intr[0], dx, c.intr[2]);
     v = mad<FAST>(c.intr[1], dy, c.intr[3]);
   }
+}
+
+// what the wide-angle models' Jacobians need beyond their cores
+//   fisheye: q = (theta_d' |z| / |p|^2 - s) / r^2 and wz = -theta_d' sgn(z) / |p|^2 (see project_jac)
+template <typename real>
+NID_HD void fisheye_partials(const CamParams<real>& c, const FisheyeCore<real>& k, real z, real& q, real& wz) {
+  const real k1 = c.dist[0], k2 = c.dist[1], k3 = c.dist[2], k4 = c.dist[3];
+  const real dtheta_d = fma(k.th2, fma(k.th2, fma(k.th2, fma(k.th2, real(9) * k4, real(7) * k3), real(5) * k2), real(3) * k1), real(1));
+  const real in2 = fast_rcp(fma(z, z, k.r2));
+  q = fma(dtheta_d * k.az, in2, -k.s) * (k.ir * k.ir);
+  wz = (z < real(0) ? dtheta_d : -dtheta_d) * in2;
+}
+//   equirectangular: du = ku (z, 0, -x), dv = (t x, kvr, t z) with ku = W / (2 pi rho^2), kvr = H rho / (pi |p|^2),
+//   t = -H y / (pi |p|^2 rho); all zero for a point the value sends to the image centre (:16)
+template <typename real>
+NID_HD void equirect_partials(const CamParams<real>& c, const EquirectCore<real>& k, real y, real& ku, real& kvr, real& t) {
+  const real in2 = fast_rcp(fma(y, y, k.rho2));
+  const real kv = k.tiny ? real(0) : (c.intr[1] * real(0.31830988618379067154)) * in2;
+  ku = k.tiny ? real(0) : (c.intr[0] * real(0.15915494309189533577)) * (k.irho * k.irho);
+  kvr = kv * (k.rho2 * k.irho);
+  t = -(kv * y) * k.irho;
 }
 
 // Jacobian of the radial-tangential distortion shared by plumb_bob / rational_polynomial / omnidir (radtan_partials
@@ -496,73 +583,50 @@ NID_HD void project_jac(const CamParams<real>& c, real x, real y, real z, real& 
     dv[1] = a11 * iz;
     dv[2] = -fma(dv[0], px, dv[1] * py);
   } else if (MODEL == MODEL_OMNIDIR) {
-    // m = s_xy / (s_z + xi), s = p / |p|:  d(m)/d(s) = [I2 | -m] / den,  d(s)/d(p) = (I - s s^T) / |p|
+    // m = p_xy / den, den = p_z + xi |p|:  d(m)/d(p) = ([I2 | 0] - m (e_z + xi p / |p|)^T) / den
     project<MODEL, real, real, true>(c, x, y, z, u, v);
-    const real n2 = fma(z, z, fma(y, y, x * x));
-    const bool pos = n2 > real(0);
-    const real in = pos ? fast_rsq(n2) : real(1);
-    const real sx = x * in, sy = y * in, sz = z * in;
-    const real iden = fast_rcp(sz + c.intr[4]);
-    const real ux = sx * iden, uy = sy * iden;
+    const OmnidirCore<real> k = omnidir_core<real>(c, x, y, z);
     real a00, a01, a10, a11;
-    radtan_jac<MODEL, real>(c, ux, uy, a00, a01, a10, a11);
-    // an un-normalised point (|p| = 0, omnidir.hpp:19) has d(s)/d(p) = I: dot = 0 and in = 1 below
+    radtan_jac<MODEL, real>(c, k.ux, k.uy, a00, a01, a10, a11);
+    // an un-normalised point (|p| = 0, omnidir.hpp:19) has den = xi, a constant: the xi p / |p| term vanishes with p
+    const real xin = c.intr[4] * k.in;
     {
-      const real b0 = a00 * iden, b1 = a01 * iden, b2 = -fma(b0, ux, b1 * uy);
-      const real dot = pos ? fma(b2, sz, fma(b1, sy, b0 * sx)) : real(0);
-      du[0] = fma(-dot, sx, b0) * in;
-      du[1] = fma(-dot, sy, b1) * in;
-      du[2] = fma(-dot, sz, b2) * in;
+      const real b0 = a00 * k.iden, b1 = a01 * k.iden, t = fma(b0, k.ux, b1 * k.uy);
+      du[0] = fma(-(t * xin), x, b0);
+      du[1] = fma(-(t * xin), y, b1);
+      du[2] = fma(-(t * xin), z, -t);
     }
     {
-      const real b0 = a10 * iden, b1 = a11 * iden, b2 = -fma(b0, ux, b1 * uy);
-      const real dot = pos ? fma(b2, sz, fma(b1, sy, b0 * sx)) : real(0);
-      dv[0] = fma(-dot, sx, b0) * in;
-      dv[1] = fma(-dot, sy, b1) * in;
-      dv[2] = fma(-dot, sz, b2) * in;
+      const real b0 = a10 * k.iden, b1 = a11 * k.iden, t = fma(b0, k.ux, b1 * k.uy);
+      dv[0] = fma(-(t * xin), x, b0);
+      dv[1] = fma(-(t * xin), y, b1);
+      dv[2] = fma(-(t * xin), z, -t);
     }
   } else if (MODEL == MODEL_FISHEYE) {
-    // (u, v) = f .* s (x, y) + c,  s = theta_d(theta) / r,  theta = atan2(r, |z|),  r = |(x, y)|:
     //   d(s x)/dx = s + x^2 q,  d(s x)/dy = x y q,  d(s x)/dz = -x theta_d' sgn(z) / |p|^2,
     //   q = (theta_d' |z| / |p|^2 - s) / r^2
     project<MODEL, real, real, true>(c, x, y, z, u, v);
-    const real k1 = c.dist[0], k2 = c.dist[1], k3 = c.dist[2], k4 = c.dist[3];
-    const real r2 = fma(x, x, y * y);
-    const real ir = fast_rsq(r2);
-    const real az = m_abs(z);
-    const real theta = fast_atan2(r2 * ir, az);
-    const real th2 = theta * theta;
-    const real theta_d = theta * fma(th2, fma(th2, fma(th2, fma(th2, k4, k3), k2), k1), real(1));
-    const real dtheta_d = fma(th2, fma(th2, fma(th2, fma(th2, real(9) * k4, real(7) * k3), real(5) * k2), real(3) * k1), real(1));
-    const real s = theta_d * ir;
-    const real in2 = fast_rcp(fma(z, z, r2));
-    const real ir2 = ir * ir;
-    const real q = fma(dtheta_d * az, in2, -s) * ir2;
-    const real wz = (z < real(0) ? dtheta_d : -dtheta_d) * in2;  // -theta_d' sgn(z) / |p|^2
+    const FisheyeCore<real> k = fisheye_core<real>(c, x, y, z);
+    real q, wz;
+    fisheye_partials<real>(c, k, z, q, wz);
     const real fx = c.intr[0], fy = c.intr[1];
     const real xq = x * q, yq = y * q;
-    du[0] = fx * fma(x, xq, s);
+    du[0] = fx * fma(x, xq, k.s);
     du[1] = fx * (x * yq);
     du[2] = fx * (x * wz);
     dv[0] = fy * (y * xq);
-    dv[1] = fy * fma(y, yq, s);
+    dv[1] = fy * fma(y, yq, k.s);
     dv[2] = fy * (y * wz);
   } else if (MODEL == MODEL_EQUIRECT) {
     // u = W (1/2 + atan2(x, z) / 2 pi),  v = H (1/2 + atan2(y, rho) / pi),  rho = |(x, z)|
-    project<MODEL, real, real, true>(c, x, y, z, u, v);
-    const real rho2 = fma(x, x, z * z);
-    const real n2 = fma(y, y, rho2);
-    const bool tiny = fma(z, z, fma(y, y, x * x)) < real(1e-3);  // the value's own test (equirectangular.hpp:16)
-    const real irho = fast_rsq(rho2);
-    const real in2 = fast_rcp(n2);
-    const real ku = tiny ? real(0) : c.intr[0] * real(0.15915494309189533577) * (irho * irho);
-    const real kv = tiny ? real(0) : c.intr[1] * real(0.31830988618379067154) * in2;
+    const EquirectCore<real> k = equirect_core<real>(c, x, y, z, u, v);
+    real ku, kvr, t;
+    equirect_partials<real>(c, k, y, ku, kvr, t);
     du[0] = ku * z;
     du[1] = real(0);
     du[2] = -ku * x;
-    const real t = -(kv * y) * irho;
     dv[0] = t * x;
-    dv[1] = kv * (rho2 * irho);
+    dv[1] = kvr;
     dv[2] = t * z;
   } else {
     typedef Dual3<real> D;
@@ -580,14 +644,20 @@ NID_HD void project_jac(const CamParams<real>& c, real x, real y, real z, real& 
 
 // Gradient pass, two halves around the tap loop.  project_fwd: the projected point (the histogram pass's own
 // expression, so both passes agree on every knot) plus what the backward half needs; project_bwd: the
-// vector-Jacobian product gp = (gx, gy) . d(u, v)/d(x, y, z).  For the pinhole family (plumb_bob,
-// rational_polynomial) the 2x3 Jacobian is never formed: with A = d(dx, dy)/d(px, py) (symmetric off-diagonal),
-//   h = A^T (fx gx, fy gy),  gp = (h0 / z, h1 / z, -(gp0 px + gp1 py))
-// -- 10 operations instead of 18 for the explicit Jacobian and its contraction.  The other models keep their
-// closed-form 2x3 Jacobians (project_jac) and contract them here.
+// vector-Jacobian product gp = (gx, gy) . d(u, v)/d(x, y, z).  No model forms its 2x3 Jacobian here (round 5; until round 4
+// only the pinhole family did not) -- each contracts (gx, gy) through the factors of its chain rule:
+//   pinhole family   A = d(dx, dy)/d(px, py) (symmetric off-diagonal):  h = A^T (fx gx, fy gy),  gp = (h0 / z, h1 / z, -(gp0 px + gp1 py))
+//   omnidir          m = p_xy / den, den = p_z + xi |p|:  b = (A / den)^T (fx gx, fy gy), t = b . m,
+//                    gp = (b0, b1, -t) - xi t p / |p| = (b0 - cd ux, b1 - cd uy, (xi^2 - 1) t - cd),  cd = xi t den / |p|
+//                    (p = den m in x and y, p_z = den - xi |p|): nothing of the camera-frame point stays alive across the taps
+//   fisheye          g' = (fx gx, fy gy), k = x g'0 + y g'1:  gp = (s g'0 + x q k, s g'1 + y q k, wz k)
+//   equirectangular  gp = (a z + b x, gy kvr, b z - a x),  a = gx ku, b = gy t
+// -- 10 / 14 / 10 / 7 operations where the explicit Jacobian and its contraction took 18 / 36 / 20 / 14.  `atan` keeps the
+// generic 2x3 Jacobian (project_jac) and contracts it here.
 template <typename real>
 struct ProjCtx {
-  real a[6];  // pinhole family: iz, px, py, A00, off, A11;  otherwise du[0..2], dv[0..2]
+  real a[6];  // pinhole family: iz, px, py, A00, off, A11;  omnidir: (A00, off, A11) / den, ux, uy, xi den / |p|;
+              // fisheye: s, q, wz, x, y;  equirectangular: ku, kvr, t, x, z;  atan: du[0..2], dv[0..2]
 };
 template <int MODEL, typename real>
 NID_HD void project_fwd(const CamParams<real>& c, real x, real y, real z, real& u, real& v, ProjCtx<real>& ctx) {
@@ -606,6 +676,37 @@ NID_HD void project_fwd(const CamParams<real>& c, real x, real y, real z, real& 
     ctx.a[3] = a00;
     ctx.a[4] = a01;  // == a10
     ctx.a[5] = a11;
+  } else if (MODEL == MODEL_OMNIDIR) {
+    project<MODEL, real, real, true>(c, x, y, z, u, v);
+    const OmnidirCore<real> k = omnidir_core<real>(c, x, y, z);
+    real a00, a01, a10, a11;
+    CamParams<real> unit = c;
+    unit.intr[0] = real(1);
+    unit.intr[1] = real(1);
+    radtan_jac<MODEL, real>(unit, k.ux, k.uy, a00, a01, a10, a11);
+    ctx.a[0] = a00 * k.iden;  // (six values stay alive across the taps, like every other model: a seventh spilled in the looped kernels)
+    ctx.a[1] = a01 * k.iden;
+    ctx.a[2] = a11 * k.iden;
+    ctx.a[3] = k.ux;
+    ctx.a[4] = k.uy;
+    // xi den / |p|; for |p| = 0 (den = xi, a constant) the term it multiplies has to vanish: in = 1, n = 1, but t = 0 there
+    // (m = 0), so whatever this is, cd = 0
+    ctx.a[5] = c.intr[4] * (fma(c.intr[4], k.n, z) * k.in);
+  } else if (MODEL == MODEL_FISHEYE) {
+    project<MODEL, real, real, true>(c, x, y, z, u, v);
+    const FisheyeCore<real> k = fisheye_core<real>(c, x, y, z);
+    real q, wz;
+    fisheye_partials<real>(c, k, z, q, wz);
+    ctx.a[0] = k.s;
+    ctx.a[1] = q;
+    ctx.a[2] = wz;
+    ctx.a[3] = x;
+    ctx.a[4] = y;
+  } else if (MODEL == MODEL_EQUIRECT) {
+    const EquirectCore<real> k = equirect_core<real>(c, x, y, z, u, v);
+    equirect_partials<real>(c, k, y, ctx.a[0], ctx.a[1], ctx.a[2]);
+    ctx.a[3] = x;
+    ctx.a[4] = z;
   } else {
     project_jac<MODEL, real>(c, x, y, z, u, v, ctx.a, ctx.a + 3);
   }
@@ -619,6 +720,28 @@ NID_HD void project_bwd(const CamParams<real>& c, const ProjCtx<real>& ctx, real
     gp[0] = h0 * ctx.a[0];
     gp[1] = h1 * ctx.a[0];
     gp[2] = -fma(gp[0], ctx.a[1], gp[1] * ctx.a[2]);
+  } else if (MODEL == MODEL_OMNIDIR) {
+    const real xi = c.intr[4];
+    const real gxf = gx * c.intr[0], gyf = gy * c.intr[1];
+    const real b0 = fma(gxf, ctx.a[0], gyf * ctx.a[1]);
+    const real b1 = fma(gxf, ctx.a[1], gyf * ctx.a[2]);
+    const real t = fma(b0, ctx.a[3], b1 * ctx.a[4]);
+    const real cd = t * ctx.a[5];
+    gp[0] = fma(-cd, ctx.a[3], b0);
+    gp[1] = fma(-cd, ctx.a[4], b1);
+    gp[2] = fma(t, fma(xi, xi, real(-1)), -cd);
+  } else if (MODEL == MODEL_FISHEYE) {
+    const real g0 = gx * c.intr[0], g1 = gy * c.intr[1];
+    const real k = fma(ctx.a[3], g0, ctx.a[4] * g1);
+    const real kq = k * ctx.a[1];
+    gp[0] = fma(ctx.a[3], kq, ctx.a[0] * g0);
+    gp[1] = fma(ctx.a[4], kq, ctx.a[0] * g1);
+    gp[2] = ctx.a[2] * k;
+  } else if (MODEL == MODEL_EQUIRECT) {
+    const real a = gx * ctx.a[0], b = gy * ctx.a[2];
+    gp[0] = fma(a, ctx.a[4], b * ctx.a[3]);
+    gp[1] = gy * ctx.a[1];
+    gp[2] = fma(b, ctx.a[4], -(a * ctx.a[3]));
   } else {
     gp[0] = fma(gx, ctx.a[0], gy * ctx.a[3]);
     gp[1] = fma(gx, ctx.a[1], gy * ctx.a[4]);

@@ -570,7 +570,9 @@ __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads, hist_min_waves(MODE
 // The bound.  Both tiers evaluate the same real-valued functions of the same inputs; with eps = 2^-52:
 //   c = M p + t:   |c_fast - c_exact| <= e1 = 8 eps (rmax (|x| + |y| + |z|) + tmax)   per component (three products, three
 //                  sums, either association; rmax / tmax = largest |entry| of the rotation block / the translation);
-//   zn = cz / |c|: |d zn| <= sqrt(3) e1 / |c| + 16 eps                                 -> band bz = 8 e1 / |c| + 1e-14;
+//   zn = cz / |c|: |d zn| <= sqrt(3) e1 / |c| + 16 eps                                 -> band bz = 8 e1 / |c| + 4e-14
+//                  (the one-Newton-step rsqrt may be 2^-46 = 1.4e-14 relative off by the documented worst case of its seed:
+//                  <= 2.1e-14 on zn, and the constant carries a factor ~2 over that);
 //   px = cx / cz:  |d px| <= e1 (1 + |px|) / |cz| + 1.5e-14 |px|  (one-Newton-step reciprocal: 2^-46 relative); same for py;
 //   (u, v) = f D(px, py) + c0 with |px|, |py| <= pmax = tan(max_fov) for a point inside the cone, D's Jacobian row sums <= K
 //                  there (from the distortion coefficients, on the host): |d u| <= A e1 / |cz| + Bc with
@@ -680,7 +682,7 @@ __global__ __launch_bounds__(kThreads, nearest_min_waves(MODEL, std::is_same<rea
           const double rs = fast_rsq(n2);  // NaN for n2 == 0
           const double e1 = fma(fast.er, (fabs(x) + fabs(y)) + fabs(z), fast.et);
           const double dz = fma(cz, rs, -double(cos_fov));
-          const bool fov_safe = fabs(dz) > fma(8.0 * e1, rs, 1e-14);
+          const bool fov_safe = fabs(dz) > fma(8.0 * e1, rs, 4e-14);
           const bool in_fov = !(dz < 0.0);
           real u, v;
           project<MODEL, real, real, true>(cam, real(cx), real(cy), real(cz), u, v);

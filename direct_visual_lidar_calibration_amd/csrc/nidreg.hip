@@ -73,6 +73,7 @@ struct nidreg_handle {
   int64_t num_points = 0;
   int nchunks = 0;       // gradient pass / generic histogram kernels
   int nslots = 0;        // segments in that table = 12-double partials of the gradient pass (>= nchunks)
+  int partials_cap = 0;  // 12-double slots allocated behind d_partials at creation (cohort / multi-pair tables must fit)
   int seg = 0, seg_hist = 0;  // the table (d_chunks / d_chunks_hist) has chunks that run across column groups: SEG kernels
   size_t chunks_cap = 0, chunks_hist_cap = 0;  // entries allocated behind d_chunks / d_chunks_hist
   struct Cohort* cohort = nullptr;  // NIDREG_COHORT=1: the handles created together for one MultiNIDCost share ONE round of workgroups
@@ -104,6 +105,7 @@ struct nidreg_handle {
   // its k_entropy zeroes the OTHER one for evaluation k + 1, so no memset sits on the critical path
   u64* d_hist_buf[2] = {nullptr, nullptr};
   bool hist_zeroed[2] = {false, false};
+  hipStream_t zero_stream = nullptr;  // the stream of the kernel that cleared the idle buffer (begin_histogram orders a launch on another stream behind it)
   int hist_cur = 0;
   bool own_hist = false;
   double* d_out = nullptr;
@@ -126,14 +128,16 @@ struct nidreg_handle {
   double* h_ring = nullptr;   // [kAsyncDepth][NIDREG_OUT_DOUBLES], pinned, host-mapped (allocated at the first submit)
   double* d_ring = nullptr;   // its device address
   struct Pending {
-    double seq = 0.0;        // 0: free
-    uint64_t bits = 0;
+    int64_t ticket = 0;      // 0: free
+    uint64_t bits = 0;       // completion tag of the evaluation (the handle's sequence number at its launch)
     bool grad = false, done = false, counted = false;  // done: evaluated synchronously inside nidreg_submit (sharded handles, ext_out); counted: holds an in-flight count of its device
     int rc = 0;
     double res[8] = {0};
   };
   Pending pending[8];
   int async_outstanding = 0;
+  int64_t next_ticket = 0;  // tickets are numbered by a counter of their own: the completion tags (seq) advance by more than one per
+                            // submit on handles whose submit evaluates synchronously (shards bump the leader's seq themselves)
 
   size_t lds_hist = 0, lds_grad = 0, lds_entropy = 0;
   int64_t hist_words = 0;
@@ -310,7 +314,7 @@ void free_handle(nidreg_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& p : h->pending)  // tickets never collected: give their in-flight counts back to the device
-    if (p.seq != 0.0 && p.counted && h->device >= 0 && h->device < NIDREG_MAX_DEVICES) g_inflight[h->device].fetch_sub(1, std::memory_order_acq_rel);
+    if (p.ticket != 0 && p.counted && h->device >= 0 && h->device < NIDREG_MAX_DEVICES) g_inflight[h->device].fetch_sub(1, std::memory_order_acq_rel);
   if (h->d_pts) (void)hipFree(h->d_pts);
   if (h->d_chunks) (void)hipFree(h->d_chunks);
   if (h->d_chunks_hist) (void)hipFree(h->d_chunks_hist);
@@ -436,6 +440,15 @@ hipError_t begin_histogram(nidreg_handle* h, hipStream_t stream) {
   if (h->own_hist) {
     h->hist_cur ^= 1;
     h->d_hist = h->d_hist_buf[h->hist_cur];
+    // The buffer was cleared by the PREVIOUS evaluation's kernels (plain stores of k_entropy / the gradient prologue), and the
+    // host may be here before that kernel has ended: it proceeds on the completion tag.  On the same stream the kernel boundary
+    // orders the clears against this evaluation's atomics; on another stream (a cohort round on a different group's stream, a
+    // caller mixing nidreg_eval and nidreg_eval_multi on one handle) nothing does -- the clears sit in the old kernel's XCD-local
+    // L2 until it ends and could land on top of the new counts.  Rare path: drain the old stream first.
+    if (h->hist_zeroed[h->hist_cur] && h->zero_stream && h->zero_stream != stream) {
+      hipError_t e = hipStreamSynchronize(h->zero_stream);
+      if (e != hipSuccess) return e;
+    }
     if (!h->hist_zeroed[h->hist_cur]) {
       hipError_t e = hipMemsetAsync(h->d_hist, 0, size_t(h->hist_words) * sizeof(u64), stream);
       if (e != hipSuccess) return e;
@@ -540,7 +553,10 @@ int launch_entropy(nidreg_handle* h, double tag, bool tail = true) {
     h->d_hist_points, h->d_scal, h->d_out, h->d_out_host, tag, h->d_counters, h->own_hist ? h->d_hist_buf[h->hist_cur ^ 1] : nullptr, h->hist_words, tail ? 1 : 0,
     static_cast<const MultiEntry*>(nullptr), NoMultiDyn());
   HIP_TRY(hipGetLastError());
-  if (h->own_hist) h->hist_zeroed[h->hist_cur ^ 1] = true;  // zeroed by this k_entropy for the next evaluation
+  if (h->own_hist) {
+    h->hist_zeroed[h->hist_cur ^ 1] = true;  // zeroed by this k_entropy for the next evaluation
+    h->zero_stream = h->stream;
+  }
   return NIDREG_OK;
 }
 
@@ -563,7 +579,10 @@ int launch_grad(nidreg_handle* h, bool alone = false, int from_partials = 0) {
   if (from_partials == 2) {
     a.gt_zero_buf = h->own_hist ? h->d_hist_buf[h->hist_cur ^ 1] : nullptr;
     a.gt_zero_words = h->hist_words;
-    if (h->own_hist) h->hist_zeroed[h->hist_cur ^ 1] = true;  // zeroed by this evaluation's gradient kernel for the next one
+    if (h->own_hist) {
+      h->hist_zeroed[h->hist_cur ^ 1] = true;  // zeroed by this evaluation's gradient kernel for the next one
+      h->zero_stream = h->stream;
+    }
   }
   a.hist = h->d_hist;  // the finished histogram (for a shard: its own columns)
   // same pose as the histogram pass of this evaluation
@@ -1222,7 +1241,8 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
     const size_t o_hist_image = carve(size_t(B) * sizeof(double));
     const size_t o_hist_points = carve(size_t(B) * sizeof(double));
     const size_t o_scal = carve(sizeof(EntropyScalars));
-    const size_t o_partials = carve(size_t(partial_slots(h)) * 12 * sizeof(double));
+    h->partials_cap = partial_slots(h);
+    const size_t o_partials = carve(size_t(h->partials_cap) * 12 * sizeof(double));
     const size_t o_counters = carve(8 * sizeof(unsigned int));
     CREATE_TRY(hipMalloc(&h->d_scratch, off));
     CREATE_TRY(hipMemset(h->d_scratch, 0, off));
@@ -1293,7 +1313,10 @@ void free_group(MultiGroup* g) {
   (void)hipSetDevice(g->device);
   if (g->stream) (void)hipStreamSynchronize(g->stream);
   for (nidreg_handle* m : g->hs)  // (ADVICE r3 made the getters drain the stream of the last evaluation: never a freed group's)
+  {
     if (m->last_stream == g->stream) m->last_stream = m->stream;
+    if (m->zero_stream == g->stream) m->zero_stream = nullptr;  // drained above: nothing left to order against
+  }
   if (g->d_table) (void)hipFree(g->d_table);
   if (g->d_chunks) (void)hipFree(g->d_chunks);
   if (g->d_chunks_hist) (void)hipFree(g->d_chunks_hist);
@@ -1363,34 +1386,42 @@ bool cohorts_enabled() {
 int cohort_reshape(nidreg_handle* h, int64_t total_points) {
   HIP_TRY(hipSetDevice(h->device));
   const int64_t mine = std::max<int64_t>(h->num_points, 1);
-  auto rebuild = [&](int per_cu, bool wide_hist, Chunk*& d_tab, size_t& cap, int& n_out, int64_t* slots_out) -> int {
-    std::vector<Chunk> chunks;
+  // both tables are built on the host first and committed together: a member whose share does not fit keeps its own tables whole
+  auto build = [&](int per_cu, bool wide_hist, std::vector<Chunk>& chunks) -> int64_t {
     const int64_t share = std::max<int64_t>(1, round_chunks(per_cu, h->num_cus, total_points) * mine / total_points);
-    const int64_t slots = split_groups(h->gcount.data(), h->NG, share, segment_overhead(wide_hist), max_segments(h->mode, h->GW), -1, chunks);
+    return split_groups(h->gcount.data(), h->NG, share, segment_overhead(wide_hist), max_segments(h->mode, h->GW), -1, chunks);
+  };
+  auto upload = [&](const std::vector<Chunk>& chunks, Chunk*& d_tab, size_t& cap) -> int {
     if (chunks.size() > cap) {
-      if (d_tab) HIP_TRY(hipFree(d_tab));
-      d_tab = nullptr;
+      Chunk* fresh = nullptr;
+      HIP_TRY(hipMalloc(&fresh, chunks.size() * sizeof(Chunk)));
+      if (d_tab) (void)hipFree(d_tab);
+      d_tab = fresh;
       cap = chunks.size();
-      HIP_TRY(hipMalloc(&d_tab, cap * sizeof(Chunk)));
     }
     if (!chunks.empty()) HIP_TRY(hipMemcpy(d_tab, chunks.data(), chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice));
-    n_out = int(chunks.size());
-    if (slots_out) *slots_out = slots;
-    (wide_hist ? h->cohort_chunks_hist : h->cohort_chunks) = std::move(chunks);
     return NIDREG_OK;
   };
-  int64_t slots = 0;
-  int rc = rebuild(h->per_cu_grad, false, h->d_chunks, h->chunks_cap, h->nchunks, &slots);
+  std::vector<Chunk> grad_chunks, hist_chunks;
+  const int64_t slots = build(h->per_cu_grad, false, grad_chunks);
+  if (slots > int64_t(h->partials_cap)) return fail(NIDREG_ERR_INVALID, "cohort: a member's share table needs more gradient-partial slots than its scratch holds");
+  const bool wide = h->wide && h->d_chunks_hist;
+  int64_t wslots = 0;
+  if (wide) wslots = build(h->per_cu_hist, true, hist_chunks);
+  // each table is committed together with the fields that describe it, right after its upload
+  int rc = upload(grad_chunks, h->d_chunks, h->chunks_cap);
   if (rc) return rc;
-  if (int(slots) > partial_slots(h)) return fail(NIDREG_ERR_INVALID, "cohort: a member's share table needs more gradient-partial slots than its scratch holds");
+  h->nchunks = int(grad_chunks.size());
   h->nslots = int(slots);
   h->seg = h->nslots > h->nchunks ? 1 : 0;
   h->lds_grad = spline_grad_lds_bytes(h->bins, h->GW, h->cshift, h->seg != 0);
-  if (h->wide && h->d_chunks_hist) {
-    int64_t wslots = 0;
-    rc = rebuild(h->per_cu_hist, true, h->d_chunks_hist, h->chunks_hist_cap, h->nchunks_hist, &wslots);
+  h->cohort_chunks = std::move(grad_chunks);
+  if (wide) {
+    rc = upload(hist_chunks, h->d_chunks_hist, h->chunks_hist_cap);
     if (rc) return rc;
-    h->seg_hist = wslots > h->nchunks_hist ? 1 : 0;
+    h->nchunks_hist = int(hist_chunks.size());
+    h->seg_hist = wslots > int64_t(h->nchunks_hist) ? 1 : 0;
+    h->cohort_chunks_hist = std::move(hist_chunks);
   }
   return NIDREG_OK;
 }
@@ -1526,7 +1557,7 @@ MultiGroup* find_or_make_group(nidreg_handle* const* handles, int n) {
     e.zero_words = h->hist_words;
     e.nslots = int(pair_slots);
     e.nchunks = int(pair_grad[size_t(i)].size());
-    if (e.nslots > partial_slots(h)) {  // the pair's partial buffer (12 doubles per slot) was sized at its creation
+    if (e.nslots > h->partials_cap) {  // the pair's partial buffer (12 doubles per slot) was sized at its creation
       delete g;
       if (g_rejected.size() >= kMaxRejected) g_rejected.erase(g_rejected.begin());
       g_rejected.emplace_back(handles, handles + n);
@@ -1618,7 +1649,10 @@ int group_eval(MultiGroup* g, const double* se3, bool want_grad, double* costs, 
       static_cast<double*>(nullptr), 0.0, static_cast<unsigned int*>(nullptr), static_cast<u64*>(nullptr), 0ll, 1, static_cast<const MultiEntry*>(g->d_table), a.dyn);
     HIP_TRY(hipGetLastError());
   }
-  for (int i = 0; i < n; i++) g->hs[size_t(i)]->hist_zeroed[g->hs[size_t(i)]->hist_cur ^ 1] = true;
+  for (int i = 0; i < n; i++) {
+    g->hs[size_t(i)]->hist_zeroed[g->hs[size_t(i)]->hist_cur ^ 1] = true;
+    g->hs[size_t(i)]->zero_stream = g->stream;
+  }
   // pass B (k_entropy<true> ran without its tail for every pair that has gradient workgroups: they run it)
   if (want_grad) {
     a.chunks = g->d_chunks;
@@ -1847,7 +1881,10 @@ int group_eval_iso(MultiGroup* g, const double* T, double* costs) {
     static_cast<u64*>(nullptr), static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<EntropyScalars*>(nullptr), static_cast<double*>(nullptr),
     static_cast<double*>(nullptr), 0.0, static_cast<unsigned int*>(nullptr), static_cast<u64*>(nullptr), 0ll, 1, static_cast<const MultiEntry*>(g->d_table), a.dyn);
   HIP_TRY(hipGetLastError());
-  for (int i = 0; i < n; i++) g->hs[size_t(i)]->hist_zeroed[g->hs[size_t(i)]->hist_cur ^ 1] = true;
+  for (int i = 0; i < n; i++) {
+    g->hs[size_t(i)]->hist_zeroed[g->hs[size_t(i)]->hist_cur ^ 1] = true;
+    g->hs[size_t(i)]->zero_stream = g->stream;
+  }
   for (int i = 0; i < n; i++) {
     const int rc = eval_finish_on(g->hs[size_t(i)], g->stream, costs + i, nullptr);
     if (rc < 0) return rc;
@@ -1946,6 +1983,7 @@ int shard_launch_phase(ShardSet* set, int g, int phase, bool alone) {
                        h->d_hist_buf[h->hist_cur ^ 1], h->hist_words, h->d_out + 10, h->d_out_host ? h->d_out_host + 10 : nullptr, set->timeout_ticks);
     HIP_TRY(hipGetLastError());
     h->hist_zeroed[h->hist_cur ^ 1] = true;
+    h->zero_stream = h->stream;
     return NIDREG_OK;
   }
   if (phase == 2) {
@@ -2399,23 +2437,23 @@ static int async_submit(nidreg_handle* h, int mode, const double* pose, bool wan
   if (!h || !pose || !ticket) return fail(NIDREG_ERR_INVALID, "nidreg_submit: null argument");
   if (h->mode != mode) return fail(NIDREG_ERR_INVALID, mode == NIDREG_MODE_SPLINE ? "nidreg_submit: handle was created in NEAREST mode" : "nidreg_submit_iso: handle was created in SPLINE mode");
   if (h->async_outstanding >= kAsyncDepth) return fail(NIDREG_ERR_INVALID, "nidreg_submit: too many evaluations in flight on this handle (8): nidreg_wait first");
+  const int64_t t = h->next_ticket + 1;
+  nidreg_handle::Pending& p = h->pending[t % kAsyncDepth];
+  if (p.ticket != 0) return fail(NIDREG_ERR_INVALID, "nidreg_submit: ticket ring collision (wait for the oldest evaluation first)");
   if (h->set || !h->d_out_host || h->timing) {
     // a handle sharded over several GPUs (its shards hand-shake inside the kernels), results in a caller's buffer, or
     // per-kernel timing: evaluated here and now, the ticket just carries the results
-    bump_seq(h);  // a ticket of its own (the evaluation below takes the next sequence numbers)
-    const int64_t t = int64_t(h->seq);
-    nidreg_handle::Pending& p = h->pending[t % kAsyncDepth];
-    if (p.seq != 0.0) return fail(NIDREG_ERR_INVALID, "nidreg_submit: ticket ring collision (wait for the oldest evaluation first)");
     double c = 0.0, g[7] = {0};
     const int rc = mode == NIDREG_MODE_SPLINE ? nidreg_eval(h, pose, &c, want_grad ? g : nullptr) : nidreg_eval_iso(h, pose, &c);
     if (rc < 0) return rc;
-    p.seq = double(t);
+    p.ticket = t;
     p.done = true;
     p.counted = false;
     p.rc = rc;
     p.grad = want_grad;
     p.res[0] = c;
     for (int k = 0; k < 7; k++) p.res[1 + k] = g[k];
+    h->next_ticket = t;
     h->async_outstanding++;
     *ticket = t;
     return NIDREG_OK;
@@ -2434,9 +2472,6 @@ static int async_submit(nidreg_handle* h, int mode, const double* pose, bool wan
     h->d_ring = static_cast<double*>(dp);
   }
   // the launch helpers write to h->d_out_host with tag h->seq: point them at this evaluation's ring block for the launch
-  const int64_t t = int64_t(h->seq) + 1;
-  nidreg_handle::Pending& p = h->pending[t % kAsyncDepth];
-  if (p.seq != 0.0) return fail(NIDREG_ERR_INVALID, "nidreg_submit: ticket ring collision (wait for the oldest evaluation first)");
   double* const own = h->d_out_host;
   h->d_out_host = h->d_ring + size_t(t % kAsyncDepth) * NIDREG_OUT_DOUBLES;
   // alone on the device = nothing in flight but this handle's own earlier submissions (they run before it, in stream order)
@@ -2447,11 +2482,12 @@ static int async_submit(nidreg_handle* h, int mode, const double* pose, bool wan
     if (h->device >= 0 && h->device < NIDREG_MAX_DEVICES) g_inflight[h->device].fetch_sub(1, std::memory_order_acq_rel);
     return rc;
   }
-  p.seq = h->seq;  // == t
-  p.bits = h->seq_bits;
+  p.ticket = t;
+  p.bits = h->seq_bits;  // the tag this evaluation's final workgroup writes behind its results
   p.grad = want_grad;
   p.done = false;
   p.counted = true;
+  h->next_ticket = t;
   h->async_outstanding++;
   *ticket = t;
   return NIDREG_OK;
@@ -2463,7 +2499,7 @@ int nidreg_submit_iso(nidreg_handle* h, const double* T, int64_t* ticket) { retu
 int nidreg_wait(nidreg_handle* h, int64_t ticket, double* cost, double* grad7) {
   if (!h || ticket <= 0) return fail(NIDREG_ERR_INVALID, "nidreg_wait: bad argument");
   nidreg_handle::Pending& p = h->pending[ticket % kAsyncDepth];
-  if (p.seq != double(ticket)) return fail(NIDREG_ERR_INVALID, "nidreg_wait: unknown ticket (already collected, or never issued by this handle)");
+  if (p.ticket != ticket) return fail(NIDREG_ERR_INVALID, "nidreg_wait: unknown ticket (already collected, or never issued by this handle)");
   int rc;
   if (p.done) {
     rc = p.rc;

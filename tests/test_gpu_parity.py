@@ -502,6 +502,102 @@ def test_headline_workload_10m_points_matches_oracle():
     cost.close()
 
 
+@pytest.mark.parametrize("camera,n,seed", [("equirect_2k", 10_000_000, 20250523 + 3), ("omnidir_2k", 10_000_000, 20250523 + 3), ("fisheye_1080p", 5_000_000, 20250523 + 4)])
+def test_config_cameras_full_size_match_oracle(camera, n, seed):
+    """BASELINE configs[2] (10M points, 2048 x 2048 equirectangular, and its omnidir variant) and one pair of configs[3] (5M points,
+    1920 x 1080 fisheye) at their FULL point counts, 256 bins, exactly as bench.py's `configs` leg builds them: value, gradient,
+    marginals and joint histogram against the oracle with its OpenMP split over points (1-2 s of CPU each), and the NEAREST twin's
+    integer histogram bit for bit.  What only shows at this size: the 32-bit chunk arithmetic, frac = 38 / 39, the table `atan2`
+    at 10^7 evaluations per pass, the Morton order of a 360-degree cloud, 2048^2 / 4 MB bin images against one XCD's L2."""
+    import torch
+
+    s = synth.make_scene(camera, num_points=n, seed=seed, device="cuda:0" if torch.cuda.is_available() else "cpu")
+    proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
+    cost = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, 256)
+    info = cost.info()
+    assert info["num_points"] == n and info["frac_bits"] == (38 if n > 2**23 else 39)
+    rng = np.random.default_rng(99)
+    x = synth.random_pose_near(s.T_camera_lidar_true, rng)
+    ref = oracle_nid(s, 256, x, want_hist=True, threads=oracle_lib.num_threads())
+    ok, c, g = cost(x)
+    assert ok and ref["ok"]
+    parity.check_cost(c, ref["cost"], what=f"{camera} {n}")
+    parity.check_grad(g, ref["grad"], what=f"{camera} {n}")
+    joint, hi, hp = cost.histograms()
+    assert np.array_equal(hp, ref["hist_points"]) and hp.sum() == ref["hist_points"].sum()
+    parity.check_hist(joint, ref["hist"], atol=parity.hist_atol_for(ref["hist"], info["frac_bits"]), what=f"{camera} {n} points")
+    ok2, c2, _ = cost(x, want_grad=False)
+    assert ok2 and c2 == c
+    cost.close()
+    max_fov = oracle_lib.estimate_camera_fov(s.model, s.intrinsics, s.distortion, s.width, s.height)
+    calc = nid.CostCalculatorNID(proj, s.image_u8, s.points, s.intensities, nid.NIDCostParams(256), max_fov=max_fov)
+    T = se3.to_matrix(x)
+    rc, rh = oracle_lib.cost_calculator_nid(s.model, s.intrinsics, s.distortion, s.image_u8, s.points, s.intensities, 256, max_fov, T, want_hist=True)
+    cn = calc.calculate(T)
+    fx, inl, frac = calc.histogram_fixed()
+    assert frac == 0 and np.array_equal(fx, rh) and int(fx.sum()) == inl and abs(cn - rc) <= 1e-12
+    calc.close()
+
+
+@pytest.mark.parametrize("shards", [2, 3])
+def test_equirect_pair_sharded_at_a_million_points(shards):
+    """configs[2]'s shape -- one equirectangular pair cut over several GPUs -- with the shards co-located on the one GPU of the
+    test box, at 1.5M points (every shard holds whole column groups of a 360-degree cloud): the set's cost is the plain handle's
+    bit for bit, cost / gradient / histogram meet the oracle's bars."""
+    import torch
+
+    s = synth.make_scene("equirect_2k", num_points=1_500_000, seed=20250523 + 3, device="cuda:0" if torch.cuda.is_available() else "cpu")
+    proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
+    rng = np.random.default_rng(5)
+    poses = [synth.random_pose_near(s.T_camera_lidar_true, rng) for _ in range(3)]
+    plain = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, 256)
+    sharded = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, 256, devices=[0] * shards)
+    assert sharded.info()["num_points"] == 1_500_000
+    ref = oracle_nid(s, 256, poses[0], want_hist=True, threads=oracle_lib.num_threads())
+    for k, x in enumerate(poses):
+        okp, cp, gp = plain(x)
+        oks, cs, gs = sharded(x)
+        assert okp and oks and cs == cp, (k, cs, cp)
+        assert np.allclose(gs, gp, rtol=1e-11, atol=1e-14)
+        assert np.array_equal(sharded.histogram_fixed()[0], plain.histogram_fixed()[0])
+        if k == 0:
+            parity.check_cost(cs, ref["cost"], what=f"equirect {shards} shards")
+            parity.check_grad(gs, ref["grad"], what=f"equirect {shards} shards")
+            parity.check_hist(sharded.histograms()[0], ref["hist"], atol=parity.hist_atol_for(ref["hist"], sharded.info()["frac_bits"]), what=f"equirect {shards} shards")
+        okc, cc, _ = sharded(x, want_grad=False)
+        assert okc and cc == cp
+    sharded.close()
+    plain.close()
+
+
+def test_eight_fisheye_pairs_as_one_grid_match_the_summed_oracle():
+    """configs[3]'s shape on ONE GPU: eight fisheye pairs (8 x 600k points, 1920 x 1080, 256 bins) through MultiNIDCost -- a single
+    grid per pass over all pairs -- against the sum of the oracle's eight costs / gradients (visual_camera_calibration.cpp:166-170),
+    and every pair's own cost against its oracle."""
+    import torch
+
+    dev = "cuda:0" if torch.cuda.is_available() else "cpu"
+    scenes = [synth.make_scene("fisheye_1080p", num_points=600_000, seed=20250523 + 40 + k, device=dev) for k in range(8)]
+    proj = nid.create_camera(scenes[0].model, scenes[0].intrinsics, scenes[0].distortion)
+    x = synth.random_pose_near(scenes[0].T_camera_lidar_true, np.random.default_rng(3), dt=0.02, drot_deg=0.2)
+    handles = [nid.NIDCost(proj, sc.image_f64, sc.points, sc.intensities, 256) for sc in scenes]
+    multi = nid.MultiNIDCost(None)
+    for h in handles:
+        multi.add(h)
+    refs = [oracle_nid(sc, 256, x, threads=oracle_lib.num_threads()) for sc in scenes]
+    ok, c, g = multi(x)
+    assert ok and all(r["ok"] for r in refs)
+    parity.check_cost(c, sum(r["cost"] for r in refs), atol=8 * parity.COST_ATOL, what="8 fisheye pairs, one grid")
+    parity.check_grad(g, sum(r["grad"] for r in refs), atol=8 * parity.GRAD_ATOL, what="8 fisheye pairs, one grid")
+    for h, r in zip(handles, refs):
+        okh, ch, gh = h(x)
+        assert okh
+        parity.check_cost(ch, r["cost"], what="fisheye pair of the 8")
+        parity.check_grad(gh, r["grad"], what="fisheye pair of the 8")
+    for h in handles:
+        h.close()
+
+
 def test_nearest_twin_10m_points_bit_exact():
     """CostCalculatorNID::calculate (cost_calculator_nid.cpp:21-67) on the headline cloud: the integer joint histogram of
     10M points bit for bit against the oracle's serial loop (~1 s of CPU), NID to 1e-12."""
@@ -1161,6 +1257,24 @@ def test_submit_wait_matches_synchronous_evaluation():
     oks, cs, gs = sharded.wait(t)
     okp, cp, gp = plain(poses[0])
     assert oks and okp and cs == cp and np.allclose(gs, gp, rtol=1e-11, atol=1e-14)
+    # eight tickets outstanding and the pipelined batch on handles whose submit evaluates synchronously (a sharded handle bumps
+    # its leader's sequence number itself, a timing handle is evaluated in place): tickets come from a counter of their own, so
+    # the ring of eight holds eight (they ran 1, 3, 5, ... and collided at the fifth)
+    ok_s, c_s, g_s = plain.eval_batch(poses)
+    timed = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, 256)
+    timed.set_timing(True)
+    for hnd, exact in ((sharded, False), (timed, True)):
+        tickets = [hnd.submit(x) for x in poses[:8]]
+        with pytest.raises(RuntimeError):
+            hnd.submit(poses[8])
+        for k in reversed(range(8)):
+            ok, c, g = hnd.wait(tickets[k])
+            assert ok and c == c_s[k]
+            assert np.array_equal(g, g_s[k]) if exact else np.allclose(g, g_s[k], rtol=1e-11, atol=1e-14)
+        ok_p, c_p, g_p = hnd.eval_batch(poses, pipelined=True)
+        assert ok_p == ok_s and np.array_equal(c_p, c_s)
+        assert np.array_equal(g_p, g_s) if exact else np.allclose(g_p, g_s, rtol=1e-11, atol=1e-14)
+    timed.close()
     sharded.close()
     plain.close()
 

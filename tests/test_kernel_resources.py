@@ -60,9 +60,10 @@ def test_no_spline_kernel_uses_scratch(kernel_metadata):
             # few registers in scratch outside the point loop
             assert m["vgpr_spill"] <= 8 and m["scratch"] <= 64, (name, m)
         elif looped:
-            # the looped (SEG) instantiations on float records are compiled for four waves per SIMD and may park one or two
-            # registers in scratch OUTSIDE the point loop (checked below); the double-record ones are left alone
-            assert m["vgpr_spill"] <= 2 and m["scratch"] <= 16, (name, m)
+            # the looped (SEG) instantiations on float records are compiled for four waves per SIMD and may park a few
+            # registers in scratch OUTSIDE the point loop (checked below: round 5's omnidir multi-pair kernel parks three, around
+            # the segment loop's head, tail and the reduction); the double-record ones are left alone
+            assert m["vgpr_spill"] <= 4 and m["scratch"] <= 16, (name, m)
         else:
             # the straight-line kernels (every table whose chunks lie inside one column group: the headline) are those of round 3
             assert m["vgpr_spill"] == 0 and m["scratch"] == 0, (name, m)

@@ -7,7 +7,8 @@ ARGS="$@"
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/pmc_$TAG
 mkdir -p $OUT
-[ -f /tmp/scene.npz ] || python $REPO/tools/make_scene_cache.py /tmp/scene.npz > $OUT/make_scene.log 2>&1
+SCENE=${SCENE_NPZ:-/tmp/scene.npz}   # SCENE_NPZ / SCENE_CAMERA / SCENE_POINTS / SCENE_SEED: another cached scene (tools/round_pass.sh pmc:<camera>:<points>)
+[ -f $SCENE ] || python $REPO/tools/make_scene_cache.py $SCENE ${SCENE_CAMERA:-pinhole_1080p} ${SCENE_POINTS:-10000000} ${SCENE_SEED:-20250525} > $OUT/make_scene.log 2>&1
 DRIVER=${PMC_DRIVER:-run_scene.py}   # PMC_DRIVER=run_scene_nearest.py: the NEAREST twin
 export RUN_SCENE_QUICK=1
 cd /tmp && export TMPDIR=/tmp
@@ -15,7 +16,7 @@ PASSES=${PMC_PASSES:-fetch write sq1 sq2 sq3 tcc tcp}  # PMC_PASSES="fetch write
 run() { # name, counters...
   NAME=$1; shift
   case " $PASSES " in *" $NAME "*) ;; *) return;; esac
-  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$NAME -- python $REPO/tools/$DRIVER /tmp/scene.npz 6 $ARGS > $OUT/$NAME.log 2>&1
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$NAME -- python $REPO/tools/$DRIVER $SCENE 6 $ARGS > $OUT/$NAME.log 2>&1
   echo "$NAME rc=$?"
 }
 run fetch FETCH_SIZE
