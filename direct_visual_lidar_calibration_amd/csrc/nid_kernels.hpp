@@ -263,20 +263,24 @@ __device__ __forceinline__ void set_progress_priority(bool on, uint32_t done, ui
 #endif
 }
 
-// ---- one pair spread over several GPUs (protocol: see the k_entropy_owned section below)
+// ---- one pair spread over several GPUs (protocol: see the k_entropy_repl section below)
 constexpr int kMaxShards = 16;
+constexpr int kShardBlockFlags = 256;  // one flag per entropy column block (at most B / 1 = 256 of them)
 struct ShardTable {            // device-resident, one per shard, constant over the set's lifetime
-  u64* flags[kMaxShards];      // flag block of every shard: [2][kMaxShards] words, [phase][source shard]
-  u64* gather[kMaxShards];     // gather block of every shard (layout below)
+  u64* flags[kMaxShards];      // flag block of every shard (fine-grained): [kShardBlockFlags] "column block j has arrived", then the
+                               // self-test's [2][kMaxShards] words
+  u64* gather[kMaxShards];     // gather block of every shard (fine-grained): the self-test's payload words
+  u64* hist[kMaxShards][2];    // both histogram buffers of every shard (fine-grained): an owner stores its columns into all of them
   int n, me;
-  int col_lo, col_hi;          // histogram columns this shard owns
+  int col_lo, col_hi;          // histogram columns this shard owns (= cut[me], cut[me + 1])
+  int cut[kMaxShards + 1];     // shard g owns the columns [cut[g], cut[g + 1]); every cut is a multiple of CB
+  int CB;                      // columns per entropy block
 };
-// gather block (64-bit words)
 constexpr int kGatherS = 0;                      // [kMaxShards] inlier count of shard g
-constexpr int kGatherHj = kMaxShards;            // [kMaxShards] fixed-point entropy partial of shard g
-constexpr int kGatherRows = 2 * kMaxShards;      // [kMaxShards][B] row sums over shard g's columns
-__host__ __device__ __forceinline__ int gather_cols(int B) { return 2 * kMaxShards + kMaxShards * B; }  // [B] column sums (each written by its owner)
-__host__ __device__ __forceinline__ int gather_words(int B) { return gather_cols(B) + B; }
+constexpr int kGatherTest = kMaxShards;          // [kMaxShards] self-test payload
+constexpr int kGatherWords = 2 * kMaxShards;
+constexpr int kFlagTest = kShardBlockFlags;      // [2][kMaxShards] self-test flags
+constexpr int kFlagWords = kShardBlockFlags + 2 * kMaxShards;
 
 __device__ __forceinline__ u64 load_sys(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void store_sys(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
@@ -290,20 +294,26 @@ __device__ __forceinline__ bool wait_flag(const u64* p, u64 seq, unsigned long l
   }
   return true;
 }
-
-// the histogram kernels' last workgroup: S_g to every shard, then flag 0.  Called by thread 0 of every workgroup AFTER its
-// own inlier-count atomic (only that word is published here; the tile flushes of the other waves may still be in flight).
-__device__ __forceinline__ void shard_announce(const ShardTable* tab, u64 seq, unsigned int* ticket, const u64* inlier_word) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (t != gridDim.x - 1u) return;
-  __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const u64 S = __hip_atomic_load(inlier_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const int n = tab->n, me = tab->me;
-  for (int q = 0; q < n; q++) store_sys(tab->gather[q] + kGatherS + me, S);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  for (int q = 0; q < n; q++) store_sys(&tab->flags[q][0 * kMaxShards + me], seq);
+// A column block's flag word: low half = the evaluation's sequence number, high half = a payload that rides on it (the
+// owning shard's inlier count on its first block: it arrives WITH the flag instead of behind a second load).  Polls back to
+// back; the wall clock (a scalar memory read of its own) is looked at every 64th poll only.
+__device__ __forceinline__ u64 block_flag(u64 seq, u64 payload) { return (payload << 32) | (seq & 0xffffffffull); }
+__device__ __forceinline__ bool wait_block_flag(const u64* p, u64 seq, unsigned long long timeout_ticks, u64* payload) {
+  const uint32_t want = uint32_t(seq);
+  u64 w = load_sys(p);
+  if (uint32_t(w) != want) {
+    const unsigned long long t0 = wall_clock64();
+    for (unsigned spins = 1;; spins++) {
+      w = load_sys(p);
+      if (uint32_t(w) == want) break;
+      if ((spins & 63u) == 0) {
+        if (wall_clock64() - t0 > timeout_ticks) return false;
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+  }
+  *payload = w >> 32;
+  return true;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -535,7 +545,7 @@ constexpr int hist_min_waves(int, bool, bool, bool) { return 1; }
 template <int MODEL, typename Rec, typename real, bool WIDE, bool MULTI, bool SEG>
 __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads, hist_min_waves(MODEL, WIDE, SEG, sizeof(Rec) == sizeof(Rec32))) void k_spline_hist(
   const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint32_t* __restrict__ gend, const uint8_t* __restrict__ img, int pitch, int W, int H, PoseParams<real> pose, CamParams<real> cam, int B,
-  int GW, int cshift, double dn_scale, u64* __restrict__ hist, int prio, const ShardTable* __restrict__ ann, u64 ann_seq, unsigned int* ann_ticket,
+  int GW, int cshift, double dn_scale, u64* __restrict__ hist, int prio,
   const MultiEntry* __restrict__ multi, typename multi_dyn_of<MULTI>::type dyn) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int kT = WIDE ? kWideThreads : kThreads;
@@ -550,8 +560,6 @@ __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads, hist_min_waves(MODE
     dn_scale = e.k16;
   }
   spline_hist_body<MODEL, Rec, real, WIDE, SEG, kT>(pts, ch, gend, img, pitch, W, H, pose, cam, B, GW, cshift, dn_scale, hist, smem, prio != 0);
-  // a shard of a pair spread over several GPUs: the last workgroup sends this shard's inlier count to every shard
-  if (!MULTI && ann && threadIdx.x == 0) shard_announce(ann, ann_seq, ann_ticket, hist + size_t(WIDE ? 256 : B) * size_t(WIDE ? 256 : B) + kTailInliers);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -595,7 +603,7 @@ constexpr int nearest_min_waves(int model, bool is_double, bool rec32, bool seg)
 template <int MODEL, typename Rec, typename real, bool MULTI, bool SEG>
 __global__ __launch_bounds__(kThreads, nearest_min_waves(MODEL, std::is_same<real, double>::value, sizeof(Rec) == sizeof(Rec32), SEG)) void k_nearest_hist(
   const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint32_t* __restrict__ gend, const uint8_t* __restrict__ img, int pitch, int W, int H, IsoParams<real> iso,
-  CamParams<real> cam, int B, int GW, int cshift, real cos_fov, NearestFast fast, u64* __restrict__ hist, const ShardTable* __restrict__ ann, u64 ann_seq, unsigned int* ann_ticket,
+  CamParams<real> cam, int B, int GW, int cshift, real cos_fov, NearestFast fast, u64* __restrict__ hist,
   const MultiEntry* __restrict__ multi, typename multi_dyn_of<MULTI>::type dyn) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* tile = reinterpret_cast<uint32_t*>(smem);
@@ -736,7 +744,6 @@ __global__ __launch_bounds__(kThreads, nearest_min_waves(MODEL, std::is_same<rea
   if ((tid & 63) == 0 && winl) atomicAdd(s_inl, winl);
   __syncthreads();
   if (tid == 0 && *s_inl) atomicAdd(&hist[size_t(B) * size_t(B) + kTailInliers], u64(*s_inl));
-  if (!MULTI && ann && tid == 0) shard_announce(ann, ann_seq, ann_ticket, hist + size_t(B) * size_t(B) + kTailInliers);
 }
 
 // nid_cost.hpp:86-104 from the three entropies (fixed point, see ent_fixed) and the inlier count: NID = (Hj - MI) / Hj,
@@ -933,90 +940,152 @@ __global__ __launch_bounds__(kEntropyThreads) void k_entropy(
 // ------------------------------------------------------------------------------------------
 // One pair spread over several GPUs by ONE host process (nidreg.hip ShardSet): the points are partitioned by
 // their pose-independent histogram column -- GPU g owns a contiguous range of column groups, balanced by their point
-// counts -- so the shards' joint histograms have DISJOINT support and nothing of the B x B table ever crosses a link.
-// What the NID needs from the other GPUs is: the total inlier count S (inside the logarithm: p = h / S), then per shard
-// one fixed-point entropy partial, the B row sums of its columns (hist_image is a sum over ALL columns) and the column
-// sums of its columns -- an all-gather of (2 + B + B/n) words, pushed straight into every peer's fine-grained gather block:
-//   k_*_hist            last workgroup (ticket): S_g -> every peer, then flag 0
-//   k_entropy_owned     waits for every flag 0; sum p log(p + eps) and row sums over the OWNED columns; last workgroup:
-//                       pushes the partials to every peer, then flag 1
-//   k_entropy_gather    one workgroup: waits for every flag 1; entropy tail on the gathered partials (integer sums: every
-//                       shard computes the same three entropies, hence the same cost, bit for bit) -> scalars for k_spline_grad
-//   k_spline_grad       the shard's own points against its own columns of G; the host adds the n gradient partials.
-// Every in-kernel wait is for something a kernel launched EARLIER (in the set's launch order) produces, and the host
-// serialises the sets of a process per device: no circular wait (nidreg.hip set_eval).  Waits are bounded by the wall clock:
-// a lost peer becomes an error code, not a hung GPU.
-// a shard without points launches no histogram kernel: announce S_g = 0
-__global__ void k_shard_announce(const ShardTable* tab, u64 seq) {
-  if (threadIdx.x != 0) return;
-  const int n = tab->n, me = tab->me;
-  for (int q = 0; q < n; q++) store_sys(tab->gather[q] + kGatherS + me, u64(0));
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  for (int q = 0; q < n; q++) store_sys(&tab->flags[q][0 * kMaxShards + me], seq);
-}
+// counts -- so the shards' joint histograms have DISJOINT support: the "all-reduce of the 2-D histogram" is an all-gather of
+// columns, and since no two shards write the same word it needs no reduction at all -- plain stores.
+//
+// Round 5: ONE exchange per evaluation (replicated histogram).  Rounds 3-4 kept the B x B table at home and exchanged
+// (2 + B + B/n) words of partial sums instead -- but the inlier count S sits inside every logarithm (p = h / S), so that took
+// TWO dependent exchanges (S first, then the partials) and two more kernels; their round trips were the whole protocol cost
+// (32 -> 50-55 us per evaluation at 2-3 shards, profiles/r04k_shard_phases.json).  Now every shard holds a replica of the whole
+// integer histogram (fine-grained device memory, mapped into every peer):
+//   k_*_hist          the shard's own points into its own columns of its own replica (as an unsharded handle does)
+//   k_entropy_repl    one workgroup per block of CB columns, as k_entropy.  PUSH: the workgroups whose block this shard owns
+//                     store the block (B x CB words) and its column sums into every peer's replica, then raise that block's
+//                     flag at every peer; the flag of a shard's first block carries the shard's inlier count S_g.
+//                     REDUCE: every workgroup waits for its block's flag (nothing to wait for when it owns the block) and for
+//                     the first flag of every shard (S = sum S_g), then does exactly what k_entropy does on the local replica.
+//                     B^2 (n - 1) / n words leave every GPU (458 KB at B = 256, n = 8: 64 KB per link), one flag per block.
+//   k_spline_grad     unchanged: the entropy tail in its prologue, the shard's points against its own columns of G.
+// Every shard computes the cost from the same integers -- bit-identical, which the host CHECKS after every evaluation.
+// Shards on different devices run PUSH | REDUCE as one launch: the owners never wait before they push, so the waits of one
+// device only depend on kernels that are already running on the others.  Shards that share a device (a 1-GPU box exercising
+// the protocol) may share an in-order hardware queue: there the host launches PUSH for every shard, then REDUCE for every
+// shard -- every wait then targets a kernel launched earlier.  Waits are bounded by the wall clock: a lost peer becomes an
+// error code, not a hung GPU.
 
 // NIDREG_SHARD_SELFTEST=1 (creation-time check of a set's exchange paths, before the first evaluation could hang on them):
 // one ordered pair of shards at a time.  `ping` (on shard a's device) writes a pattern into b's gather block, releases, raises
-// b's flag [0][a] and waits for b's answer in its own flag [1][b]; `pong` (on b's device) waits for the flag, checks that the
-// pattern is visible behind it, answers.  out[0] = 1 ok / 2 flag wait timed out / 3 payload not visible behind the flag;
-// out[1] (ping) = round trip in ticks of the 100 MHz wall clock.
+// b's test flag [0][a] and waits for b's answer in its own test flag [1][b]; `pong` (on b's device) waits for the flag, checks
+// that the pattern is visible behind it, answers.  out[0] = 1 ok / 2 flag wait timed out / 3 payload not visible behind the
+// flag; out[1] (ping) = round trip in ticks of the 100 MHz wall clock.
 __global__ void k_shard_selftest_ping(const ShardTable* tab, int peer, u64 seq, u64 pattern, u64* out, unsigned long long timeout_ticks) {
   if (threadIdx.x != 0) return;
   const int me = tab->me;
   const unsigned long long t0 = wall_clock64();
-  store_sys(tab->gather[peer] + kGatherHj + me, pattern);
+  store_sys(tab->gather[peer] + kGatherTest + me, pattern);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  store_sys(&tab->flags[peer][0 * kMaxShards + me], seq);
-  const bool ok = wait_flag(&tab->flags[me][1 * kMaxShards + peer], seq, timeout_ticks);
+  store_sys(&tab->flags[peer][kFlagTest + 0 * kMaxShards + me], seq);
+  const bool ok = wait_flag(&tab->flags[me][kFlagTest + 1 * kMaxShards + peer], seq, timeout_ticks);
   out[1] = wall_clock64() - t0;
   out[0] = ok ? 1 : 2;
 }
 __global__ void k_shard_selftest_pong(const ShardTable* tab, int peer, u64 seq, u64 pattern, u64* out, unsigned long long timeout_ticks) {
   if (threadIdx.x != 0) return;
   const int me = tab->me;
-  const bool ok = wait_flag(&tab->flags[me][0 * kMaxShards + peer], seq, timeout_ticks);
+  const bool ok = wait_flag(&tab->flags[me][kFlagTest + 0 * kMaxShards + peer], seq, timeout_ticks);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-  const u64 seen = load_sys(tab->gather[me] + kGatherHj + peer);
-  store_sys(&tab->flags[peer][1 * kMaxShards + me], seq);
+  const u64 seen = load_sys(tab->gather[me] + kGatherTest + peer);
+  store_sys(&tab->flags[peer][kFlagTest + 1 * kMaxShards + me], seq);
   out[0] = !ok ? 2 : (seen == pattern ? 1 : 3);
 }
 
-// entropy partials over the OWNED columns (k_entropy's thread layout: 16 columns per 1024-thread workgroup), pushed to
-// every shard by the last workgroup.  err_out / err_host: set to `seq` when a flag wait times out.
-__global__ __launch_bounds__(kEntropyThreads) void k_entropy_owned(
-  const u64* __restrict__ hist, int B, double inv_unit, const ShardTable* __restrict__ tab, u64 seq, long long* part_hj, u64* row_part, unsigned int* counter,
-  u64* __restrict__ zero_buf, long long zero_words, double* err_out, double* err_host, unsigned long long timeout_ticks) {
-  __shared__ long long s_red[kEntropyWaves];
+enum { SHARD_PUSH = 1, SHARD_REDUCE = 2 };
+// k_entropy for a shard of a replicated histogram (thread layout, partial sums and tail are k_entropy's; see above).
+// hist = this shard's replica of the current evaluation (= tab->hist[me][cur]); err_out / err_host: set to `seq` when a wait
+// timed out.
+__global__ __launch_bounds__(kEntropyThreads) void k_entropy_repl(
+  u64* __restrict__ hist, int B, double inv_unit, const ShardTable* __restrict__ tab, u64 seq, int cur, int role, double* phi_q, double* hist_image_out, double* hist_points_out,
+  EntropyScalars* scal, double* out, double* out_host, double tag, unsigned int* counter, u64* __restrict__ zero_buf, long long zero_words, int tail, double* err_out, double* err_host,
+  unsigned long long timeout_ticks) {
+  __shared__ long long s_red[3 * kEntropyWaves];
   __shared__ u64 s_row[3][256];
   __shared__ int s_flag;
   __shared__ int s_bad;
   const int tid = threadIdx.x;
   const int j = blockIdx.x, nblocks = int(gridDim.x);
-  const int n = tab->n, me = tab->me;
-  if (tid == 0) s_bad = 0;
-  __syncthreads();
-  if (tid < n && !wait_flag(&tab->flags[me][0 * kMaxShards + tid], seq, timeout_ticks)) s_bad = 1;
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-  u64 Sn = 0;
-  for (int g = 0; g < n; g++) Sn += load_sys(tab->gather[me] + kGatherS + g);
-  const double S = double(Sn);
-  // double-buffered histogram: clear the buffer the NEXT evaluation accumulates into
-  if (zero_buf)
-    for (long long k = (long long)j * kEntropyThreads + tid; k < zero_words; k += (long long)nblocks * kEntropyThreads) zero_buf[k] = 0;
+  const int n = tab->n, me = tab->me, CB = tab->CB;
+  const int c0 = j * CB;
+  const int ncols = min(CB, B - c0);
+  int owner = 0;
+  while (owner + 1 < n && c0 >= tab->cut[owner + 1]) owner++;  // the last shard whose range starts at or before c0 (empty ranges are skipped)
+  const bool mine = owner == me;
   const int r = tid & 255, q = tid >> 8;
-  const int c0 = tab->col_lo + j * kEntropyColsMax;
-  const int ncols = min(kEntropyColsMax, tab->col_hi - c0);
-  constexpr int kPer = kEntropyColsMax / (kEntropyThreads / 256);
+  constexpr int kPer = kEntropyColsMax / (kEntropyThreads / 256);  // columns per thread
+  const size_t tail_at = size_t(B) * size_t(B);
   u64 v[kPer];
 #pragma unroll
-  for (int c = 0; c < kPer; c++) {
-    const int col = q * kPer + c;
-    v[c] = (r < B && col < ncols) ? hist[size_t(c0 + col) * size_t(B) + r] : 0;
+  for (int c = 0; c < kPer; c++) v[c] = 0;
+  if (mine) {
+#pragma unroll
+    for (int c = 0; c < kPer; c++) {
+      const int col = q * kPer + c;
+      if (r < B && col < ncols) v[c] = hist[size_t(c0 + col) * size_t(B) + r];  // accumulated by this shard's histogram kernel (device-scope atomics)
+    }
   }
-  const double scale = inv_unit / S;
+  if ((role & SHARD_PUSH) && mine) {
+    for (int p = 0; p < n; p++) {
+      if (p == me) continue;
+      u64* dst = tab->hist[p][cur];
+#pragma unroll
+      for (int c = 0; c < kPer; c++) {
+        const int col = q * kPer + c;
+        if (r < B && col < ncols) store_sys(dst + size_t(c0 + col) * size_t(B) + r, v[c]);
+      }
+      if (tid < ncols) store_sys(dst + tail_at + kTailWords + c0 + tid, hist[tail_at + kTailWords + c0 + tid]);  // the block's column sums (the flush's)
+    }
+    // the shard's first block carries its inlier count, in the flag word itself -- to every shard, itself included
+    const u64 Sg = (tid == 0 && c0 == tab->col_lo) ? hist[tail_at + kTailInliers] : 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's stores have been performed at system scope
+    __syncthreads();
+    if (tid == 0) {
+#ifdef NID_SHARD_LIGHT_FENCE  // (A/B: every payload word above is a write-through system-scope store that has been waited for)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#else
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      const u64 word = block_flag(seq, Sg);
+      for (int p = 0; p < n; p++) store_sys(&tab->flags[p][j], word);
+    }
+  }
+  if (!(role & SHARD_REDUCE)) return;
+  __shared__ u64 s_S[kMaxShards];
+  if (tid == 0) s_bad = 0;
+  __syncthreads();
+  // wave 0: the first block of every shard that owns columns (its inlier count rides on the flag); wave 1: this block
+  if (tid < n) {
+    u64 Sg = 0;
+    if (tab->cut[tid] < tab->cut[tid + 1] && !wait_block_flag(&tab->flags[me][tab->cut[tid] / CB], seq, timeout_ticks, &Sg)) s_bad = 1;
+    s_S[tid] = Sg;
+  } else if (tid == 64 && !mine) {
+    u64 unused;
+    if (!wait_block_flag(&tab->flags[me][j], seq, timeout_ticks, &unused)) s_bad = 1;
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  if (s_bad && tid == 0) {
+    *err_out = double(seq);
+    if (err_host) *err_host = double(seq);
+  }
+  u64 Sn = 0;
+  for (int g = 0; g < n; g++) Sn += s_S[g];
+  const double S = double(Sn);
+  // the whole pair's inlier count where k_spline_grad's prologue / the tail / the getters look for it (this shard's own count
+  // was read by its first block before that block raised the flag waited for above)
+  if (j == 0 && tid == 0) hist[tail_at + kTailInliers] = Sn;
+  // double-buffered histogram: clear the replica the NEXT evaluation accumulates into (the peers write into it only after the
+  // host has collected this evaluation from every shard)
+  if (zero_buf)
+    for (long long k = (long long)j * kEntropyThreads + tid; k < zero_words; k += (long long)nblocks * kEntropyThreads) zero_buf[k] = 0;
+  if (!mine) {
+#pragma unroll
+    for (int c = 0; c < kPer; c++) {
+      const int col = q * kPer + c;
+      if (r < B && col < ncols) v[c] = load_sys(hist + size_t(c0 + col) * size_t(B) + r);  // stored by the block's owner
+    }
+  }
+  const double scale = inv_unit / S;  // fixed-point word -> probability
   long long acc = 0;
   u64 row = 0;
 #pragma unroll
@@ -1035,64 +1104,19 @@ __global__ __launch_bounds__(kEntropyThreads) void k_entropy_owned(
     u64 t = row;
 #pragma unroll
     for (int i = 0; i < kEntropyThreads / 256 - 1; i++) t += s_row[i][r];
-    row_part[size_t(j) * size_t(B) + r] = t;
+    if (t) atomicAdd(&hist[hist_row_sums_at(B) + size_t(r)], t);
   }
   if (tid < 64) {
     const long long t = wave_sum(tid < kEntropyWaves ? s_red[tid] : 0ll);
-    if (tid == 0) part_hj[j] = t;
+    if (tid == 0 && t) atomicAdd(&hist[tail_at + kTailHj], u64(t));
   }
-  if (s_bad && tid == 0) {
-    *err_out = double(seq);
-    if (err_host) *err_host = double(seq);
-  }
-  if (!last_workgroup_arrives<false>(counter, unsigned(nblocks), &s_flag)) return;
-  // the last workgroup: this shard's totals -> every shard's gather block
-  const u64* col_sum = hist + size_t(B) * size_t(B) + kTailWords;
-  if (tid < B) {
-    u64 t = 0;
-    for (int g = 0; g < nblocks; g++) t += row_part[size_t(g) * size_t(B) + tid];
-    for (int p = 0; p < n; p++) store_sys(tab->gather[p] + kGatherRows + me * B + tid, t);
-    if (tid >= tab->col_lo && tid < tab->col_hi) {
-      const u64 cs = col_sum[tid];
-      for (int p = 0; p < n; p++) store_sys(tab->gather[p] + gather_cols(B) + tid, cs);
-    }
-  }
-  if (tid == 0) {
-    long long t = 0;
-    for (int g = 0; g < nblocks; g++) t += part_hj[g];
-    for (int p = 0; p < n; p++) store_sys(tab->gather[p] + kGatherHj + me, u64(t));
-  }
+  if (!tail) return;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (int p = 0; p < n; p++) store_sys(&tab->flags[p][1 * kMaxShards + me], seq);
+  if (last_workgroup_arrives<true>(counter, unsigned(nblocks), &s_flag)) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // the other blocks' column sums were stored by their owners on other devices
+    entropy_final_body(S, B, 1, inv_unit, reinterpret_cast<const long long*>(hist + tail_at + kTailHj), hist + hist_row_sums_at(B), hist + tail_at + kTailWords, phi_q, hist_image_out,
+                       hist_points_out, scal, out, out_host, tag, s_red);
   }
-}
-
-// entropy tail on the gathered partials: every shard runs it on the same integers
-__global__ __launch_bounds__(kThreads) void k_entropy_gather(
-  int B, double inv_unit, const ShardTable* __restrict__ tab, u64 seq, double* phi_q, double* hist_image_out, double* hist_points_out, EntropyScalars* scal, double* out,
-  double* out_host, double tag, double* err_out, double* err_host, unsigned long long timeout_ticks) {
-  __shared__ long long s_red[3 * kWaves];
-  __shared__ int s_bad;
-  const int tid = threadIdx.x;
-  const int n = tab->n, me = tab->me;
-  if (tid == 0) s_bad = 0;
-  __syncthreads();
-  if (tid < n && !wait_flag(&tab->flags[me][1 * kMaxShards + tid], seq, timeout_ticks)) s_bad = 1;
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-  if (s_bad && tid == 0) {
-    *err_out = double(seq);
-    if (err_host) *err_host = double(seq);
-  }
-  const u64* gb = tab->gather[me];
-  u64 Sn = 0;
-  for (int g = 0; g < n; g++) Sn += load_sys(gb + kGatherS + g);
-  entropy_final_body(double(Sn), B, n, inv_unit, reinterpret_cast<const long long*>(gb + kGatherHj), gb + kGatherRows, gb + gather_cols(B), phi_q, hist_image_out, hist_points_out, scal,
-                     out, out_host, tag, s_red);
 }
 
 #endif  // NID_COMMON_KERNELS

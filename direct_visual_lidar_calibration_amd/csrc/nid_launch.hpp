@@ -55,10 +55,6 @@ struct PassArgs {
   size_t lds_hist, lds_grad;
   const MultiEntry* multi;  // non-NULL: one grid over several pairs (chunks / nchunks are then the combined table)
   MultiDyn dyn;
-  // a shard of a pair spread over several GPUs (nid_kernels.hpp ShardTable): the histogram kernel's last workgroup announces
-  const ShardTable* ann;
-  unsigned long long ann_seq;
-  unsigned int* ann_ticket;
   // the gradient kernel runs the entropy tail itself (k_entropy launched with tail = 0): nid_kernels.hpp GradTail
   double* gt_phi_q;
   double* gt_hist_image;

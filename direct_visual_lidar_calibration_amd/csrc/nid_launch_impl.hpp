@@ -71,13 +71,13 @@ static hipError_t launch_spline_hist_rec(const PassArgs& a) {
     hipError_t e = ensure_lds(k, a.lds_hist);                                                                                                          \
     if (e != hipSuccess) return e;                                                                                                                     \
     hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(THREADS), a.lds_hist, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.gend, a.img, a.pitch, a.W, a.H, pose, \
-                       cam, a.B, a.GW, a.cshift, a.magic, a.hist, a.prio, a.ann, a.ann_seq, a.ann_ticket, a.multi, a.dyn);                             \
+                       cam, a.B, a.GW, a.cshift, a.magic, a.hist, a.prio, a.multi, a.dyn);                             \
   } else {                                                                                                                                             \
     auto k = k_spline_hist<M, Rec, real, WIDE, false, SEG>;                                                                                            \
     hipError_t e = ensure_lds(k, a.lds_hist);                                                                                                          \
     if (e != hipSuccess) return e;                                                                                                                     \
     hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(THREADS), a.lds_hist, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.gend, a.img, a.pitch, a.W, a.H, pose, \
-                       cam, a.B, a.GW, a.cshift, a.magic, a.hist, a.prio, a.ann, a.ann_seq, a.ann_ticket, a.multi, NoMultiDyn());                      \
+                       cam, a.B, a.GW, a.cshift, a.magic, a.hist, a.prio, a.multi, NoMultiDyn());                      \
   }
   if (a.wide) {  // B = 256, GW = 1, 32 copies, 512 threads (see k_spline_hist)
     if (a.seg) {
@@ -240,13 +240,13 @@ static hipError_t launch_nearest_hist_rec(const PassArgs& a) {
     hipError_t e = ensure_lds(k, a.lds_hist);                                                                                                          \
     if (e != hipSuccess) return e;                                                                                                                     \
     hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(kThreads), a.lds_hist, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.gend, a.img, a.pitch, a.W, a.H, iso, cam,  \
-                       a.B, a.GW, a.cshift, real(a.cos_fov), fast, a.hist, a.ann, a.ann_seq, a.ann_ticket, a.multi, a.dyn);                                                                   \
+                       a.B, a.GW, a.cshift, real(a.cos_fov), fast, a.hist, a.multi, a.dyn);                                                                   \
   } else {                                                                                                                                             \
     auto k = k_nearest_hist<M, Rec, real, false, SEG>;                                                                                                      \
     hipError_t e = ensure_lds(k, a.lds_hist);                                                                                                          \
     if (e != hipSuccess) return e;                                                                                                                     \
     hipLaunchKernelGGL(k, dim3(a.nchunks), dim3(kThreads), a.lds_hist, a.stream, static_cast<const Rec*>(a.pts), a.chunks, a.gend, a.img, a.pitch, a.W, a.H, iso, cam,  \
-                       a.B, a.GW, a.cshift, real(a.cos_fov), fast, a.hist, a.ann, a.ann_seq, a.ann_ticket, a.multi, NoMultiDyn());                                                            \
+                       a.B, a.GW, a.cshift, real(a.cos_fov), fast, a.hist, a.multi, NoMultiDyn());                                                            \
   }
   if (a.seg) {
 #define NID_LAUNCH(M) NID_LAUNCH_N(M, true)

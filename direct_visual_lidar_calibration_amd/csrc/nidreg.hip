@@ -24,6 +24,9 @@
 #include <thread>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and enums only: the library is opened at run time (nidreg_shard_attach_rccl), never linked
+
 #include "../../include/nidreg.h"
 
 using namespace nidreg;
@@ -99,6 +102,10 @@ struct nidreg_handle {
   bool is_shard = false;
   int shard_index = 0;
   ShardTable* d_shard_tab = nullptr;  // device copy of this shard's ShardTable (peer flag / gather blocks, owned columns)
+  // one process per GPU (nidreg_shard_attach_rccl / nidreg_shard_comm_init): this handle holds an index-range slice of the pair,
+  // every evaluation all-reduces the integer histogram (and the 7-double gradient partial) over this communicator
+  void* rccl_comm = nullptr;
+  bool rccl_owned = false;
   int col_lo = 0, col_hi = 0;         // owned histogram columns
   size_t img_bytes = 0;
   // double buffering of the histogram (own buffers only): evaluation k accumulates into one buffer and
@@ -174,17 +181,19 @@ struct Cohort {
 // One LiDAR-camera pair spread over several GPUs (BASELINE north_star: "disjoint point slices with a final all-reduce of the
 // 2D histogram over xGMI"), driven by ONE host process.  The slices are cut along the pose-independent histogram column
 // ("shard by histogram column"): shard g holds the points of a contiguous range of column groups, chosen from
-// the groups' point counts so that the shards are balanced to within one group.  The shards' histograms then have disjoint
-// support, the all-reduce of the B x B table degenerates to an all-gather of (2 + B + B/n) words per shard (inlier count,
-// entropy partial, row sums, column sums; nid_kernels.hpp k_entropy_owned), and the gradient pass of a shard needs only its
-// own columns of G.  Per evaluation every shard runs  histogram (+ inlier-count announce) -> k_entropy_owned ->
-// k_entropy_gather -> gradient  on its own stream, launched by its own host thread (the caller for shard 0), and the host adds
-// the n 7-double gradient partials.  Every shard computes the cost from the same gathered integers: bit-identical, which
-// the host CHECKS after every evaluation (a stale cross-device read cannot go unnoticed).
+// the groups' point counts so that the shards are balanced to within one cut unit.  The shards' histograms then have disjoint
+// support: the all-reduce of the B x B table is an all-gather of columns by plain stores -- every shard keeps a replica of the
+// whole integer histogram in fine-grained memory and the owners of a column block store it into every replica
+// (nid_kernels.hpp k_entropy_repl: ONE exchange per evaluation).  Per evaluation every shard runs  histogram -> k_entropy_repl
+// -> gradient  on its own stream -- the kernels of an unsharded handle with one exchange inside the middle one --, launched by
+// its own host thread (the caller for shard 0), and the host adds the n 7-double gradient partials.  Every shard computes the
+// cost from the same integers: bit-identical, which the host CHECKS after every evaluation (a stale cross-device read cannot
+// go unnoticed).
 struct ShardSet {
   std::vector<nidreg_handle*> shards;  // [0] = the leader (owns this set), the rest are owned by the set
-  std::vector<u64*> flags;             // per shard: fine-grained [2][kMaxShards] flag block on its device
-  std::vector<u64*> gather;            // per shard: fine-grained gather block (gather_words(B))
+  std::vector<u64*> flags;             // per shard: fine-grained flag block on its device (kFlagWords)
+  std::vector<u64*> gather;            // per shard: fine-grained gather block (kGatherWords)
+  int CB = kEntropyCols, nblocks = 0;  // k_entropy_repl: columns per workgroup, workgroups (every cut between shards is a multiple of CB columns)
   std::vector<int> lock_devices;       // distinct devices of the set, ascending: set_eval locks them in this order
   bool colocated = false;              // a device is listed more than once (a 1-GPU box exercising the protocol)
   bool poisoned = false;               // an evaluation failed half way: the flag sequence is no longer trustworthy
@@ -209,6 +218,7 @@ struct ShardSet {
 namespace {
 
 void free_shard_set(ShardSet* set);
+void rccl_release(nidreg_handle* h);
 void drop_groups_of(const nidreg_handle* h);
 void cohort_leave(nidreg_handle* h);
 std::atomic<int> g_inflight[NIDREG_MAX_DEVICES];  // evaluations in flight per device (InflightGuard below)
@@ -313,6 +323,7 @@ void free_handle(nidreg_handle* h) {
   cohort_leave(h);
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  rccl_release(h);
   for (auto& p : h->pending)  // tickets never collected: give their in-flight counts back to the device
     if (p.ticket != 0 && p.counted && h->device >= 0 && h->device < NIDREG_MAX_DEVICES) g_inflight[h->device].fetch_sub(1, std::memory_order_acq_rel);
   if (h->d_pts) (void)hipFree(h->d_pts);
@@ -460,15 +471,10 @@ hipError_t begin_histogram(nidreg_handle* h, hipStream_t stream) {
 }
 hipError_t begin_histogram(nidreg_handle* h) { return begin_histogram(h, h->stream); }
 
-int launch_hist_spline(nidreg_handle* h, const double* se3, bool alone = false, u64 ann_seq = 0) {
+int launch_hist_spline(nidreg_handle* h, const double* se3, bool alone = false) {
   PassArgs a;
   fill_pass_args(h, a);
   a.prio = alone ? 1 : 0;
-  if (ann_seq) {  // a shard of a pair spread over several GPUs: the kernel's last workgroup announces the inlier count
-    a.ann = h->d_shard_tab;
-    a.ann_seq = ann_seq;
-    a.ann_ticket = h->d_counters + 2;
-  }
   if (h->d_chunks_hist) {
     a.chunks = h->d_chunks_hist;
     a.nchunks = h->nchunks_hist;
@@ -523,15 +529,10 @@ NearestFastArgs nearest_fast_args(const nidreg_handle* h, const double* T) {
   return f;
 }
 
-int launch_hist_nearest(nidreg_handle* h, const double* T, u64 ann_seq = 0) {
+int launch_hist_nearest(nidreg_handle* h, const double* T) {
   PassArgs a;
   fill_pass_args(h, a);
   a.nfast = nearest_fast_args(h, T);
-  if (ann_seq) {
-    a.ann = h->d_shard_tab;
-    a.ann_seq = ann_seq;
-    a.ann_ticket = h->d_counters + 2;
-  }
   for (int k = 0; k < 12; k++) a.iso[k] = T[k];
   HIP_TRY(begin_histogram(h));
   a.hist = h->d_hist;
@@ -1210,8 +1211,15 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
   if (d->ext_hist) {
     h->d_hist = static_cast<u64*>(d->ext_hist);
   } else {
-    CREATE_TRY(hipMalloc(&h->d_hist_buf[0], size_t(h->hist_words) * sizeof(u64)));
-    CREATE_TRY(hipMalloc(&h->d_hist_buf[1], size_t(h->hist_words) * sizeof(u64)));
+    if (opts.shard) {
+      // a shard's two buffers are replicas of the WHOLE pair's histogram: the owners of the other columns store into them from
+      // their own devices (nid_kernels.hpp k_entropy_repl) -- fine-grained (coherent) device memory, mapped into every peer
+      CREATE_TRY(hipExtMallocWithFlags(reinterpret_cast<void**>(&h->d_hist_buf[0]), size_t(h->hist_words) * sizeof(u64), hipDeviceMallocFinegrained));
+      CREATE_TRY(hipExtMallocWithFlags(reinterpret_cast<void**>(&h->d_hist_buf[1]), size_t(h->hist_words) * sizeof(u64), hipDeviceMallocFinegrained));
+    } else {
+      CREATE_TRY(hipMalloc(&h->d_hist_buf[0], size_t(h->hist_words) * sizeof(u64)));
+      CREATE_TRY(hipMalloc(&h->d_hist_buf[1], size_t(h->hist_words) * sizeof(u64)));
+    }
     CREATE_TRY(hipMemset(h->d_hist_buf[1], 0, size_t(h->hist_words) * sizeof(u64)));
     h->d_hist = h->d_hist_buf[0];
     h->hist_cur = 0;
@@ -1235,8 +1243,8 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
       off = (off + bytes + 255) & ~size_t(255);
       return at;
     };
-    const size_t o_part_hj = carve(size_t(h->NEB) * sizeof(long long));   // k_entropy_owned: per column block
-    const size_t o_row_part = carve(size_t(h->NEB) * B * sizeof(u64));    // k_entropy_owned: [NEB][B]
+    const size_t o_part_hj = carve(size_t(h->NEB) * sizeof(long long));   // (split-phase ABI scratch: per column block)
+    const size_t o_row_part = carve(size_t(h->NEB) * B * sizeof(u64));    // [NEB][B]
     const size_t o_phi_q = carve(size_t(B) * sizeof(double));
     const size_t o_hist_image = carve(size_t(B) * sizeof(double));
     const size_t o_hist_points = carve(size_t(B) * sizeof(double));
@@ -1918,6 +1926,125 @@ bool can_group(nidreg_handle* const* handles, int n) {
   return true;
 }
 
+// ---- one pair, one process per GPU: the north star's literal form -- "disjoint point slices with a final RCCL all-reduce of
+// the 2D histogram over xGMI" -- inside the library.  Every rank creates a plain handle over ITS slice of the cloud
+// (desc.scale_points = the pair's total point count: the same fixed-point unit on every rank) and attaches a communicator;
+// nidreg_eval / nidreg_eval_iso then run
+//     histogram kernel -> ncclAllReduce(int64, sum; hist_words words in place) -> k_entropy (tail) ->
+//     gradient kernel  -> ncclAllReduce(float64, sum; 7 words of the result block in place)
+// on the handle's stream -- no host synchronisation between the steps.  The histogram is integer, so the all-reduce is exact
+// and order independent: every rank computes the same cost, bit for bit, whatever the ring order.  librccl.so is opened at
+// run time (dlopen; a process that has torch loaded gets the copy torch already mapped): libnidreg.so does not link it and a
+// caller that never attaches a communicator never touches it.
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string error;
+};
+RcclApi* rccl_api() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* names[] = {std::getenv("NIDREG_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* nm : names) {
+      if (!nm || !*nm) continue;
+      api.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+      if (api.lib) break;
+    }
+    if (!api.lib) {
+      const char* e = dlerror();
+      api.error = std::string("cannot open librccl.so (set NIDREG_RCCL_LIB): ") + (e ? e : "?");
+      return;
+    }
+    auto sym = [&](const char* nm) {
+      void* p = dlsym(api.lib, nm);
+      if (!p && api.error.empty()) api.error = std::string("librccl.so has no symbol ") + nm;
+      return p;
+    };
+    api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+    api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+    api.CommCount = reinterpret_cast<decltype(api.CommCount)>(sym("ncclCommCount"));
+    api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
+    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+  });
+  return &api;
+}
+int rccl_fail(const char* what, ncclResult_t r) {
+  RcclApi* api = rccl_api();
+  return fail(NIDREG_ERR_HIP, std::string(what) + ": " + (api->GetErrorString ? api->GetErrorString(r) : "RCCL error"));
+}
+#define RCCL_TRY(expr)                                \
+  do {                                                \
+    const ncclResult_t _r = (expr);                   \
+    if (_r != ncclSuccess) return rccl_fail(#expr, _r); \
+  } while (0)
+
+void rccl_release(nidreg_handle* h) {
+  if (h->rccl_comm && h->rccl_owned) {
+    RcclApi* api = rccl_api();
+    if (api->CommDestroy) (void)api->CommDestroy(static_cast<ncclComm_t>(h->rccl_comm));
+  }
+  h->rccl_comm = nullptr;
+  h->rccl_owned = false;
+}
+
+int rccl_attachable(const nidreg_handle* h, const char* who) {
+  if (!h) return fail(NIDREG_ERR_INVALID, std::string(who) + ": null handle");
+  if (h->set || h->is_shard) return fail(NIDREG_ERR_INVALID, std::string(who) + ": the handle is already sharded inside the library (desc.device_ids / NIDREG_DEVICES)");
+  if (!h->own_hist || !h->own_out) return fail(NIDREG_ERR_INVALID, std::string(who) + ": the handle must own its histogram and result buffers (no ext_hist / ext_out)");
+  if (h->async_outstanding != 0) return fail(NIDREG_ERR_INVALID, std::string(who) + ": collect the handle's outstanding tickets first");
+  return NIDREG_OK;
+}
+
+// one evaluation of a handle with a communicator; mode SPLINE: pose = se3[7], NEAREST: row-major 4x4.  Collective: every rank
+// of the communicator calls it with the same pose.
+int rccl_eval(nidreg_handle* h, int mode, const double* pose, double* cost, double* grad7) {
+  if (h->mode != mode) return fail(NIDREG_ERR_INVALID, mode == NIDREG_MODE_SPLINE ? "nidreg_eval: handle was created in NEAREST mode" : "nidreg_eval_iso: handle was created in SPLINE mode");
+  RcclApi* api = rccl_api();
+  ncclComm_t comm = static_cast<ncclComm_t>(h->rccl_comm);
+  HIP_TRY(hipSetDevice(h->device));
+  InflightGuard guard(h->device);
+  bump_seq(h);
+  const bool grad = mode == NIDREG_MODE_SPLINE && grad7 != nullptr;
+  if (h->timing) HIP_TRY(hipEventRecord(h->ev[0], h->stream));
+  if (h->num_points == 0) {  // a rank without points launches no histogram kernel: its (cleared) buffer still takes part in the sum
+    HIP_TRY(begin_histogram(h));
+    if (mode == NIDREG_MODE_SPLINE) {
+      for (int k = 0; k < 4; k++) h->last_q[k] = pose[k];
+      pose_from_se3(pose, h->last_R, h->last_t);
+    }
+  } else {
+    const int rc = mode == NIDREG_MODE_SPLINE ? launch_hist_spline(h, pose, guard.alone) : launch_hist_nearest(h, pose);
+    if (rc) return rc;
+  }
+  if (h->timing) HIP_TRY(hipEventRecord(h->ev[2], h->stream));
+  RCCL_TRY(api->AllReduce(h->d_hist, h->d_hist, size_t(h->hist_words), ncclInt64, ncclSum, comm, h->stream));
+  int rc = launch_entropy(h, 0.0, true);
+  if (rc) return rc;
+  if (h->timing) HIP_TRY(hipEventRecord(h->ev[3], h->stream));
+  if (grad) {
+    rc = launch_grad(h, guard.alone, 0);
+    if (rc) return rc;
+    RCCL_TRY(api->AllReduce(h->d_out + 1, h->d_out + 1, 7, ncclFloat64, ncclSum, comm, h->stream));
+  } else if (h->timing) {
+    HIP_TRY(hipEventRecord(h->ev[4], h->stream));
+  }
+  if (h->timing) HIP_TRY(hipEventRecord(h->ev[5], h->stream));
+  h->ev_grad = grad;
+  HIP_TRY(hipMemcpyAsync(h->h_out, h->d_out, NIDREG_OUT_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (cost) *cost = h->h_out[0];
+  if (grad)
+    for (int k = 0; k < 7; k++) grad7[k] = h->h_out[1 + k];
+  return h->h_out[8] != 0.0 ? NIDREG_FALSE : NIDREG_OK;
+}
+
 // ---- sharded pairs ----------------------------------------------------------------------------------------------
 
 // NIDREG_DEVICES="0,1,2,3": spread every SPLINE / NEAREST handle over these devices without touching the caller -- this is
@@ -1952,49 +2079,47 @@ bool wants_shards(const nidreg_desc* d) { return !d->ext_hist && !d->ext_out && 
 // set).  One mutex per device, taken in ascending device order.
 std::mutex g_shard_device_mu[NIDREG_MAX_DEVICES];
 
-// one shard's launches of one evaluation, phase by phase (0 histogram, 1 owned entropy, 2 gathered tail, 3 gradient)
+// one shard's launches of one evaluation, phase by phase: 0 histogram; 1 k_entropy_repl (shards on devices of their own: PUSH | REDUCE
+// in one launch; shards that share a device: PUSH only); 2 REDUCE where phase 1 only pushed; 3 gradient
 int shard_launch_phase(ShardSet* set, int g, int phase, bool alone) {
   nidreg_handle* h = set->shards[size_t(g)];
   HIP_TRY(hipSetDevice(h->device));
   const bool grad = set->job_mode == NIDREG_MODE_SPLINE && set->job_grad;
+  const bool grad_runs_tail = grad && h->nchunks > 0;  // (a shard without points has no gradient workgroup to run the entropy tail)
   if (phase == 0) {
     bump_seq(h);
-      h->h_out[10] = 0.0;
+    h->h_out[10] = 0.0;
     if (h->timing) HIP_TRY(hipEventRecord(h->ev[0], h->stream));
-    if (h->nchunks == 0) {  // no points in this shard's columns: no histogram kernel runs, announce S_g = 0
+    if (h->nchunks == 0) {  // no points in this shard's columns: no histogram kernel runs, its columns of the replica stay zero
       HIP_TRY(begin_histogram(h));
-      hipLaunchKernelGGL(k_shard_announce, dim3(1), dim3(64), 0, h->stream, h->d_shard_tab, set->seq);
-      HIP_TRY(hipGetLastError());
       if (set->job_mode == NIDREG_MODE_SPLINE) {
         for (int k = 0; k < 4; k++) h->last_q[k] = set->job_pose[k];
         pose_from_se3(set->job_pose, h->last_R, h->last_t);
       }
     } else {
-      const int rc = set->job_mode == NIDREG_MODE_SPLINE ? launch_hist_spline(h, set->job_pose, alone, set->seq) : launch_hist_nearest(h, set->job_pose, set->seq);
+      const int rc = set->job_mode == NIDREG_MODE_SPLINE ? launch_hist_spline(h, set->job_pose, alone) : launch_hist_nearest(h, set->job_pose);
       if (rc) return rc;
     }
     if (h->timing) HIP_TRY(hipEventRecord(h->ev[2], h->stream));
     return NIDREG_OK;
   }
-  if (phase == 1) {
-    const int ncols = std::max(0, h->col_hi - h->col_lo);
-    const int nblk = std::max(1, (ncols + kEntropyCols - 1) / kEntropyCols);
-    hipLaunchKernelGGL(k_entropy_owned, dim3(nblk), dim3(kEntropyThreads), 0, h->stream, h->d_hist, h->bins, 1.0 / fixed_unit(h), h->d_shard_tab, set->seq, h->d_part_hj, h->d_row_part, h->d_counters,
-                       h->d_hist_buf[h->hist_cur ^ 1], h->hist_words, h->d_out + 10, h->d_out_host ? h->d_out_host + 10 : nullptr, set->timeout_ticks);
+  if (phase == 1 || phase == 2) {
+    const int role = set->colocated ? (phase == 1 ? SHARD_PUSH : SHARD_REDUCE) : (SHARD_PUSH | SHARD_REDUCE);
+    if (phase == 2 && !set->colocated) return NIDREG_OK;
+    const bool reduces = (role & SHARD_REDUCE) != 0;
+    hipLaunchKernelGGL(k_entropy_repl, dim3(set->nblocks), dim3(kEntropyThreads), 0, h->stream, h->d_hist, h->bins, 1.0 / fixed_unit(h), h->d_shard_tab, set->seq, h->hist_cur, role, h->d_phi_q,
+                       h->d_hist_image, h->d_hist_points, h->d_scal, h->d_out, h->d_out_host, grad ? 0.0 : h->seq, h->d_counters, reduces ? h->d_hist_buf[h->hist_cur ^ 1] : nullptr, h->hist_words,
+                       grad_runs_tail ? 0 : 1, h->d_out + 10, h->d_out_host ? h->d_out_host + 10 : nullptr, set->timeout_ticks);
     HIP_TRY(hipGetLastError());
-    h->hist_zeroed[h->hist_cur ^ 1] = true;
-    h->zero_stream = h->stream;
-    return NIDREG_OK;
-  }
-  if (phase == 2) {
-    hipLaunchKernelGGL(k_entropy_gather, dim3(1), dim3(kThreads), 0, h->stream, h->bins, 1.0 / fixed_unit(h), h->d_shard_tab, set->seq, h->d_phi_q, h->d_hist_image, h->d_hist_points, h->d_scal, h->d_out,
-                       h->d_out_host, grad ? 0.0 : h->seq, h->d_out + 10, h->d_out_host ? h->d_out_host + 10 : nullptr, set->timeout_ticks);
-    HIP_TRY(hipGetLastError());
-    if (h->timing) HIP_TRY(hipEventRecord(h->ev[3], h->stream));
+    if (reduces) {
+      h->hist_zeroed[h->hist_cur ^ 1] = true;
+      h->zero_stream = h->stream;
+      if (h->timing) HIP_TRY(hipEventRecord(h->ev[3], h->stream));
+    }
     return NIDREG_OK;
   }
   if (grad) {
-    const int rc = launch_grad(h, alone);  // records ev[4]; an empty shard finalises zeros stand-alone
+    const int rc = launch_grad(h, alone, grad_runs_tail ? 1 : 0);  // records ev[4]; an empty shard finalises zeros stand-alone
     if (rc) return rc;
   } else if (h->timing) {
     HIP_TRY(hipEventRecord(h->ev[4], h->stream));
@@ -2213,9 +2338,30 @@ int create_sharded(const nidreg_desc* d, const nidreg_cloud* cloud, const double
     const int rc = create_impl(&md, cloud, T_cull, min_z, enable_depth, CreateOpts(), &master);
     if (rc) return rc;
   }
-  const std::vector<int> cut = partition_groups(master->gcount, master->NG, n);
+  // every cut between shards is a whole number of k_entropy_repl column blocks: CB columns per block, the largest of 8, 4, 2, 1
+  // that tiles with the column groups (GW columns each) and still leaves every shard a cut unit of its own
+  const int GWm = master->GW, NGm = master->NG;
+  int CB = 1, unit = 1;  // unit = column groups per cut unit
+  for (int cb = kEntropyCols; cb >= 1; cb /= 2) {
+    if (cb % GWm != 0 && GWm % cb != 0) continue;
+    const int u = std::max(1, cb / GWm);
+    if (cb > 1 && (NGm + u - 1) / u < n) continue;
+    CB = cb;
+    unit = u;
+    break;
+  }
+  std::vector<int> cut(size_t(n) + 1, 0);
+  {
+    const int NU = (NGm + unit - 1) / unit;
+    std::vector<int64_t> ucount(size_t(NU) + 1, 0);
+    for (int u = 0; u <= NU; u++) ucount[size_t(u)] = master->gcount[size_t(std::min(NGm, u * unit))];
+    const std::vector<int> ucut = partition_groups(ucount, NU, n);
+    for (int k = 0; k <= n; k++) cut[size_t(k)] = std::min(NGm, ucut[size_t(k)] * unit);
+  }
 
   ShardSet* set = new ShardSet();
+  set->CB = CB;
+  set->nblocks = (B + CB - 1) / CB;
   set->shards.assign(size_t(n), nullptr);
   set->flags.assign(size_t(n), nullptr);
   set->gather.assign(size_t(n), nullptr);
@@ -2265,13 +2411,13 @@ int create_sharded(const nidreg_desc* d, const nidreg_cloud* cloud, const double
       if (rcs[size_t(g)]) return bail(fail(rcs[size_t(g)], "shard " + std::to_string(g) + ": " + errs[size_t(g)]));
   }
   // flag and gather blocks: fine-grained (coherent) device memory, mapped into every peer
-  const size_t gw = size_t(gather_words(B));
+  const size_t gw = size_t(kGatherWords);
   for (int g = 0; g < n; g++) {
     nidreg_handle* h = set->shards[size_t(g)];
     h->shard_index = g;
     hipError_t e = hipSetDevice(h->device);
-    if (e == hipSuccess) e = hipExtMallocWithFlags(reinterpret_cast<void**>(&set->flags[size_t(g)]), 2 * kMaxShards * sizeof(u64), hipDeviceMallocFinegrained);
-    if (e == hipSuccess) e = hipMemset(set->flags[size_t(g)], 0, 2 * kMaxShards * sizeof(u64));
+    if (e == hipSuccess) e = hipExtMallocWithFlags(reinterpret_cast<void**>(&set->flags[size_t(g)]), kFlagWords * sizeof(u64), hipDeviceMallocFinegrained);
+    if (e == hipSuccess) e = hipMemset(set->flags[size_t(g)], 0, kFlagWords * sizeof(u64));
     if (e == hipSuccess) e = hipExtMallocWithFlags(reinterpret_cast<void**>(&set->gather[size_t(g)]), gw * sizeof(u64), hipDeviceMallocFinegrained);
     if (e == hipSuccess) e = hipMemset(set->gather[size_t(g)], 0, gw * sizeof(u64));
     if (e != hipSuccess) return bail(fail(NIDREG_ERR_HIP, std::string("sharded handle: flag / gather block: ") + hipGetErrorString(e)));
@@ -2283,7 +2429,12 @@ int create_sharded(const nidreg_desc* d, const nidreg_cloud* cloud, const double
     for (int p = 0; p < n; p++) {
       tab.flags[p] = set->flags[size_t(p)];
       tab.gather[p] = set->gather[size_t(p)];
+      tab.hist[p][0] = set->shards[size_t(p)]->d_hist_buf[0];
+      tab.hist[p][1] = set->shards[size_t(p)]->d_hist_buf[1];
+      tab.cut[p] = set->shards[size_t(p)]->col_lo;
     }
+    tab.cut[n] = B;
+    tab.CB = set->CB;
     tab.n = n;
     tab.me = g;
     tab.col_lo = h->col_lo;
@@ -2337,7 +2488,7 @@ int create_sharded(const nidreg_desc* d, const nidreg_cloud* cloud, const double
     // flags and payload words back to zero: the evaluations' sequence numbers start at 1
     for (int g = 0; g < n; g++) {
       (void)hipSetDevice(set->shards[size_t(g)]->device);
-      (void)hipMemset(set->flags[size_t(g)], 0, 2 * kMaxShards * sizeof(u64));
+      (void)hipMemset(set->flags[size_t(g)], 0, kFlagWords * sizeof(u64));
       (void)hipMemset(set->gather[size_t(g)], 0, gw * sizeof(u64));
     }
   }
@@ -2416,6 +2567,7 @@ void nidreg_destroy(nidreg_handle* h) { free_handle(h); }
 int nidreg_eval(nidreg_handle* h, const double* se3, double* cost, double* grad7) {
   if (!h || !se3) return fail(NIDREG_ERR_INVALID, "nidreg_eval: null argument");
   if (h->set) return set_eval(h->set, NIDREG_MODE_SPLINE, se3, cost, grad7);
+  if (h->rccl_comm) return rccl_eval(h, NIDREG_MODE_SPLINE, se3, cost, grad7);
   cohort_check(h);
   if (h->cohort && h->cohort->members.size() >= 2 && h->mode == NIDREG_MODE_SPLINE && !h->timing && h->async_outstanding == 0) {
     const int rc = cohort_eval(h, se3, grad7 != nullptr, cost, grad7);
@@ -2440,7 +2592,7 @@ static int async_submit(nidreg_handle* h, int mode, const double* pose, bool wan
   const int64_t t = h->next_ticket + 1;
   nidreg_handle::Pending& p = h->pending[t % kAsyncDepth];
   if (p.ticket != 0) return fail(NIDREG_ERR_INVALID, "nidreg_submit: ticket ring collision (wait for the oldest evaluation first)");
-  if (h->set || !h->d_out_host || h->timing) {
+  if (h->set || h->rccl_comm || !h->d_out_host || h->timing) {
     // a handle sharded over several GPUs (its shards hand-shake inside the kernels), results in a caller's buffer, or
     // per-kernel timing: evaluated here and now, the ticket just carries the results
     double c = 0.0, g[7] = {0};
@@ -2565,6 +2717,7 @@ int nidreg_eval_pipelined(nidreg_handle* h, const double* se3s, int n, double* c
 int nidreg_eval_iso(nidreg_handle* h, const double* T, double* cost) {
   if (!h || !T) return fail(NIDREG_ERR_INVALID, "nidreg_eval_iso: null argument");
   if (h->set) return set_eval(h->set, NIDREG_MODE_NEAREST, T, cost, nullptr) < 0 ? NIDREG_ERR_HIP : NIDREG_OK;
+  if (h->rccl_comm) return rccl_eval(h, NIDREG_MODE_NEAREST, T, cost, nullptr) < 0 ? NIDREG_ERR_HIP : NIDREG_OK;
   cohort_check(h);
   const int rc = iso_launch(h, T);
   if (rc) return rc;
@@ -2576,6 +2729,8 @@ int nidreg_eval_multi(nidreg_handle* const* handles, int n, const double* init_s
   if (init_se3 && !trust_gate_ok(init_se3, se3)) return NIDREG_FALSE;
   for (int i = 0; i < n; i++)
     if (!handles[i]) return fail(NIDREG_ERR_INVALID, "nidreg_eval_multi: null handle");
+  for (int i = 0; i < n; i++)
+    if (handles[i]->rccl_comm) return fail(NIDREG_ERR_INVALID, "nidreg_eval_multi: a handle with a communicator (nidreg_shard_attach_rccl) is a collective of its own: evaluate it with nidreg_eval");
   for (int i = 0; i < n; i++) cohort_check(handles[i]);
   // several compatible pairs on ONE GPU: a single grid per pass over all pairs (group_eval)
   if (handles[0]->mode == NIDREG_MODE_SPLINE) {
@@ -2641,6 +2796,8 @@ int nidreg_eval_iso_multi(nidreg_handle* const* handles, int n, const double* T,
   if (!handles || n <= 0 || !T) return fail(NIDREG_ERR_INVALID, "nidreg_eval_iso_multi: bad argument");
   for (int i = 0; i < n; i++)
     if (!handles[i]) return fail(NIDREG_ERR_INVALID, "nidreg_eval_iso_multi: null handle");
+  for (int i = 0; i < n; i++)
+    if (handles[i]->rccl_comm) return fail(NIDREG_ERR_INVALID, "nidreg_eval_iso_multi: a handle with a communicator (nidreg_shard_attach_rccl) is a collective of its own: evaluate it with nidreg_eval_iso");
   for (int i = 0; i < n; i++) cohort_check(handles[i]);
   if (handles[0]->mode == NIDREG_MODE_NEAREST && can_group(handles, n)) {  // several pairs on one GPU: one grid per pass
     MultiGroup* g = find_or_make_group(handles, n);
@@ -2674,23 +2831,11 @@ int nidreg_eval_iso_multi(nidreg_handle* const* handles, int n, const double* T,
 
 int nidreg_get_hist_fixed(nidreg_handle* h, int64_t* joint, int64_t* inliers, int* frac_bits) {
   if (!h) return fail(NIDREG_ERR_INVALID, "nidreg_get_hist_fixed: null handle");
-  if (h->set) {  // every shard holds its own columns of the pair's histogram
-    const int B = h->bins;
-    std::vector<u64> tmp(size_t(h->hist_words));
-    int64_t inl = 0;
-    if (joint) std::fill(joint, joint + size_t(B) * B, int64_t(0));
+  if (h->set) {  // every shard holds a replica of the whole histogram once an evaluation has run: read the leader's
     for (nidreg_handle* sh : h->set->shards) {
       HIP_TRY(hipSetDevice(sh->device));
       HIP_TRY(hipStreamSynchronize(sh->stream));
-      HIP_TRY(hipMemcpy(tmp.data(), sh->d_hist, tmp.size() * sizeof(u64), hipMemcpyDeviceToHost));
-      if (joint)
-        for (int c = sh->col_lo; c < sh->col_hi; c++)
-          for (int r = 0; r < B; r++) joint[size_t(r) * B + c] = int64_t(tmp[size_t(c) * B + r]);
-      inl += int64_t(tmp[size_t(B) * B + kTailInliers]);
     }
-    if (inliers) *inliers = inl;
-    if (frac_bits) *frac_bits = h->frac_bits;
-    return NIDREG_OK;
   }
   HIP_TRY(hipSetDevice(h->device));
   // the marginals / scalars are plain stores of a gradient workgroup: the host sees the completion tag before the kernel has
@@ -2826,6 +2971,51 @@ int64_t nidreg_view_culling(int model_id, const double* intrinsics, const double
   for (int64_t i = 0; i < num_points; i++)
     if (keep[size_t(i)]) indices_out[m++] = int32_t(i);
   return m;
+}
+
+int nidreg_rccl_unique_id(unsigned char* id128) {
+  if (!id128) return fail(NIDREG_ERR_INVALID, "nidreg_rccl_unique_id: null argument");
+  RcclApi* api = rccl_api();
+  if (!api->lib || !api->error.empty()) return fail(NIDREG_ERR_HIP, "nidreg_rccl_unique_id: " + api->error);
+  static_assert(sizeof(ncclUniqueId) == NIDREG_RCCL_ID_BYTES, "ncclUniqueId is 128 bytes");
+  ncclUniqueId id;
+  RCCL_TRY(api->GetUniqueId(&id));
+  std::memcpy(id128, &id, sizeof(id));
+  return NIDREG_OK;
+}
+
+int nidreg_shard_comm_init(nidreg_handle* h, int world_size, int rank, const unsigned char* id128) {
+  int rc = rccl_attachable(h, "nidreg_shard_comm_init");
+  if (rc) return rc;
+  if (!id128 || world_size < 1 || rank < 0 || rank >= world_size) return fail(NIDREG_ERR_INVALID, "nidreg_shard_comm_init: bad argument");
+  RcclApi* api = rccl_api();
+  if (!api->lib || !api->error.empty()) return fail(NIDREG_ERR_HIP, "nidreg_shard_comm_init: " + api->error);
+  HIP_TRY(hipSetDevice(h->device));
+  ncclUniqueId id;
+  std::memcpy(&id, id128, sizeof(id));
+  ncclComm_t comm = nullptr;
+  RCCL_TRY(api->CommInitRank(&comm, world_size, id, rank));
+  rccl_release(h);
+  h->rccl_comm = comm;
+  h->rccl_owned = true;
+  return NIDREG_OK;
+}
+
+int nidreg_shard_attach_rccl(nidreg_handle* h, void* nccl_comm) {
+  int rc = rccl_attachable(h, "nidreg_shard_attach_rccl");
+  if (rc) return rc;
+  if (!nccl_comm) {  // detach: the handle evaluates on its own again
+    rccl_release(h);
+    return NIDREG_OK;
+  }
+  RcclApi* api = rccl_api();
+  if (!api->lib || !api->error.empty()) return fail(NIDREG_ERR_HIP, "nidreg_shard_attach_rccl: " + api->error);
+  int count = 0;
+  RCCL_TRY(api->CommCount(static_cast<ncclComm_t>(nccl_comm), &count));  // (also rejects a pointer that is not a communicator of this RCCL)
+  rccl_release(h);
+  h->rccl_comm = nccl_comm;
+  h->rccl_owned = false;
+  return NIDREG_OK;
 }
 
 int nidreg_shard_hist(nidreg_handle* h, const double* se3) {

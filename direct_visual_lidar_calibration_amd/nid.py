@@ -210,6 +210,20 @@ class _Handle:
     def num_shards(self):
         return int(self._lib.nidreg_num_shards(self.h))
 
+    # ---- one process per GPU, RCCL inside the library (include/nidreg.h): after comm_init / attach_rccl every evaluation of
+    # this handle is a collective over the communicator's ranks
+    @staticmethod
+    def rccl_unique_id():
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(_lib.load().nidreg_rccl_unique_id(buf), "nidreg_rccl_unique_id")
+        return buf.raw
+
+    def comm_init(self, world_size, rank, unique_id):
+        _lib.check(self._lib.nidreg_shard_comm_init(self.h, int(world_size), int(rank), bytes(unique_id)), "nidreg_shard_comm_init")
+
+    def attach_rccl(self, comm_ptr):
+        _lib.check(self._lib.nidreg_shard_attach_rccl(self.h, ctypes.c_void_p(comm_ptr) if comm_ptr else None), "nidreg_shard_attach_rccl")
+
     def shard_devices(self):
         ids = (ctypes.c_int * 16)()
         n = self._lib.nidreg_shard_devices(self.h, ids, 16)

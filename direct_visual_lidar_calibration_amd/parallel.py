@@ -101,6 +101,39 @@ class ShardedNIDCost:
         self.inner.close()
 
 
+class InLibShardedNIDCost:
+    """The same split as ``ShardedNIDCost`` with the collectives INSIDE libnidreg.so (``nidreg_shard_comm_init``: the library
+    opens librccl.so itself and runs histogram -> ncclAllReduce(int64) -> entropy -> gradient -> ncclAllReduce(f64 x 7) on the
+    handle's stream) -- what a C++ caller of the drop-in gets.  torch.distributed is used once, to hand rank 0's
+    ncclUniqueId to the other ranks."""
+
+    def __init__(self, proj, normalized_image, points, intensities, bins=16, device=0, precision="fp64", total_points=None, group=None, **tuning):
+        from . import nid
+
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        dev = torch.device("cuda", device)
+        n_local = int(np.asarray(points).shape[0])
+        if total_points is None:
+            t = torch.tensor([n_local], dtype=torch.int64, device=dev)
+            if world > 1:
+                dist.all_reduce(t, group=group)
+            total_points = int(t.item())
+        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            uid = torch.frombuffer(bytearray(nid.NIDCost.rccl_unique_id()), dtype=torch.uint8).to(dev)
+        if world > 1:
+            dist.broadcast(uid, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        self.inner = nid.NIDCost(proj, normalized_image, points, intensities, bins, device=device, precision=precision, scale_points=int(total_points), **tuning)
+        self.inner.comm_init(world, rank, bytes(uid.cpu().numpy().tobytes()))
+
+    def __call__(self, x, want_grad=True):
+        return self.inner(x, want_grad)
+
+    def close(self):
+        self.inner.close()
+
+
 class PairParallelNIDCost:
     """``MultiNIDCost`` with the pairs spread over ranks: each rank evaluates its own pairs (one
     ``nidreg_eval_multi`` over its local handles), then ONE all-reduce of 9 doubles

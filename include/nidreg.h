@@ -284,6 +284,27 @@ int nidreg_shard_entropy(nidreg_handle* h);
 int nidreg_shard_grad(nidreg_handle* h);
 int nidreg_shard_finish(nidreg_handle* h, double* cost, double* grad7);
 
+/* ---- the same protocol with RCCL inside the library (one process per GPU; BASELINE north_star: "disjoint point slices with
+ * a final RCCL all-reduce of the 2D histogram over xGMI") -----------------------------------------------------------------
+ * Every rank creates a plain handle over ITS slice of the pair's cloud (desc.scale_points = the pair's total point count, so
+ * that every rank uses the same fixed-point unit; no ext_hist / ext_out / device_ids) and gives it a communicator; from then on
+ * nidreg_eval / nidreg_eval_iso / nidreg_eval_batch on that handle are COLLECTIVE calls (every rank, same pose) that run
+ *     histogram kernel -> ncclAllReduce(int64 sum, nidreg_hist_words(bins) words) -> entropy tail ->
+ *     gradient kernel  -> ncclAllReduce(float64 sum, 7 words)
+ * on the handle's stream.  Replaces nothing in the reference (its only parallelism is the OpenMP loop over pairs,
+ * src/vlcal/calib/visual_camera_calibration.cpp:161); the cost is bit-identical on every rank and to the unsharded handle's,
+ * the gradient equal up to the order of the partial sums.  librccl.so is opened with dlopen at the first of these calls
+ * (NIDREG_RCCL_LIB overrides the name); libnidreg.so does not link it.
+ *   nidreg_rccl_unique_id     rank 0: ncclGetUniqueId into 128 bytes, which the caller hands to the other ranks (MPI, a file,
+ *                             torch.distributed -- any way it likes)
+ *   nidreg_shard_comm_init    every rank: ncclCommInitRank(world_size, id, rank) on the handle's device; the handle owns the
+ *                             communicator and destroys it with itself
+ *   nidreg_shard_attach_rccl  a communicator the caller owns (an ncclComm_t, passed as void*); NULL detaches */
+#define NIDREG_RCCL_ID_BYTES 128
+int nidreg_rccl_unique_id(unsigned char* id128);
+int nidreg_shard_comm_init(nidreg_handle* h, int world_size, int rank, const unsigned char* id128);
+int nidreg_shard_attach_rccl(nidreg_handle* h, void* nccl_comm);
+
 /* number of GPUs a handle is sharded over (1 = plain handle) and their device ordinals */
 int nidreg_num_shards(nidreg_handle* h);
 int nidreg_shard_devices(nidreg_handle* h, int* device_ids, int capacity);

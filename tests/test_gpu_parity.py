@@ -740,9 +740,9 @@ def test_concurrent_handles_from_host_threads_and_no_leaks():
 @pytest.mark.parametrize("nshards", [2, 3, 5])
 def test_in_library_sharding_matches_plain_handle(nshards):
     """desc.num_devices > 1 (here: the same GPU listed several times -- all a 1-GPU box offers; the peer-mapped
-    fine-grained flag / gather blocks, the announce in the histogram kernel, k_entropy_owned / k_entropy_gather are the ones
-    a multi-GPU node runs): the points are cut along the histogram column, every shard owns a range of column groups, and
-    only inlier counts, entropy partials, row sums and column sums cross between the shards.  Histogram and cost are
+    fine-grained flag blocks and histogram replicas, k_entropy_repl's push / wait are the ones a multi-GPU node runs): the
+    points are cut along the histogram column, every shard owns a range of column groups and stores its columns into every
+    shard's replica of the integer histogram -- one exchange per evaluation.  Histogram and cost are
     bit-identical to the unsharded handle, the gradient equal up to summation order -- SPLINE and NEAREST, 16 and 256 bins,
     a cloud size that does not divide evenly."""
     s = scene_for("plumb_bob", n=30011)

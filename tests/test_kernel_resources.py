@@ -119,7 +119,7 @@ def test_spline_kernels_use_global_not_flat_memory_instructions(kernel_metadata)
         start = text.index("\n" + name + ":")
         body = text[start:text.index(".Lfunc_end", start)]
         flat = re.findall(r"^\s+(flat_\w+)", body, flags=re.M)
-        # allowed: the system-scope stores of shard_announce / the host mirror (peer and host pointers come from tables too,
+        # allowed: the system-scope stores of the host mirror (peer and host pointers come from tables too,
         # a handful per workgroup) and the phi(q_r) load; not allowed: record loads (dwordx3 / dwordx4) and the flush's atomics
         hot = [f for f in flat if f in ("flat_load_dwordx3", "flat_load_dwordx4") or f.startswith("flat_atomic_add_x2")]
         assert not hot, (name, hot)

@@ -1,0 +1,89 @@
+"""RCCL inside the library (include/nidreg.h: nidreg_rccl_unique_id / nidreg_shard_comm_init / nidreg_shard_attach_rccl): the
+C test program tests/cxx/test_rccl_world1.cpp builds against the C ABI + librccl (CPU test) and, on a GPU, runs the chain
+histogram -> ncclAllReduce(int64) -> entropy -> gradient -> ncclAllReduce(f64 x 7) with one-rank communicators: the
+all-reduce of one rank is the identity, so the results must be the plain handle's -- and the oracle's."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import parity
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "direct_visual_lidar_calibration_amd", "csrc")
+EXE = os.path.join(ROOT, "tests", "cxx", "test_rccl_world1.bin")
+
+
+def build_exe():
+    import __graft_entry__
+
+    if not os.path.exists(os.path.join(CSRC, "libnidreg.so")):
+        __graft_entry__.build()
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include", os.path.join(ROOT, "tests", "cxx", "test_rccl_world1.cpp"),
+           "-L", CSRC, "-lnidreg", "-L", "/opt/rocm/lib", "-lrccl", f"-Wl,-rpath,{CSRC}", "-Wl,-rpath,/opt/rocm/lib", "-o", EXE]
+    subprocess.check_call(cmd)
+    return EXE
+
+
+def test_rccl_program_compiles_and_links():
+    assert os.path.exists(build_exe())
+
+
+def test_library_does_not_link_rccl():
+    """librccl.so is opened at run time by the first call that needs it: a caller that never attaches a communicator never
+    loads it."""
+    out = subprocess.check_output(["ldd", os.path.join(CSRC, "libnidreg.so")]).decode()
+    assert "rccl" not in out
+
+
+@pytest.mark.gpu
+def test_world1_communicators_return_the_plain_handles_bits(tmp_path):
+    import oracle_lib
+    from direct_visual_lidar_calibration_amd import se3, synth
+    from test_gpu_parity import CAMERAS
+
+    exe = EXE if os.path.exists(EXE) else build_exe()
+    for name, bins in (("plumb_bob", 256), ("equirectangular", 16)):
+        s = synth.make_scene(CAMERAS[name], num_points=40000, seed=77)
+        x = s.T_camera_lidar_init
+        intr = np.zeros(5)
+        intr[: len(s.intrinsics)] = s.intrinsics
+        dist = np.zeros(8)
+        dist[: len(s.distortion)] = s.distortion
+        path = tmp_path / f"{name}.bin"
+        with open(path, "wb") as f:
+            f.write(s.model.encode().ljust(64, b"\0"))
+            f.write(struct.pack("<6i", s.width, s.height, s.points.shape[0], bins, len(s.intrinsics), len(s.distortion)))
+            f.write(intr.tobytes() + dist.tobytes() + np.asarray(x, dtype=np.float64).tobytes() + struct.pack("<d", 1.0) + se3.to_matrix(x).astype(np.float64).tobytes())
+            f.write(np.ascontiguousarray(s.image_u8).tobytes())
+            f.write(np.ascontiguousarray(s.points, dtype=np.float64).tobytes())
+            f.write(np.ascontiguousarray(s.intensities, dtype=np.float64).tobytes())
+        res = subprocess.run([exe, str(path)], capture_output=True, timeout=300)
+        assert res.returncode == 0, (res.returncode, res.stderr.decode()[-2000:])
+        v = np.array([float(t) for t in res.stdout.decode().strip().splitlines()[-1].split()]).reshape(3, 8)  # (RCCL prints a version banner first)
+        assert v[1, 0] == v[0, 0] and v[2, 0] == v[0, 0]  # the cost: same integers, same bits
+        assert np.array_equal(v[1, 1:], v[0, 1:]) and np.array_equal(v[2, 1:], v[0, 1:])  # one rank: the partial IS the gradient
+        ref = oracle_lib.nid_cost(s.model, s.intrinsics, s.distortion, s.image_u8.astype(np.float64) / 255.0, s.points, s.intensities, bins, x)
+        parity.check_cost(v[1, 0], ref["cost"], what=f"in-library RCCL route, {name}")
+        parity.check_grad(v[1, 1:], ref["grad"], what=f"in-library RCCL route, {name}")
+
+
+@pytest.mark.gpu
+def test_inlib_sharded_cost_python_world1():
+    """parallel.InLibShardedNIDCost without a process group: a one-rank communicator created by the library."""
+    from direct_visual_lidar_calibration_amd import nid, parallel, synth
+
+    s = synth.make_scene("pinhole_vga", num_points=30000, seed=3)
+    proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
+    plain = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, 64)
+    sh = parallel.InLibShardedNIDCost(proj, s.image_f64, s.points, s.intensities, 64, device=0)
+    for x in (s.T_camera_lidar_init, s.T_camera_lidar_true):
+        ok, c, g = plain(x)
+        ok2, c2, g2 = sh(x)
+        assert ok and ok2 and c2 == c and np.array_equal(g2, g)
+        ok3, c3, _ = sh(x, want_grad=False)
+        assert ok3 and c3 == c
+    sh.close()
+    plain.close()

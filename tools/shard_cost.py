@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Protocol cost of the in-library sharded evaluation on ONE GPU (the same device listed n times, every shard driven by its
 own host thread on its own hardware queue like shards on different devices): with a cloud so small that the kernels' work
-is negligible, the time per evaluation beyond the plain handle's is the protocol -- the announce at the end of the histogram
-kernel, k_entropy_owned's flag wait and push, k_entropy_gather's flag wait, one more launch, the host-thread hand-off.
+is negligible, the time per evaluation beyond the plain handle's is the protocol -- k_entropy_repl's push of the owned column
+blocks into every replica, its one flag wait, the host-thread hand-off.
 Also the 10M-point case for the record (there the shards' kernels share the one GPU, so nothing is gained -- it only shows
 the protocol at full size).
 Usage: shard_cost.py [bins]"""
