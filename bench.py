@@ -603,20 +603,26 @@ def main():
             return {"config": config_name, "scaling": "weak", "value": round(world * 1e3 / mm["ms_per_step"], 2), "unit": "pair-evals/s (all ranks)", "ms_per_step": round(mm["ms_per_step"], 5),
                     "points_per_gpu": n_points, "ranks_seen": ranks_seen}
 
-        def shard_leg(camera, n_points, config_name, seed):
+        def shard_leg(camera, n_points, config_name, seed, inlib=False):
             s = synth.make_scene(camera, num_points=n_points, seed=seed, device=f"cuda:{local_rank}")
             pr = nid.create_camera(s.model, s.intrinsics, s.distortion)
             lo_, hi_ = parallel.shard_slice(n_points, rank, world)
-            c = parallel.ShardedNIDCost(pr, s.image_f64, s.points[lo_:hi_], s.intensities[lo_:hi_], args.bins, device=local_rank, precision=args.precision, total_points=n_points)
+            # inlib: the collectives run INSIDE libnidreg.so (nidreg_shard_comm_init: dlopen'ed RCCL on the handle's stream) -- what
+            # a C++ caller of the drop-in gets; otherwise the split-phase ABI with torch.distributed's all-reduce between the phases
+            cls = parallel.InLibShardedNIDCost if inlib else parallel.ShardedNIDCost
+            c = cls(pr, s.image_f64, s.points[lo_:hi_], s.intensities[lo_:hi_], args.bins, device=local_rank, precision=args.precision, total_points=n_points)
             ps_ = [synth.random_pose_near(s.T_camera_lidar_true, rng) for _ in range(32)]
             mm = measure(c, ps_, steps2, 3, blocks2, batch=False)
             c.close()
             return {"config": config_name, "scaling": "strong", "value": round(1e3 / mm["ms_per_step"], 2), "unit": "evals/s", "ms_per_step": round(mm["ms_per_step"], 5),
-                    "points": n_points, "points_per_gpu": hi_ - lo_, "collective": "RCCL all-reduce: int64 fixed-point histogram + 7-double gradient", "ranks_seen": ranks_seen}
+                    "points": n_points, "points_per_gpu": hi_ - lo_, "collective": "RCCL all-reduce: int64 fixed-point histogram + 7-double gradient" + (", issued by libnidreg.so itself (dlopen)" if inlib else ""),
+                    "ranks_seen": ranks_seen}
 
         leg("pairs_configs3", lambda: pairs_leg("fisheye_1080p", int(5_000_000 * ps), "BASELINE configs[3]: one 5M-pt fisheye pair per GPU"))
         leg("shard_configs2", lambda: shard_leg("equirect_2k", int(10_000_000 * ps), "BASELINE configs[2]: 10M-pt equirectangular, points sharded", 20250523 + 3))
         leg("shard_configs4", lambda: shard_leg("pinhole_4k", int(50_000_000 * ps), "BASELINE configs[4]: 50M-pt 4K pinhole, points sharded", 20250523 + 5))
+        if backend == "nccl" and not os.environ.get("NIDREG_BENCH_NO_INLIB_RCCL"):
+            leg("shard_configs2_inlib", lambda: shard_leg("equirect_2k", int(10_000_000 * ps), "BASELINE configs[2]: 10M-pt equirectangular, points sharded, RCCL inside the library", 20250523 + 3, inlib=True))
 
         # the single-process route of the C ABI (what an unchanged one-process calibrate uses): rank 0 drives every GPU
         # of the job itself, the other ranks wait on the host

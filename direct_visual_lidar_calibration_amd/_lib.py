@@ -66,7 +66,7 @@ EXPORTS = [
     "nidreg_shard_entropy", "nidreg_shard_grad", "nidreg_shard_finish", "nidreg_set_timing", "nidreg_get_timing", "nidreg_get_info", "nidreg_last_error",
     "nidreg_version", "nidreg_colorizer_create", "nidreg_colorizer_update", "nidreg_colorizer_device_colors", "nidreg_colorizer_destroy", "nidreg_generate_lidar_image",
     "nidreg_equalize_intensities", "nidreg_num_shards", "nidreg_shard_devices", "nidreg_trim", "nidreg_eval_batch", "nidreg_submit", "nidreg_submit_iso", "nidreg_wait", "nidreg_eval_pipelined",
-    "nidreg_rccl_unique_id", "nidreg_shard_comm_init", "nidreg_shard_attach_rccl",
+    "nidreg_estimate_camera_fov", "nidreg_rccl_unique_id", "nidreg_shard_comm_init", "nidreg_shard_attach_rccl",
 ]
 
 _lib = None
@@ -129,6 +129,7 @@ def load():
     lib.nidreg_shard_devices.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_int]
     lib.nidreg_trim.restype = None
     lib.nidreg_trim.argtypes = []
+    lib.nidreg_estimate_camera_fov.argtypes = [ctypes.c_int, c_double_p, c_double_p, ctypes.c_int, ctypes.c_int, c_double_p]
     lib.nidreg_rccl_unique_id.argtypes = [ctypes.c_char_p]
     lib.nidreg_shard_comm_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
     lib.nidreg_shard_attach_rccl.argtypes = [ctypes.c_void_p, ctypes.c_void_p]

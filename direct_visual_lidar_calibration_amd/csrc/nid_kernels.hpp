@@ -1,18 +1,22 @@
 // nid_kernels.hpp -- the HIP kernels of the NID registration core (gfx950, wave64).
 //
-// Pipeline of one NIDCost evaluation (include/vlcal/costs/nid_cost.hpp:36-107 redesigned):
-//   (hist is zero on entry: double-buffered, cleared by the previous evaluation's k_entropy; a
-//    caller-provided buffer is cleared with a memset)
-//   k_spline_hist   <model,rec,real>  stream points once; LDS-tiled fixed-point joint histogram
-//   k_entropy_partial                 per column-group: sum p log(p+eps), row partials, column sums
-//   k_entropy_final                   H_image, H_points, H_joint -> NID, dNID/dh coefficients
-//   k_spline_grad   <model,rec,real>  stream points again; contract dNID/dh with d(weight)/d(p_cam),
-//                                     fold d(p_cam)/d(pose) into a 3x3 + 3 accumulator per workgroup
-//   k_grad_final                      reduce workgroup partials, chain to d/d[qx qy qz qw tx ty tz]
-// and of one CostCalculatorNID evaluation (src/vlcal/calib/cost_calculator_nid.cpp:21-67):
-//   memset(hist); k_nearest_hist; k_entropy_partial; k_entropy_final
+// One NIDCost evaluation (include/vlcal/costs/nid_cost.hpp:36-107 redesigned) -- the histogram buffer is zero on entry:
+// double-buffered, cleared by the previous evaluation's kernels; a caller-provided buffer is cleared with a memset:
+//   k_spline_hist   <model,rec,real,WIDE,MULTI,SEG>  stream the point records once; LDS-tiled fixed-point joint histogram
+//   k_entropy       <MULTI>                          per block of 8 columns: sum p log(p + eps) (fixed point) and row sums, added
+//                                                    behind the histogram; cost-only evaluations: its last workgroup runs the
+//                                                    entropy tail (H_image, H_points, H_joint -> NID).  Not launched for
+//                                                    tables of <= 1024 cells in a cost+Jacobian evaluation (kSelfEntropyCells)
+//   k_spline_grad   <model,rec,real,GW1,MULTI,SEG>   prologue: the entropy tail on those sums (every workgroup, same integers),
+//                                                    the G tile; stream the records again; contract dNID/dh with
+//                                                    d(weight)/d(p_cam), fold d(p_cam)/d(pose) into a 3x3 + 3 accumulator per
+//                                                    segment; last workgroup: reduce the partials, chain to
+//                                                    d/d[qx qy qz qw tx ty tz], results + completion tag to the host
+// One CostCalculatorNID evaluation (src/vlcal/calib/cost_calculator_nid.cpp:21-67):  k_nearest_hist; k_entropy (tail).
+// A pair spread over several GPUs by one process:  k_*_hist; k_entropy_repl (k_entropy + one exchange); k_spline_grad.
+// k_grad_final: stand-alone finalisation, launched only for an empty cloud (no gradient workgroup exists to do it).
 //
-// All kernels: 256 threads (4 waves of 64); dynamic LDS only, base 16-B aligned.
+// Point kernels: 256 threads (4 waves of 64; the WIDE histogram kernel 512); dynamic LDS only, base 16-B aligned.
 #pragma once
 #include "nid_device.hpp"
 #include "nid_multi.hpp"
@@ -541,9 +545,8 @@ __host__ __device__ __forceinline__ size_t spline_hist_lds_bytes(int B, int GW, 
 // waves per SIMD the WIDE kernel is compiled for: two 8-wave workgroups per CU need <= 128 VGPRs; both the straight-line and
 // the looped kernels land there by themselves (the `atan` model's Dual3 forward mode holds ~164 either way), so no bound is
 // imposed (a forced bound made the compiler give up the four-deep record prefetch: +20-30 % on the looped kernel).
-constexpr int hist_min_waves(int, bool, bool, bool) { return 1; }
 template <int MODEL, typename Rec, typename real, bool WIDE, bool MULTI, bool SEG>
-__global__ __launch_bounds__(WIDE ? kWideThreads : kThreads, hist_min_waves(MODEL, WIDE, SEG, sizeof(Rec) == sizeof(Rec32))) void k_spline_hist(
+__global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_spline_hist(
   const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint32_t* __restrict__ gend, const uint8_t* __restrict__ img, int pitch, int W, int H, PoseParams<real> pose, CamParams<real> cam, int B,
   int GW, int cshift, double dn_scale, u64* __restrict__ hist, int prio,
   const MultiEntry* __restrict__ multi, typename multi_dyn_of<MULTI>::type dyn) {

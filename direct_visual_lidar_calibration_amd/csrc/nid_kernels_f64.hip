@@ -26,6 +26,33 @@ template <> hipError_t launch_project<double>(int model, const double* intr, con
   return hipGetLastError();
 }
 
+// the same projection code on the HOST (nid_device.hpp's scalar math is __host__ __device__): for callers that project a
+// handful of points at a time -- estimate_camera_fov inverts the projection at three pixels with NelderMead<2>, ~240 probes
+// of ONE point (src/vlcal/common/estimate_fov.cpp:17-51), host work in the reference as well
+int project_host(int model, const double* intr, const double* dist, const double* p3, long long n, double* uv, double* jac) {
+  struct { int model; } a{model};
+  const CamParams<double> cam = make_cam<double>(intr, dist);
+#define NID_LAUNCH(M)                                                                                      \
+  for (long long i = 0; i < n; i++) {                                                                      \
+    double u, v, du[3], dv[3];                                                                             \
+    project_jac<M, double>(cam, p3[3 * i], p3[3 * i + 1], p3[3 * i + 2], u, v, du, dv);                     \
+    uv[2 * i] = u, uv[2 * i + 1] = v;                                                                      \
+    if (jac)                                                                                               \
+      for (int k = 0; k < 3; k++) jac[6 * i + k] = du[k], jac[6 * i + 3 + k] = dv[k];                      \
+  }
+  switch (a.model) {
+    case MODEL_PLUMB_BOB: NID_LAUNCH(MODEL_PLUMB_BOB) break;
+    case MODEL_FISHEYE: NID_LAUNCH(MODEL_FISHEYE) break;
+    case MODEL_OMNIDIR: NID_LAUNCH(MODEL_OMNIDIR) break;
+    case MODEL_EQUIRECT: NID_LAUNCH(MODEL_EQUIRECT) break;
+    case MODEL_ATAN: NID_LAUNCH(MODEL_ATAN) break;
+    case MODEL_RATIONAL: NID_LAUNCH(MODEL_RATIONAL) break;
+    default: return -1;
+  }
+#undef NID_LAUNCH
+  return 0;
+}
+
 }  // namespace nidreg
 
 

@@ -75,6 +75,9 @@ template <typename real> int occupancy_spline_hist(const PassArgs& a);
 template <typename real> int occupancy_spline_grad(const PassArgs& a);
 template <typename real> hipError_t launch_project(int model, const double* intr, const double* dist, const double* p3, long long n, double* uv, double* jac, hipStream_t stream);
 
+// the same scalar projection code run on the host (nid_kernels_f64.hip): host arrays, fp64, 0 = ok
+int project_host(int model, const double* intr, const double* dist, const double* p3, long long n, double* uv, double* jac);
+
 // ViewCulling::cull (nid_cull_kernels.hpp); all pointers are device memory
 hipError_t launch_cull(int model, const double* intr, const double* dist, const double* d_pts, long long stride_d, long long n, const double* T, int W, int H, double min_z,
                        int depth, int* d_pix, unsigned int* d_zbuf, unsigned char* d_keep, hipStream_t stream);

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <ctime>
 #include <functional>
+#include <limits>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -2921,8 +2922,100 @@ int nidreg_project(nidreg_handle* h, const double* p3, int64_t n, double* uv, do
   return NIDREG_OK;
 }
 
+/* vlcal::estimate_camera_fov (src/vlcal/common/estimate_fov.cpp:17-51) on the host: for each of the pixels (0, 0), (W/2, 0),
+ * (0, H/2) the bearing that projects onto it, found by NelderMead<2> (include/dfo/nelder_mead.hpp:32-113, defaults) over two
+ * rotation angles, then the largest angle to the optical axis.  ~240 projections of ONE point: host work in the reference
+ * and here (the device's scalar projection code compiled for the host, project_host) -- through Python and the GPU it was
+ * 8 of the 13 ms a whole configs[0] calibration took. */
+int nidreg_estimate_camera_fov(int model_id, const double* intrinsics, const double* distortion, int width, int height, double* max_fov) {
+  if (model_id < 0 || model_id > 5 || !intrinsics || !distortion || !max_fov) return fail(NIDREG_ERR_INVALID, "nidreg_estimate_camera_fov: bad argument");
+  double intr5[5], dist8[8];
+  std::memcpy(intr5, intrinsics, sizeof(intr5));
+  std::memcpy(dist8, distortion, sizeof(dist8));
+  // AngleAxis(x0, X) * AngleAxis(x1, Y) * UnitZ through quaternions, as Eigen evaluates it (estimate_fov.cpp:19-21)
+  auto to_dir = [](const double* x, double* d) {
+    const double aw = std::cos(0.5 * x[0]), ax = std::sin(0.5 * x[0]);
+    const double bw = std::cos(0.5 * x[1]), by = std::sin(0.5 * x[1]);
+    const double qw = aw * bw, qx = ax * bw, qy = aw * by, qz = ax * by;
+    const double ux = 2.0 * qy, uy = -2.0 * qx, uz = 0.0;  // 2 (vec x ez)
+    d[0] = qw * ux + (qy * uz - qz * uy);
+    d[1] = qw * uy + (qz * ux - qx * uz);
+    d[2] = (1.0 + qw * uz) + (qx * uy - qy * ux);
+  };
+  const double corners[3][2] = {{0.0, 0.0}, {double(width / 2), 0.0}, {0.0, double(height / 2)}};
+  double best = 0.0;
+  for (int c = 0; c < 3; c++) {
+    const double pu = corners[c][0], pv = corners[c][1];
+    auto f = [&](const double* x) {
+      double d[3], uv[2];
+      to_dir(x, d);
+      if (project_host(model_id, intr5, dist8, d, 1, uv, nullptr) != 0) return std::numeric_limits<double>::max();
+      const double e = (pu - uv[0]) * (pu - uv[0]) + (pv - uv[1]) * (pv - uv[1]);
+      return std::isfinite(e) ? e : std::numeric_limits<double>::max();
+    };
+    // NelderMead<2>: rows (y, x0, x1), init_step 0.1, (alpha, gamma, rho) = (1, 2, 0.5), 1024 iterations, variance threshold 1e-5
+    std::array<std::array<double, 3>, 3> x;
+    for (int i = 0; i < 3; i++) {
+      x[size_t(i)] = {0.0, 0.0, 0.0};
+      if (i > 0) x[size_t(i)][size_t(i)] += 0.1;
+      x[size_t(i)][0] = f(&x[size_t(i)][1]);
+    }
+    for (int it = 0; it < 1024; it++) {
+      std::stable_sort(x.begin(), x.end(), [](const std::array<double, 3>& a, const std::array<double, 3>& b) { return a[0] < b[0]; });
+      double var = 0.0;
+      for (int k = 1; k < 3; k++) {
+        const double m = ((x[0][size_t(k)] + x[1][size_t(k)]) + x[2][size_t(k)]) / 3.0;
+        double v = 0.0;
+        for (int i = 0; i < 3; i++) v += (x[size_t(i)][size_t(k)] - m) * (x[size_t(i)][size_t(k)] - m);
+        var += v;
+      }
+      if (var < 1e-5) break;
+      std::array<double, 3> xo, xr;
+      for (int k = 1; k < 3; k++) xo[size_t(k)] = (x[0][size_t(k)] + x[1][size_t(k)]) / 2.0;
+      xo[0] = f(&xo[1]);
+      for (int k = 1; k < 3; k++) xr[size_t(k)] = xo[size_t(k)] + 1.0 * (xo[size_t(k)] - x[2][size_t(k)]);
+      xr[0] = f(&xr[1]);
+      if (x[0][0] <= xr[0] && xr[0] < x[1][0]) {
+        x[2] = xr;
+      } else if (xr[0] < x[0][0]) {
+        std::array<double, 3> xe;
+        for (int k = 1; k < 3; k++) xe[size_t(k)] = xo[size_t(k)] + 2.0 * (xo[size_t(k)] - x[2][size_t(k)]);
+        xe[0] = f(&xe[1]);
+        x[2] = xe[0] < xr[0] ? xe : xr;
+      } else {
+        std::array<double, 3> xc;
+        for (int k = 1; k < 3; k++) xc[size_t(k)] = xo[size_t(k)] + 0.5 * (xo[size_t(k)] - x[2][size_t(k)]);
+        xc[0] = f(&xc[1]);
+        if (xc[0] < x[2][0]) {
+          x[2] = xc;
+        } else {
+          for (int j = 1; j < 3; j++) {
+            for (int k = 1; k < 3; k++) x[size_t(j)][size_t(k)] = x[0][size_t(k)] + 0.5 * (x[size_t(j)][size_t(k)] - x[0][size_t(k)]);
+            x[size_t(j)][0] = f(&x[size_t(j)][1]);
+          }
+        }
+      }
+    }
+    // (the loop leaves the rows sorted when it converges; after 1024 iterations without convergence the best row may not be first)
+    std::stable_sort(x.begin(), x.end(), [](const std::array<double, 3>& a, const std::array<double, 3>& b) { return a[0] < b[0]; });
+    double d[3];
+    to_dir(&x[0][1], d);
+    const double n = std::sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+    const double fov = std::acos(n > 0.0 ? d[2] / n : d[2]);
+    if (fov > best) best = fov;
+  }
+  *max_fov = best;
+  return NIDREG_OK;
+}
+
 int nidreg_project_model(int model_id, const double* intrinsics, const double* distortion, int device_id, int precision, const double* p3, int64_t n, double* uv, double* jac) {
   if (model_id < 0 || model_id > 5 || !intrinsics || !distortion || !p3 || !uv || n < 0) return fail(NIDREG_ERR_INVALID, "nidreg_project_model: bad argument");
+  if (device_id == NIDREG_DEVICE_HOST) {  // the device's scalar projection code compiled for the host: no GPU involved (fp64 whatever `precision` says)
+    double intr5[5], dist8[8];
+    std::memcpy(intr5, intrinsics, sizeof(intr5));
+    std::memcpy(dist8, distortion, sizeof(dist8));
+    return project_host(model_id, intr5, dist8, p3, n, uv, jac) == 0 ? NIDREG_OK : fail(NIDREG_ERR_INVALID, "nidreg_project_model: unknown camera model");
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(NIDREG_ERR_NO_DEVICE, "nidreg_project_model: no HIP device");
   nidreg_handle tmp;

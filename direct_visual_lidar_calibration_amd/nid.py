@@ -377,8 +377,10 @@ class MultiNIDCost:
         return rc == _lib.NIDREG_OK, cost.value, grad
 
 
-def estimate_direction(proj, pt_2d, device=0):
-    """estimate_fov.cpp:17-34: invert the projection at one pixel with NelderMead<2> defaults."""
+def estimate_direction(proj, pt_2d, device=-1):
+    """estimate_fov.cpp:17-34: invert the projection at one pixel with NelderMead<2> defaults.  Host work in the reference
+    and here (device = -1 = NIDREG_DEVICE_HOST: the device's scalar projection code compiled for the host; ~80 probes of
+    one point each -- on the GPU they were 8 of the 13 ms a whole configs[0] calibration took)."""
 
     def to_dir(x):
         # AngleAxis(x0, X) * AngleAxis(x1, Y) * UnitZ through quaternions, as Eigen evaluates it
@@ -397,13 +399,24 @@ def estimate_direction(proj, pt_2d, device=0):
     return to_dir(result.x)
 
 
-def estimate_camera_fov(proj, image_size, device=0):
-    """estimate_fov.cpp:36-51: max view angle over (0,0), (W/2,0), (0,H/2) (integer division)."""
+def estimate_camera_fov(proj, image_size, device=None):
+    """estimate_fov.cpp:36-51: max view angle over (0,0), (W/2,0), (0,H/2) (integer division).  Host work in the reference
+    and here: nidreg_estimate_camera_fov runs the three NelderMead<2> inversions natively on the device's scalar projection
+    code compiled for the host (`device` is accepted for compatibility and ignored).  ``estimate_direction`` above is the
+    same procedure spelled out in Python (tests compare the two)."""
+    out = ctypes.c_double(0.0)
+    rc = _lib.load().nidreg_estimate_camera_fov(proj.model_id, _dp(proj._intr5), _dp(proj._dist8), int(image_size[0]), int(image_size[1]), ctypes.byref(out))
+    _lib.check(rc, "nidreg_estimate_camera_fov")
+    return out.value
+
+
+def estimate_camera_fov_py(proj, image_size):
+    """The same through ``estimate_direction`` (Python NelderMead, one host projection per probe)."""
     w, h = int(image_size[0]), int(image_size[1])
     corners = [(0.0, 0.0), (float(w // 2), 0.0), (0.0, float(h // 2))]
     max_fov = 0.0
     for c in corners:
-        d = estimate_direction(proj, c, device=device)
+        d = estimate_direction(proj, c, device=-1)
         n = np.linalg.norm(d)
         fov = math.acos((d / n)[2] if n > 0 else d[2])
         if fov > max_fov:

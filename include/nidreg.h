@@ -221,7 +221,15 @@ int nidreg_get_hist_fixed(nidreg_handle* h, int64_t* joint, int64_t* inliers, in
  * jac (nullable): n x 6 doubles = d(u,v)/d(x,y,z) row-major 2x3. */
 int nidreg_project(nidreg_handle* h, const double* p3, int64_t n, double* uv, double* jac);
 /* the same without a handle (used for one-time host set-up such as estimate_camera_fov,
- * src/vlcal/common/estimate_fov.cpp:17-51); intrinsics[5] / distortion[8] as in nidreg_desc */
+ * src/vlcal/common/estimate_fov.cpp:17-51); intrinsics[5] / distortion[8] as in nidreg_desc.
+ * device_id = NIDREG_DEVICE_HOST: the device's scalar projection code compiled for the host (fp64; equal to the device's
+ * result up to the reciprocal seeds, ~1e-14 relative) -- for callers that probe ONE point at a time, like the ~240 probes of
+ * estimate_camera_fov's NelderMead<2>, which is host work in the reference too. */
+#define NIDREG_DEVICE_HOST (-1)
+/* vlcal::estimate_camera_fov (src/vlcal/common/estimate_fov.cpp:36-51; estimate_direction :17-34 with NelderMead<2>,
+ * include/dfo/nelder_mead.hpp): the largest view angle over the pixels (0,0), (W/2,0), (0,H/2) [rad] -- what
+ * CostCalculatorNID's max_fov, ViewCulling's min_z and generate_lidar_image take.  Host only (no GPU involved). */
+int nidreg_estimate_camera_fov(int model_id, const double* intrinsics, const double* distortion, int width, int height, double* max_fov);
 int nidreg_project_model(int model_id, const double* intrinsics, const double* distortion, int device_id, int precision, const double* p3, int64_t n, double* uv, double* jac);
 
 /* ViewCulling::cull (src/vlcal/calib/view_culling.cpp:21-92) on the device: FoV gate against

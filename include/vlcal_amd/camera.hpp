@@ -44,8 +44,9 @@ public:
   using ConstPtr = std::shared_ptr<const GenericCameraBase>;
   virtual ~GenericCameraBase() {}
 
-  // generic_camera_base.hpp:29,34 -- evaluated by the device projection code (one call = one
-  // kernel launch: fine for set-up code such as estimate_camera_fov, not for per-point loops)
+  // generic_camera_base.hpp:29,34 -- one point at a time is host work (set-up code such as the reference's
+  // estimate_camera_fov, ~240 calls): the device's scalar projection code compiled for the host (NIDREG_DEVICE_HOST);
+  // per-point loops over a cloud belong in the kernels, not here
   virtual Eigen::Vector2d project(const Eigen::Vector3d& point_3d) const = 0;
   virtual Eigen::Vector2d operator()(const Eigen::Vector3d& point_3d) const = 0;
 
@@ -65,7 +66,7 @@ public:
   Eigen::Vector2d operator()(const Eigen::Vector3d& p) const override {
     const double p3[3] = {p[0], p[1], p[2]};
     double uv[2] = {0.0, 0.0};
-    nidreg_project_model(model_id, intr, dist, 0, NIDREG_PREC_FP64, p3, 1, uv, nullptr);
+    nidreg_project_model(model_id, intr, dist, NIDREG_DEVICE_HOST, NIDREG_PREC_FP64, p3, 1, uv, nullptr);
     Eigen::Vector2d r;
     r[0] = uv[0];
     r[1] = uv[1];

@@ -46,7 +46,8 @@ private:
 class NIDCost {
 public:
   // device_ids (optional extension): more than one entry shards the pair's points over those GPUs inside the library
-  // (single process; the histogram is all-reduced GPU to GPU).  Without it the environment variable NIDREG_DEVICES
+  // (single process; the cloud is cut along the histogram column and every GPU stores its columns of the integer histogram
+  // into every other GPU's replica: one GPU-to-GPU exchange per evaluation).  Without it the environment variable NIDREG_DEVICES
   // does the same for a caller that cannot be changed (visual_camera_calibration.cpp:206).
   NIDCost(const camera::GenericCameraBase::ConstPtr& proj, const cv::Mat& normalized_image, const Frame::ConstPtr& points, const int bins = 16, const int device_id = 0,
           const int precision = NIDREG_PREC_FP64, const std::vector<int>& device_ids = std::vector<int>())

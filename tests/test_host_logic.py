@@ -134,7 +134,8 @@ def test_bench_helpers_algorithmic_bytes_labels_and_committed_traffic():
     assert bench.baseline_config_label(ns) == "custom workload"
     files = sorted(glob.glob(os.path.join(root, "profiles", "*_traffic.json")))
     assert files, "a PMC traffic summary must be committed under profiles/"
-    t = json.load(open(files[-1]))
+    headline = [f for f in files if json.load(open(f)).get("workload", {}).get("width") == 1920 and json.load(open(f))["workload"].get("points") == 10_000_000]
+    t = json.load(open(headline[-1]))  # (other camera models' summaries are committed next to it since round 5)
     got = bench.pmc_traffic("k_spline_grad", 10_000_000, 1920, 1080, 256, "fp64")
     assert got == t["kernels"]["k_spline_grad"]["hbm_bytes_corrected"]
     assert 0.95 < got / bench.algorithmic_bytes(10_000_000, 1920, 1080, 256) < 1.15  # no over-fetch
@@ -315,3 +316,26 @@ def test_chunk_rule_lands_near_the_best_measured_count():
         worst = max(worst, at_rule / best)
         assert at_rule <= 1.08 * best, (n, bins, chosen, at_rule, best)
     assert worst > 1.0  # (the table is real data: the rule is not the argmin of every row)
+
+
+def test_estimate_camera_fov_runs_on_the_host_and_equals_the_oracle():
+    """vlcal::estimate_camera_fov (estimate_fov.cpp:17-51) is set-up work on the host in the reference and here
+    (nidreg_estimate_camera_fov: NelderMead<2> natively, on the device's scalar projection code compiled for the host -- no GPU
+    involved): the oracle's value on every camera model and every BASELINE config camera, equal to the Python spelling of the
+    same procedure, and the host projection itself against the oracle's."""
+    import oracle_lib
+    from direct_visual_lidar_calibration_amd import nid, synth
+    from test_gpu_parity import CAMERAS
+
+    rng = np.random.default_rng(4)
+    for name, (model, intr, dist, W, H) in list(CAMERAS.items()) + list(synth.CONFIG_CAMERAS.items()):
+        proj = nid.create_camera(model, intr, dist)
+        fov = nid.estimate_camera_fov(proj, (W, H))
+        assert abs(fov - oracle_lib.estimate_camera_fov(model, intr, dist, W, H)) <= 1e-12, name
+        assert abs(fov - nid.estimate_camera_fov_py(proj, (W, H))) <= 1e-12, name
+        p = rng.normal(size=(40, 3))
+        p[:, 2] = np.abs(p[:, 2]) + 1.0
+        uv, jac = proj.project(p, device=-1, jacobian=True)
+        ref_uv, ref_jac = oracle_lib.project_jacobian(model, intr, dist, p)
+        assert np.allclose(uv, ref_uv, rtol=1e-12, atol=1e-9), name
+        assert np.allclose(jac, ref_jac, rtol=1e-9, atol=1e-8), name
