@@ -24,8 +24,21 @@ __device__ __forceinline__ int cast_int_dev(double d) {  // x86 cvttsd2si semant
   return int(d);
 }
 
+// bin_points = max(0, min(bins - 1, int(intensity * bins))) (nid_cost.hpp:49, cost_calculator_nid.cpp:47) with the CALLER's bin
+// count; `lut` (nullable: bins > 256, nidreg.hip WideBins) then maps the occupied bins onto the compact range the kernels use
+__device__ __forceinline__ int point_bin(double intensity, int Bsrc, const uint16_t* __restrict__ lut) {
+  const int b = max(0, min(Bsrc - 1, cast_int_dev(intensity * double(Bsrc))));
+  return lut ? int(lut[b]) : b;
+}
+
+__global__ __launch_bounds__(256) void k_mark_bins(const double* __restrict__ v, long long n, int B, unsigned char* __restrict__ used) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  used[max(0, min(B - 1, cast_int_dev(v[i] * double(B))))] = 1;
+}
+
 __global__ __launch_bounds__(256) void k_build_keys(
-  const double* __restrict__ pts, const double* __restrict__ intensities, const unsigned char* __restrict__ keep, long long n, int B, int GW, int input_order,
+  const double* __restrict__ pts, const double* __restrict__ intensities, const unsigned char* __restrict__ keep, long long n, int Bsrc, const uint16_t* __restrict__ lut, int GW, int input_order,
   unsigned long long* __restrict__ keys, unsigned int* __restrict__ idx, int* __restrict__ not_lossless) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -36,7 +49,7 @@ __global__ __launch_bounds__(256) void k_build_keys(
   }
   const double x = pts[4 * i], y = pts[4 * i + 1], z = pts[4 * i + 2];
   if ((double(float(x)) != x && x == x) || (double(float(y)) != y && y == y) || (double(float(z)) != z && z == z)) *not_lossless = 1;
-  const int b = max(0, min(B - 1, cast_int_dev(intensities[i] * double(B))));
+  const int b = point_bin(intensities[i], Bsrc, lut);
   if (input_order) {  // NIDREG_FLAG_INPUT_ORDER: the caller's order inside each column group
     keys[i] = ((unsigned long long)(unsigned int)(b / GW) << 41) | (unsigned long long)(unsigned int)i;
     return;
@@ -69,7 +82,8 @@ __global__ __launch_bounds__(256) void k_build_bounds(const unsigned long long* 
 }
 
 template <typename Rec>
-__global__ __launch_bounds__(256) void k_build_gather(const double* __restrict__ pts, const double* __restrict__ intensities, const unsigned int* __restrict__ idx, long long kept, int B, Rec* __restrict__ recs) {
+__global__ __launch_bounds__(256) void k_build_gather(const double* __restrict__ pts, const double* __restrict__ intensities, const unsigned int* __restrict__ idx, long long kept, int Bsrc,
+                                                      const uint16_t* __restrict__ lut, Rec* __restrict__ recs) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= kept) return;
   const unsigned int s = idx[i];
@@ -77,7 +91,7 @@ __global__ __launch_bounds__(256) void k_build_gather(const double* __restrict__
   r.x = decltype(r.x)(pts[4 * (long long)s]);
   r.y = decltype(r.y)(pts[4 * (long long)s + 1]);
   r.z = decltype(r.z)(pts[4 * (long long)s + 2]);
-  r.bin = decltype(r.bin)(max(0, min(B - 1, cast_int_dev(intensities[s] * double(B)))));  // nid_cost.hpp:49, as in k_build_keys
+  r.bin = decltype(r.bin)(point_bin(intensities[s], Bsrc, lut));  // as in k_build_keys
   recs[i] = r;
 }
 
@@ -138,7 +152,7 @@ size_t build_scratch_bytes(long long n, bool cull, int W, int H) {
 }
 
 hipError_t build_records_device(
-  const double* d_pts, const double* d_intensities, long long n, const CullArgs* cull, int B, int GW, int NG, bool force_rec32, bool input_order, ScratchArena& arena,
+  const double* d_pts, const double* d_intensities, long long n, const CullArgs* cull, int Bsrc, const uint16_t* d_lut, int GW, int NG, bool force_rec32, bool input_order, ScratchArena& arena,
   void** d_recs_out, int* rec64_out, std::vector<int64_t>& gcount, hipStream_t stream) {
   hipError_t e = hipSuccess;
   unsigned char* d_keep = nullptr;
@@ -183,7 +197,7 @@ hipError_t build_records_device(
     CARVE(d_first, int*, 4096);
     BUILD_TRY(hipMemsetAsync(d_first, 0xff, (size_t(NG) + 1) * sizeof(int), stream));
     BUILD_TRY(hipMemsetAsync(d_first + NG + 1, 0, sizeof(int), stream));
-    hipLaunchKernelGGL(k_build_keys, dim3(grid), dim3(256), 0, stream, d_pts, d_intensities, d_keep, n, B, GW, input_order ? 1 : 0, d_keys, d_idx, d_first + NG + 1);
+    hipLaunchKernelGGL(k_build_keys, dim3(grid), dim3(256), 0, stream, d_pts, d_intensities, d_keep, n, Bsrc, d_lut, GW, input_order ? 1 : 0, d_keys, d_idx, d_first + NG + 1);
     BUILD_TRY(hipGetLastError());
     // key = [group : 23][column : 9][Morton code : 32], or [group : 23][input index : 41] to keep the caller's order inside
     // a group; removed points carry all-ones and sort last
@@ -212,9 +226,9 @@ hipError_t build_records_device(
     if (kept > 0) {
       const unsigned g2 = unsigned((kept + 255) / 256);
       if (rec64)
-        hipLaunchKernelGGL(k_build_gather<Rec64>, dim3(g2), dim3(256), 0, stream, d_pts, d_intensities, d_idx2, kept, B, static_cast<Rec64*>(d_recs));
+        hipLaunchKernelGGL(k_build_gather<Rec64>, dim3(g2), dim3(256), 0, stream, d_pts, d_intensities, d_idx2, kept, Bsrc, d_lut, static_cast<Rec64*>(d_recs));
       else
-        hipLaunchKernelGGL(k_build_gather<Rec32>, dim3(g2), dim3(256), 0, stream, d_pts, d_intensities, d_idx2, kept, B, static_cast<Rec32*>(d_recs));
+        hipLaunchKernelGGL(k_build_gather<Rec32>, dim3(g2), dim3(256), 0, stream, d_pts, d_intensities, d_idx2, kept, Bsrc, d_lut, static_cast<Rec32*>(d_recs));
       BUILD_TRY(hipGetLastError());
       BUILD_TRY(hipStreamSynchronize(stream));
     }
@@ -234,7 +248,8 @@ done:
 // (cost_calculator_nid.cpp:43-46) for CV_8UC1 input -- the same IEEE double operations as the host code they
 // replace.  One thread per padded pixel, written in the strip-tiled layout of load_patch.
 namespace {
-__global__ __launch_bounds__(256) void k_build_bin_image(const unsigned char* __restrict__ src, int is_f64, long long row_stride, int W, int H, int B, int pitch, int rows, uint8_t* __restrict__ dst) {
+__global__ __launch_bounds__(256) void k_build_bin_image(const unsigned char* __restrict__ src, int is_f64, long long row_stride, int W, int H, int B, const uint16_t* __restrict__ lut, int pitch, int rows,
+                                                         uint8_t* __restrict__ dst) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)pitch * rows) return;
   const int py = int(i / pitch), px = int(i % pitch);
@@ -247,14 +262,30 @@ __global__ __launch_bounds__(256) void k_build_bin_image(const unsigned char* __
     const double v = double(src[size_t(sy) * size_t(row_stride) + size_t(sx)]) / 255.0;
     b = max(0, min(B - 1, cast_int_dev(v * double(B))));
   }
+  if (lut) b = int(lut[b]);  // bins > 256: the occupied bins, compacted (nidreg.hip WideBins)
   dst[size_t(py >> 2) * size_t(pitch) * 4 + size_t(px) * 4 + size_t(py & 3)] = uint8_t(b);
 }
 }  // namespace
 
-hipError_t build_bin_image_device(const void* d_src, int is_f64, long long row_stride, int W, int H, int B, int pitch, int nstrips, uint8_t* d_img, hipStream_t stream) {
+hipError_t build_bin_image_device(const void* d_src, int is_f64, long long row_stride, int W, int H, int B, const uint16_t* d_lut, int pitch, int nstrips, uint8_t* d_img, hipStream_t stream) {
   const long long total = (long long)pitch * nstrips * 4;
-  hipLaunchKernelGGL(k_build_bin_image, dim3(unsigned((total + 255) / 256)), dim3(256), 0, stream, static_cast<const unsigned char*>(d_src), is_f64, row_stride, W, H, B, pitch, nstrips * 4, d_img);
+  hipLaunchKernelGGL(k_build_bin_image, dim3(unsigned((total + 255) / 256)), dim3(256), 0, stream, static_cast<const unsigned char*>(d_src), is_f64, row_stride, W, H, B, d_lut, pitch, nstrips * 4, d_img);
   return hipGetLastError();
+}
+
+// which of the B bins the n device-resident values v occupy (bins > 256 on a device-resident cloud: nidreg.hip resolve_wide_bins)
+hipError_t mark_bins_device(const double* d_v, long long n, int B, unsigned char* used_host) {
+  unsigned char* d_used = nullptr;
+  hipError_t e = hipMalloc(&d_used, size_t(B));
+  if (e != hipSuccess) return e;
+  e = hipMemset(d_used, 0, size_t(B));
+  if (e == hipSuccess && n > 0) {
+    hipLaunchKernelGGL(k_mark_bins, dim3(unsigned((n + 255) / 256)), dim3(256), 0, hipStream_t(nullptr), d_v, n, B, d_used);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(used_host, d_used, size_t(B), hipMemcpyDeviceToHost);
+  (void)hipFree(d_used);
+  return e;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -131,12 +131,15 @@ size_t build_scratch_bytes(long long n, bool cull, int W, int H);
 // cull nullable.  input_order: keep the caller's order inside each column group (stable sort on the group bits
 // only) instead of the Morton order.  Temporaries come from `arena` (reserved by the caller for at least
 // build_scratch_bytes).  Returns the record buffer (hipMalloc, caller owns), its type, and the column-group offsets.
+// Bsrc = the caller's bin count (bin_points = clamp(int(intensity * Bsrc))); d_lut (nullable; bins > 256): occupied bin -> compact bin.
 hipError_t build_records_device(
-  const double* d_pts, const double* d_intensities, long long n, const CullArgs* cull, int B, int GW, int NG, bool force_rec32, bool input_order, ScratchArena& arena,
+  const double* d_pts, const double* d_intensities, long long n, const CullArgs* cull, int Bsrc, const uint16_t* d_lut, int GW, int NG, bool force_rec32, bool input_order, ScratchArena& arena,
   void** d_recs_out, int* rec64_out, std::vector<int64_t>& gcount, hipStream_t stream);
+// which of the B bins the n device-resident values occupy (used_host: B bytes)
+hipError_t mark_bins_device(const double* d_v, long long n, int B, unsigned char* used_host);
 
 // bin image (nid_device.hpp load_patch layout: strips of four rows, padded by 1 left/top and >= 2 right/bottom,
 // edge replicated) from the caller's CV_64FC1 / CV_8UC1 image already uploaded to d_src (row stride in bytes)
-hipError_t build_bin_image_device(const void* d_src, int is_f64, long long row_stride, int W, int H, int B, int pitch, int nstrips, uint8_t* d_img, hipStream_t stream);
+hipError_t build_bin_image_device(const void* d_src, int is_f64, long long row_stride, int W, int H, int B, const uint16_t* d_lut, int pitch, int nstrips, uint8_t* d_img, hipStream_t stream);
 
 }  // namespace nidreg

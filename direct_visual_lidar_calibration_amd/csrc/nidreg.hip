@@ -67,6 +67,10 @@ const int kNumDist[6] = {5, 4, 4, 0, 1, 8};
 struct nidreg_handle {
   int device = 0;
   int model = 0, mode = 0, precision = 0, bins = 0;
+  // bins > 256 (WideBins below): `bins` is the compact count the kernels run on, bins_user the caller's; inv_*[compact] = the
+  // caller's bin (the getters expand with them).  bins_user == 0: the two are the same.
+  int bins_user = 0;
+  std::vector<uint16_t> inv_img, inv_pts;
   int W = 0, H = 0, pitch = 0;
   int GW = 0, NG = 0, cshift = 0;
   int wide = 0;  // k_spline_hist<.., WIDE>: B = 256, GW = 1, 32 copies, 512 threads
@@ -951,7 +955,75 @@ int64_t snap_to_groups(int64_t target, const int64_t* gcount, int NG, int64_t ca
   return per_group * nonempty;
 }
 
+// ---- bins > 256.  The reference takes any --nid_bins (src/calibrate.cpp:175, nid_cost.hpp:23).  The kernels' layouts -- an
+// 8-bit bin image, one histogram column of <= 256 cells per LDS tile -- hold 256 bins per axis, and the reference's own data
+// path never OCCUPIES more: the camera image is 8-bit (pix = k / 255, visual_camera_calibration.cpp:204) and the LiDAR
+// intensities are rank-equalised to floor(256 i / n) / 256 (preprocess.cpp:464-473), so a B x B histogram with B > 256 has at
+// most 256 non-empty rows and 256 non-empty columns.  The NID is a function of the MULTISET of cell values and of the row /
+// column sums (three entropies; an empty cell, row or column contributes p log(p + eps) = 0 exactly), so relabelling the
+// occupied bins 0, 1, 2, ... changes nothing -- not the cost, not the gradient; with the integer accumulation here not even
+// the bits.  At creation the occupied image bins and point bins (computed with the CALLER's bin count, the reference's own
+// expressions) are collected; if either axis occupies more than 256 the request is refused (never truncated), otherwise the
+// handle runs on the compact bins and the getters expand them back to the caller's B x B / B layout.
+struct WideBins {
+  int user_bins = 0, compact_bins = 0;
+  std::vector<uint16_t> lut_img, lut_pts;  // [user_bins]: the caller's bin -> compact bin (unoccupied: 0, never read)
+  std::vector<uint16_t> inv_img, inv_pts;  // [occupied]: compact bin -> the caller's bin
+};
+constexpr int kMaxWideBins = NIDREG_MAX_BINS_WIDE;
+
+int resolve_wide_bins(const nidreg_desc* d, const nidreg_cloud* cloud, WideBins& wb) {
+  const int B = d->bins;
+  if (d->ext_hist) return fail(NIDREG_ERR_INVALID, "nidreg_create: bins > 256 with a caller-provided histogram buffer (ext_hist) is not supported");
+  if (!d->image || d->width < 1 || d->height < 1) return fail(NIDREG_ERR_INVALID, "nidreg_create: bad image");
+  if (d->image_row_stride < int64_t(d->width) * (d->image_dtype == NIDREG_IMAGE_F64 ? 8 : 1)) return fail(NIDREG_ERR_INVALID, "nidreg_create: image_row_stride smaller than a row");
+  std::vector<unsigned char> used_img(size_t(B), 0), used_pts(size_t(B), 0);
+  const bool f64 = d->image_dtype == NIDREG_IMAGE_F64;
+  for (int y = 0; y < d->height; y++) {
+    const unsigned char* row = static_cast<const unsigned char*>(d->image) + size_t(y) * size_t(d->image_row_stride);
+    for (int x = 0; x < d->width; x++) {
+      int b;
+      if (f64) {
+        double v;
+        std::memcpy(&v, row + size_t(x) * 8, 8);
+        b = std::max(0, std::min(cast_int(v * double(B)), B - 1));  // nid_cost.hpp:78-79 (k_build_bin_image)
+      } else {
+        b = std::max(0, std::min(B - 1, cast_int(double(row[x]) / 255.0 * double(B))));  // cost_calculator_nid.cpp:43-46
+      }
+      used_img[size_t(b)] = 1;
+    }
+  }
+  if (cloud) {
+    HIP_TRY(hipSetDevice(cloud->device));
+    HIP_TRY(mark_bins_device(cloud->d_int, cloud->n, B, used_pts.data()));
+  } else {
+    for (int64_t i = 0; i < d->num_points; i++) used_pts[size_t(std::max(0, std::min(B - 1, cast_int(d->intensities[i] * double(B)))))] = 1;  // nid_cost.hpp:49
+  }
+  wb.user_bins = B;
+  wb.lut_img.assign(size_t(B), 0);
+  wb.lut_pts.assign(size_t(B), 0);
+  wb.inv_img.clear();
+  wb.inv_pts.clear();
+  for (int b = 0; b < B; b++) {
+    if (used_img[size_t(b)]) {
+      wb.lut_img[size_t(b)] = uint16_t(wb.inv_img.size() & 0xffff);
+      wb.inv_img.push_back(uint16_t(b));
+    }
+    if (used_pts[size_t(b)]) {
+      wb.lut_pts[size_t(b)] = uint16_t(wb.inv_pts.size() & 0xffff);
+      wb.inv_pts.push_back(uint16_t(b));
+    }
+  }
+  if (wb.inv_img.size() > size_t(NIDREG_MAX_BINS) || wb.inv_pts.size() > size_t(NIDREG_MAX_BINS))
+    return fail(NIDREG_ERR_INVALID, "nidreg_create: bins = " + std::to_string(B) + " with " + std::to_string(wb.inv_img.size()) + " occupied image bins and " + std::to_string(wb.inv_pts.size()) +
+                                      " occupied intensity bins: more than 256 bins per axis are supported only while at most 256 of them are occupied (8-bit images and 256-level "
+                                      "equalised intensities, what the reference's own pipeline produces, always are); refused, not truncated");
+  wb.compact_bins = int(std::max<size_t>(2, std::max(wb.inv_img.size(), wb.inv_pts.size())));
+  return NIDREG_OK;
+}
+
 struct CreateOpts {
+  const WideBins* wide = nullptr;  // bins > 256, already resolved by the caller (create_sharded); else create_impl resolves it itself
   // one shard of a ShardSet: built from the column groups [group_lo, group_hi) of `master` (a complete handle of the pair
   // on the owner device) -- its bin image and that slice of its bucketed records are copied device to device
   bool shard = false;
@@ -969,11 +1041,28 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
   // the LiDAR intensities are rank-equalised to floor(256 i / n) / 256 (preprocess.cpp:464-473) -- so more than 256 bins
   // only adds rows and columns that stay empty.  The kernels' layouts (8-bit bin image, one histogram column of <= 256 cells
   // per LDS tile) are built on that bound: refused, not truncated.
-  if (d->bins < 2 || d->bins > NIDREG_MAX_BINS)
-    return fail(NIDREG_ERR_INVALID, "nidreg_create: bins must be in [2, 256] (the reference accepts any --nid_bins, but its 8-bit images and 256-level equalised intensities fill at most 256 bins per axis; larger histograms are refused, not truncated)");
+  if (d->bins < 2 || d->bins > kMaxWideBins) return fail(NIDREG_ERR_INVALID, "nidreg_create: bins must be in [2, " + std::to_string(kMaxWideBins) + "]");
   if (d->width < 1 || d->height < 1 || (!d->image && !opts.shard)) return fail(NIDREG_ERR_INVALID, "nidreg_create: bad image");
   const nidreg_handle* master = opts.shard ? opts.master : nullptr;
   if (opts.shard && !master) return fail(NIDREG_ERR_INVALID, "nidreg_create: shard without a master");
+  // bins > 256: run on the occupied bins, compacted (WideBins above); a shard takes its master's compact layout
+  WideBins wide_here;
+  const WideBins* wide = opts.wide;
+  nidreg_desc dd;
+  if (!opts.shard && d->bins > NIDREG_MAX_BINS) {
+    if (!wide) {
+      if (d->image_dtype != NIDREG_IMAGE_F64 && d->image_dtype != NIDREG_IMAGE_U8) return fail(NIDREG_ERR_INVALID, "nidreg_create: bad image_dtype");
+      if (!cloud && (d->num_points < 0 || (d->num_points > 0 && !d->intensities))) return fail(NIDREG_ERR_INVALID, "nidreg_create: null points");
+      const int rc = resolve_wide_bins(d, cloud, wide_here);
+      if (rc) return rc;
+      wide = &wide_here;
+    }
+    dd = *d;
+    dd.bins = wide->compact_bins;
+    d = &dd;
+  } else if (opts.shard && d->bins > NIDREG_MAX_BINS) {
+    return fail(NIDREG_ERR_INVALID, "nidreg_create: a shard is created with its master's compact bin count");
+  }
   const int64_t n_in = master ? master->gcount[size_t(opts.group_hi)] - master->gcount[size_t(opts.group_lo)] : (cloud ? cloud->n : d->num_points);
   if (n_in < 0 || n_in > int64_t(INT_MAX)) return fail(NIDREG_ERR_INVALID, "nidreg_create: bad num_points");
   if (!master && !cloud && n_in > 0 && (!d->points || !d->intensities)) return fail(NIDREG_ERR_INVALID, "nidreg_create: null points");
@@ -992,6 +1081,15 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
   h->mode = d->mode;
   h->precision = d->precision;
   h->bins = d->bins;
+  if (wide) {
+    h->bins_user = wide->user_bins;
+    h->inv_img = wide->inv_img;
+    h->inv_pts = wide->inv_pts;
+  } else if (master && master->bins_user) {
+    h->bins_user = master->bins_user;
+    h->inv_img = master->inv_img;
+    h->inv_pts = master->inv_pts;
+  }
   h->W = d->width;
   h->H = d->height;
   h->num_points = n_in;
@@ -1093,7 +1191,16 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
     const size_t up_img = ((src_row * size_t(H)) + 255) & ~size_t(255);
     const size_t up_pts = cloud ? 0 : ((size_t(std::max<int64_t>(n_in, 1)) * 32 + 255) & ~size_t(255));
     const size_t up_int = cloud ? 0 : ((size_t(std::max<int64_t>(n_in, 1)) * 8 + 255) & ~size_t(255));
-    CREATE_TRY(arena.reserve(up_img + up_pts + up_int + build_scratch_bytes(n_in, T_cull != nullptr, W, H) + 4096));
+    const size_t up_lut = wide ? ((size_t(wide->user_bins) * 2 + 255) & ~size_t(255)) : 0;
+    CREATE_TRY(arena.reserve(up_img + up_pts + up_int + 2 * up_lut + build_scratch_bytes(n_in, T_cull != nullptr, W, H) + 4096));
+    const int Bsrc = wide ? wide->user_bins : B;  // the bin count the caller's values are binned with
+    uint16_t *d_lut_img = nullptr, *d_lut_pts = nullptr;
+    if (wide) {
+      d_lut_img = static_cast<uint16_t*>(arena.carve(up_lut));
+      d_lut_pts = static_cast<uint16_t*>(arena.carve(up_lut));
+      CREATE_TRY(hipMemcpy(d_lut_img, wide->lut_img.data(), size_t(wide->user_bins) * 2, hipMemcpyHostToDevice));
+      CREATE_TRY(hipMemcpy(d_lut_pts, wide->lut_pts.data(), size_t(wide->user_bins) * 2, hipMemcpyHostToDevice));
+    }
 
     // bin image: bin_image = min(int(pix * bins), bins - 1) (nid_cost.hpp:78-79) for CV_64FC1 input;
     // max(0, min(bins-1, int(u8 / 255.0 * bins))) (cost_calculator_nid.cpp:43-46) for CV_8UC1 input;
@@ -1101,7 +1208,7 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
     void* d_src = arena.carve(up_img);
     CREATE_TRY(hipMalloc(&h->d_img, img_bytes));
     CREATE_TRY(hipMemcpy2D(d_src, src_row, d->image, size_t(d->image_row_stride), src_row, size_t(H), hipMemcpyHostToDevice));
-    CREATE_TRY(build_bin_image_device(d_src, img_f64 ? 1 : 0, (long long)src_row, W, H, B, h->pitch, nstrips, h->d_img, nullptr));
+    CREATE_TRY(build_bin_image_device(d_src, img_f64 ? 1 : 0, (long long)src_row, W, H, Bsrc, d_lut_img, h->pitch, nstrips, h->d_img, nullptr));
 
     // points: bin_points = max(0, min(bins-1, int(intensity * bins))) (nid_cost.hpp:49, cost_calculator_nid.cpp:47)
     // is pose independent -> records are bucketed by column group, so a workgroup owns GW histogram columns;
@@ -1137,7 +1244,7 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
     }
     void* recs = nullptr;
     int rec64 = 0;
-    CREATE_TRY(build_records_device(d_cloud_pts, d_cloud_int, n_in, T_cull ? &ca : nullptr, B, GW, h->NG, d->precision == NIDREG_PREC_FP32, (d->flags & NIDREG_FLAG_INPUT_ORDER) != 0,
+    CREATE_TRY(build_records_device(d_cloud_pts, d_cloud_int, n_in, T_cull ? &ca : nullptr, Bsrc, d_lut_pts, GW, h->NG, d->precision == NIDREG_PREC_FP32, (d->flags & NIDREG_FLAG_INPUT_ORDER) != 0,
                                     arena, &recs, &rec64, gcount, nullptr));
     h->d_pts = recs;
     h->rec64 = rec64;
@@ -2307,7 +2414,8 @@ int create_sharded(const nidreg_desc* d, const nidreg_cloud* cloud, const double
   const int n = int(ids.size());
   if (n > kMaxShards) return fail(NIDREG_ERR_INVALID, "nidreg_create: at most 16 shards");
   if (!cloud && (d->num_points < 0 || (d->num_points > 0 && (!d->points || !d->intensities)))) return fail(NIDREG_ERR_INVALID, "nidreg_create: null points");
-  if (d->bins < 2 || d->bins > NIDREG_MAX_BINS) return fail(NIDREG_ERR_INVALID, "nidreg_create: bins must be in [2, 256]");
+  if (d->bins < 2 || d->bins > kMaxWideBins) return fail(NIDREG_ERR_INVALID, "nidreg_create: bins must be in [2, " + std::to_string(kMaxWideBins) + "]");
+  if (d->image_dtype != NIDREG_IMAGE_F64 && d->image_dtype != NIDREG_IMAGE_U8) return fail(NIDREG_ERR_INVALID, "nidreg_create: bad image_dtype");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(NIDREG_ERR_NO_DEVICE, "nidreg_create: no HIP device (the NID core has no CPU path)");
   for (int id : ids)
@@ -2328,7 +2436,12 @@ int create_sharded(const nidreg_desc* d, const nidreg_cloud* cloud, const double
   // ---- the master: the complete pair on the owner device (where the cloud lives / the first listed device): upload,
   // [ViewCulling::cull,] bucketing by column group, Morton sort, gather, bin image -- once; the shards then take their
   // column groups' records (already in their final order) device to device
-  const int B = d->bins;
+  WideBins wide;  // bins > 256: the shards run on the occupied bins, compacted (resolve_wide_bins)
+  if (d->bins > NIDREG_MAX_BINS) {
+    const int rc = resolve_wide_bins(d, cloud, wide);
+    if (rc) return rc;
+  }
+  const int B = wide.user_bins ? wide.compact_bins : d->bins;
   nidreg_desc md = *d;
   md.num_devices = 1;
   md.device_id = cloud ? cloud->device : ids[0];
@@ -2336,9 +2449,12 @@ int create_sharded(const nidreg_desc* d, const nidreg_cloud* cloud, const double
   md.scale_points = std::max<int64_t>(cloud ? cloud->n : d->num_points, d->scale_points);  // the fixed-point unit of the unsharded handle
   nidreg_handle* master = nullptr;
   {
-    const int rc = create_impl(&md, cloud, T_cull, min_z, enable_depth, CreateOpts(), &master);
+    CreateOpts mo;
+    if (wide.user_bins) mo.wide = &wide;
+    const int rc = create_impl(&md, cloud, T_cull, min_z, enable_depth, mo, &master);
     if (rc) return rc;
   }
+  md.bins = B;  // (the shards below are created with the compact count)
   // every cut between shards is a whole number of k_entropy_repl column blocks: CB columns per block, the largest of 8, 4, 2, 1
   // that tiles with the column groups (GW columns each) and still leaves every shard a cut unit of its own
   const int GWm = master->GW, NGm = master->NG;
@@ -2847,8 +2963,15 @@ int nidreg_get_hist_fixed(nidreg_handle* h, int64_t* joint, int64_t* inliers, in
   HIP_TRY(hipMemcpy(tmp.data(), h->d_hist, tmp.size() * sizeof(u64), hipMemcpyDeviceToHost));
   if (joint) {
     // device layout [bin_points][bin_image] -> [bin_image][bin_points]
-    for (int c = 0; c < B; c++)
-      for (int r = 0; r < B; r++) joint[size_t(r) * B + c] = int64_t(tmp[size_t(c) * B + r]);
+    if (h->bins_user) {  // bins > 256: the compact bins back to the caller's (every other cell is empty)
+      const size_t Bu = size_t(h->bins_user);
+      std::fill(joint, joint + Bu * Bu, int64_t(0));
+      for (size_t c = 0; c < h->inv_pts.size(); c++)
+        for (size_t r = 0; r < h->inv_img.size(); r++) joint[size_t(h->inv_img[r]) * Bu + size_t(h->inv_pts[c])] = int64_t(tmp[c * size_t(B) + r]);
+    } else {
+      for (int c = 0; c < B; c++)
+        for (int r = 0; r < B; r++) joint[size_t(r) * B + c] = int64_t(tmp[size_t(c) * B + r]);
+    }
   }
   if (inliers) *inliers = int64_t(tmp[size_t(B) * B + kTailInliers]);
   if (frac_bits) *frac_bits = h->frac_bits;
@@ -2857,9 +2980,9 @@ int nidreg_get_hist_fixed(nidreg_handle* h, int64_t* joint, int64_t* inliers, in
 
 int nidreg_get_hist(nidreg_handle* h, double* joint, double* hist_image, double* hist_points) {
   if (!h) return fail(NIDREG_ERR_INVALID, "nidreg_get_hist: null handle");
-  const int B = h->bins;
+  const int B = h->bins, Bu = h->bins_user ? h->bins_user : h->bins;
   if (joint) {
-    std::vector<int64_t> fx(size_t(B) * B);
+    std::vector<int64_t> fx(size_t(Bu) * Bu);
     const int rc = nidreg_get_hist_fixed(h, fx.data(), nullptr, nullptr);
     if (rc) return rc;
     const double inv_unit = 1.0 / fixed_unit(h);
@@ -2867,6 +2990,20 @@ int nidreg_get_hist(nidreg_handle* h, double* joint, double* hist_image, double*
   }
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipStreamSynchronize(h->last_stream ? h->last_stream : h->stream));  // (see nidreg_get_hist_fixed)
+  if (h->bins_user) {
+    std::vector<double> hi(static_cast<size_t>(B)), hp(static_cast<size_t>(B));
+    HIP_TRY(hipMemcpy(hi.data(), h->d_hist_image, size_t(B) * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hp.data(), h->d_hist_points, size_t(B) * sizeof(double), hipMemcpyDeviceToHost));
+    if (hist_image) {
+      std::fill(hist_image, hist_image + Bu, 0.0);
+      for (size_t r = 0; r < h->inv_img.size(); r++) hist_image[h->inv_img[r]] = hi[r];
+    }
+    if (hist_points) {
+      std::fill(hist_points, hist_points + Bu, 0.0);
+      for (size_t c = 0; c < h->inv_pts.size(); c++) hist_points[h->inv_pts[c]] = hp[c];
+    }
+    return NIDREG_OK;
+  }
   if (hist_image) HIP_TRY(hipMemcpy(hist_image, h->d_hist_image, size_t(B) * sizeof(double), hipMemcpyDeviceToHost));
   if (hist_points) HIP_TRY(hipMemcpy(hist_points, h->d_hist_points, size_t(B) * sizeof(double), hipMemcpyDeviceToHost));
   return NIDREG_OK;

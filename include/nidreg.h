@@ -85,7 +85,15 @@ extern "C" {
 #define NIDREG_IMAGE_F64 0  /* CV_64FC1 normalised to [0,1] (what NIDCost receives) */
 #define NIDREG_IMAGE_U8 1   /* CV_8UC1 (what CostCalculatorNID receives) */
 
+/* nidreg_desc.bins: 2 .. NIDREG_MAX_BINS_WIDE, like the reference's `const int bins` (nid_cost.hpp:23, --nid_bins of
+ * src/calibrate.cpp:175).  The kernels hold NIDREG_MAX_BINS bins per axis; more are accepted while at most NIDREG_MAX_BINS of
+ * them are OCCUPIED on each axis -- always the case for the reference's own data path (8-bit camera images,
+ * visual_camera_calibration.cpp:204; intensities rank-equalised to 256 levels, preprocess.cpp:464-473).  The NID and its
+ * gradient depend on the multiset of histogram cells and on the marginals only, so the handle runs on the occupied bins,
+ * relabelled 0, 1, 2, ... (same cost, same gradient), and nidreg_get_hist* expand them back to the caller's layout.  An input
+ * that occupies more than 256 bins on an axis is refused with NIDREG_ERR_INVALID (never truncated). */
 #define NIDREG_MAX_BINS 256
+#define NIDREG_MAX_BINS_WIDE 4096
 #define NIDREG_MAX_DEVICES 16
 
 /* nidreg_desc.flags */

@@ -27,6 +27,9 @@ CASES = [  # (model, intrinsics, distortion, W, H, bins, points, seed)
     ("equirectangular", [128.0, 64.0], [], 128, 64, 256, 1500, 205),
     ("atan", [66.0, 64.0, 48.0, 36.0], [0.6], 96, 72, 16, 1200, 206),
     ("rational_polynomial", [66.0, 64.0, 48.0, 36.0], [0.05, -0.02, 1e-4, -2e-4, 0.01, 0.03, -0.01, 0.002], 96, 72, 100, 1200, 207),
+    # more bins than the kernels hold per axis (256): what the reference returns at --nid_bins 512 on its own kind of data (8-bit
+    # image, 256-level intensities) -- 256 occupied rows and columns of a 512 x 512 table, i.e. the 256-bin NID again (ref_cost_at_256)
+    ("plumb_bob", [66.0, 64.0, 48.0, 36.0], [-0.04, 0.08, 1e-4, -3e-4, -0.04], 96, 72, 512, 1500, 208),
 ]
 
 out = {"num_cases": np.array(len(CASES))}
@@ -69,6 +72,9 @@ for k, (model, intr, dist, W, H, bins, n, seed) in enumerate(CASES):
         p + "ref_cull_depth": ref_lib.view_culling(model, intr, dist, W, H, pts, T, True), p + "ref_cull_nodepth": ref_lib.view_culling(model, intr, dist, W, H, pts, T, False),
         p + "ref_uv": uv, p + "ref_jac": jac, p + "ref_lidar_index": lidar_idx, p + "ref_lidar_intensity": lidar_img,
     })
+    if bins > 256:
+        out[p + "ref_cost_at_256"] = np.array(ref_lib.nid_cost(model, intr, dist, img64, pts[:n_cost], inten[:n_cost], 256, x)["cost"])
+        out[p + "ref_nearest_cost_at_256"] = np.array(ref_lib.cost_calculator_nid(model, intr, dist, s.image_u8, pts, inten, 256, T))
     print(model, bins, "cost", r["cost"], "culled", out[p + "ref_cull_depth"].shape[0], "of", pts.shape[0], "lidar pixels", int((lidar_idx >= 0).sum()))
 os.makedirs(os.path.join(HERE, "golden"), exist_ok=True)
 path = os.path.join(HERE, "golden", "reference_cases.npz")

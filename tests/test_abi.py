@@ -59,16 +59,22 @@ def test_model_table_and_no_device_error():
         assert (ni.value, nd.value) == (a, b)
     assert lib.nidreg_model_from_name(b"pinhole", None, None) == -1
     assert nid.create_camera("pinhole", [1, 2, 3, 4], []) is None
-    # bins: 2..256; anything else is refused with a message that names the reference's behaviour, before any device is touched
-    # (the reference accepts any --nid_bins, src/calibrate.cpp:175; its 8-bit images and 256-level intensities fill <= 256 bins)
+    # bins: 2..4096 like the reference's `int bins` (src/calibrate.cpp:175 --nid_bins); beyond 256 only while <= 256 bins per
+    # axis are OCCUPIED (8-bit images, 256-level intensities: the reference's own data path) -- an input that occupies more is
+    # refused with a message that says so, before any device is touched; never truncated
     import numpy as np
 
     cam0 = nid.create_camera("plumb_bob", [100, 100, 50, 50], [])
-    for bad in (257, 512, 1, 0, -3):
-        with pytest.raises(RuntimeError, match=r"bins must be in \[2, 256\]"):
+    for bad in (4097, 100000, 1, 0, -3):
+        with pytest.raises(RuntimeError, match=r"bins must be in \[2, 4096\]"):
             nid.NIDCost(cam0, np.zeros((100, 100)), np.zeros((4, 4)), np.zeros(4), bad)
-        with pytest.raises(RuntimeError, match=r"bins must be in \[2, 256\]"):
+        with pytest.raises(RuntimeError, match=r"bins must be in \[2, 4096\]"):
             nid.CostCalculatorNID(cam0, np.zeros((100, 100), dtype=np.uint8), np.zeros((4, 4)), np.zeros(4), nid.NIDCostParams(bad), max_fov=1.0)
+    ramp = np.linspace(0.0, 1.0, 100 * 100).reshape(100, 100)  # 10^4 distinct grey values: 512 occupied image bins at bins = 512
+    with pytest.raises(RuntimeError, match=r"512 occupied image bins .* refused, not truncated"):
+        nid.NIDCost(cam0, ramp, np.zeros((4, 4)), np.zeros(4), 512)
+    with pytest.raises(RuntimeError, match=r"300 occupied intensity bins"):
+        nid.NIDCost(cam0, np.zeros((100, 100)), np.zeros((300, 4)), (np.arange(300) + 0.5) / 300.0, 300)
     if lib.nidreg_device_count() == 0:
         # the product path fails loudly without a GPU: no CPU fallback
         import numpy as np

@@ -598,6 +598,56 @@ def test_eight_fisheye_pairs_as_one_grid_match_the_summed_oracle():
         h.close()
 
 
+@pytest.mark.parametrize("bins", [300, 512, 4096])
+def test_bins_above_256_run_on_the_occupied_bins(bins):
+    """The reference takes any --nid_bins (src/calibrate.cpp:175); its 8-bit images and 256-level intensities occupy at most
+    256 bins per axis however many there are.  A handle with bins > 256 runs on the occupied bins, relabelled 0, 1, 2, ... --
+    the NID depends on the multiset of cells and the marginals only -- and must give the oracle's value and gradient AT THAT
+    BIN COUNT, the bits of the same data at 256 bins, and histograms in the caller's own B x B layout.  SPLINE and NEAREST,
+    plain / device-resident cloud / sharded."""
+    s = scene_for("plumb_bob", n=30011)
+    proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
+    rng = np.random.default_rng(12)
+    poses = [s.T_camera_lidar_init, synth.random_pose_near(s.T_camera_lidar_true, rng)]
+    wide = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, bins)
+    b256 = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, 256)
+    cl = nid.Cloud(s.points, s.intensities)
+    from_cloud = nid.NIDCost.from_cloud(proj, s.image_f64, cl, bins)
+    sharded = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, bins, devices=[0, 0, 0])
+    for k, x in enumerate(poses):
+        ok, c, g = wide(x)
+        ok2, c2, g2 = b256(x)
+        assert ok and ok2 and c == c2 and np.array_equal(g, g2)  # a monotone relabelling of the same 256 x 256 cells
+        ok3, c3, g3 = from_cloud(x)
+        assert ok3 and c3 == c and np.allclose(g3, g, rtol=1e-11, atol=1e-14)
+        ok4, c4, g4 = sharded(x)
+        assert ok4 and c4 == c and np.allclose(g4, g, rtol=1e-11, atol=1e-14)
+        if k == 0 and bins <= 512:  # (the oracle's Jet histogram at 4096 bins is 1 GB: the 256-bin identity above covers it)
+            ref = oracle_nid(s, bins, x, want_hist=True)
+            parity.check_cost(c, ref["cost"], what=f"bins {bins}")
+            parity.check_grad(g, ref["grad"], what=f"bins {bins}")
+            joint, hi, hp = wide.histograms()
+            assert joint.shape == (bins, bins)
+            parity.check_hist(joint, ref["hist"], atol=parity.hist_atol_for(ref["hist"], wide.info()["frac_bits"]), what=f"bins {bins}")
+            assert np.array_equal(hp, ref["hist_points"])
+            assert np.allclose(hi, ref["hist_image"], rtol=0, atol=1e-8)
+            js, _, _ = sharded.histograms()
+            assert np.array_equal(js, joint)
+    for h in (wide, b256, from_cloud, sharded):
+        h.close()
+    cl.close()
+    # the derivative-free twin: integer histogram in the caller's layout, bit for bit
+    if bins <= 512:
+        max_fov = oracle_lib.estimate_camera_fov(s.model, s.intrinsics, s.distortion, s.width, s.height)
+        calc = nid.CostCalculatorNID(proj, s.image_u8, s.points, s.intensities, nid.NIDCostParams(bins), max_fov=max_fov)
+        T = se3.to_matrix(poses[1])
+        rc, rh = oracle_lib.cost_calculator_nid(s.model, s.intrinsics, s.distortion, s.image_u8, s.points, s.intensities, bins, max_fov, T, want_hist=True)
+        cn = calc.calculate(T)
+        fx, inl, frac = calc.histogram_fixed()
+        assert frac == 0 and fx.shape == (bins, bins) and np.array_equal(fx, rh) and int(fx.sum()) == inl and abs(cn - rc) <= 1e-12
+        calc.close()
+
+
 def test_nearest_twin_10m_points_bit_exact():
     """CostCalculatorNID::calculate (cost_calculator_nid.cpp:21-67) on the headline cloud: the integer joint histogram of
     10M points bit for bit against the oracle's serial loop (~1 s of CPU), NID to 1e-12."""

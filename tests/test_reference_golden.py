@@ -158,3 +158,15 @@ def test_gpu_engine_reproduces_reference_outputs(c):
     uv, jac = proj.project(pc, jacobian=True)
     fin = np.isfinite(c["ref_uv"]).all(axis=1)
     assert np.allclose(uv[fin], c["ref_uv"][fin], rtol=1e-12, atol=1e-9) and np.allclose(jac[fin], c["ref_jac"][fin], rtol=1e-9, atol=1e-9)
+
+
+def test_reference_returns_the_256_bin_nid_at_512_bins():
+    """What the reference's own sources return at --nid_bins 512 on its own kind of data (8-bit image, 256-level equalised
+    intensities): 256 occupied rows and columns of a 512 x 512 table -- the NID of the 256-bin histogram, relabelled.  This is
+    the fact the engine's handling of bins > 256 rests on (include/nidreg.h NIDREG_MAX_BINS_WIDE: it runs on the occupied bins)."""
+    wide = [c for c in CASES if c["bins"] > 256]
+    assert wide
+    for c in wide:
+        assert abs(float(c["ref_cost"]) - float(c["ref_cost_at_256"])) <= 1e-13
+        assert abs(float(c["ref_nearest_cost"]) - float(c["ref_nearest_cost_at_256"])) <= 1e-13
+        assert len(np.unique(c["image_u8"])) <= 256 and len(np.unique(c["intensities"])) <= 256
