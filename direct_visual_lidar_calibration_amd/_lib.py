@@ -16,7 +16,7 @@ NIDREG_FALSE = 1
 NIDREG_OUT_DOUBLES = 16
 
 MODE_SPLINE, MODE_NEAREST = 0, 1
-PREC_FP64, PREC_FP32 = 0, 1
+PREC_FP64 = 0  # (1 = NIDREG_PREC_FP32: removed in round 5, refused by nidreg_create)
 IMAGE_F64, IMAGE_U8 = 0, 1
 FLAG_INPUT_ORDER = 1
 FLAG_EXT_STREAM = 2
@@ -144,7 +144,7 @@ def kernel_source_hash():
     import hashlib
 
     h = hashlib.sha256()
-    names = ["nid_device.hpp", "nid_atan_table.hpp", "nid_multi.hpp", "nid_kernels.hpp", "nid_launch_impl.hpp", "nid_kernels_f64.hip", "nid_kernels_f32.hip", "nid_kernels_f64_exact.hip", "Makefile"]
+    names = ["nid_device.hpp", "nid_atan_table.hpp", "nid_multi.hpp", "nid_kernels.hpp", "nid_launch_impl.hpp", "nid_kernels_f64.hip", "nid_kernels_f64_exact.hip", "Makefile"]
     for path in [os.path.join(CSRC_DIR, n) for n in names]:
         h.update(os.path.basename(path).encode())
         with open(path, "rb") as f:

@@ -34,7 +34,7 @@ def build_parser():
     p.add_argument("--nelder_mead_convergence_criteria", type=float, default=1e-8, help="Nelder-mead convergence criteria")
     p.add_argument("--auto_quit", action="store_true", help="accepted for compatibility (there is no viewer to keep open)")
     p.add_argument("--background", action="store_true", help="accepted for compatibility (there is no viewer to hide)")
-    p.add_argument("--precision", default="fp64", choices=["fp64", "fp32"], help="geometry precision of the cost kernels (extension; the reference is fp64)")
+    p.add_argument("--precision", default="fp64", choices=["fp64"], help="geometry precision of the cost kernels (extension; the reference is fp64)")
     p.add_argument("--dry_run", action="store_true", help="load and validate the dataset, do not optimise or write (extension)")
     return p
 

@@ -25,6 +25,12 @@ namespace nidreg {
 
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
+#ifdef NID_EXP_HANDOFF
+// EXPERIMENT (VERDICT r4 #6 ii; profiles/r05_experiments.md): the histogram pass hands every record's projected (u, v) to the
+// gradient pass as an fp64 pair, 16 B / point, instead of the gradient pass recomputing the projection's value.  One buffer per
+// process (the experiment runs one handle), set by nidreg::set_handoff_buffer.
+static __device__ double2* g_uv_handoff;
+#endif
 #ifndef NID_UNROLL
 #define NID_UNROLL 4
 #endif
@@ -481,6 +487,9 @@ __device__ __forceinline__ void spline_hist_body(
         // floor(u) in [0,W) and floor(v) in [0,H); NaN / inf / overflow compare false -> outlier
         // (the reference's int conversion sends those to INT_MIN, nid_cost.hpp:52-58)
         ins[k] = bool(int(valid) & int(us[k] >= real(0)) & int(us[k] < fW) & int(vs[k] >= real(0)) & int(vs[k] < fH));  // no short circuit: branch-free
+#ifdef NID_EXP_HANDOFF
+        if (valid) g_uv_handoff[seg.pos + base + uint32_t(k) * kT + tid] = make_double2(double(us[k]), double(vs[k]));
+#endif
         inl += ins[k] ? 1u : 0u;
         all_in = bool(int(all_in) & int(ins[k]));
       }
@@ -1150,7 +1159,7 @@ enum { TAP_COPIES = 0,   // gtile[(cell << cshift) + lane copy]: lane-private co
 template <int MODEL, typename Rec, typename real, int TAP, int kT, bool SPLIT>
 __device__ __forceinline__ void spline_grad_loop(
   const Rec* __restrict__ recs, uint32_t cnt, uint32_t col0, uint32_t done, uint32_t total, const uint8_t* __restrict__ img, int pitch, int W, int H, const PoseParams<real>& pose,
-  const CamParams<real>& cam, int B, int cshift, const double* gtile, double* acc, bool prio) {
+  const CamParams<real>& cam, int B, int cshift, const double* gtile, double* acc, bool prio, uint32_t rec0 = 0) {
   const int tid = threadIdx.x;
   if (TAP == TAP_SINGLE) cshift = 0;
   const uint32_t cmask = (1u << cshift) - 1u;
@@ -1166,6 +1175,11 @@ __device__ __forceinline__ void spline_grad_loop(
     RawBatch<Rec, kUnroll> rb;
 #pragma unroll
     for (int k = 0; k < kUnroll; k++) rb.load(rec_base, (GUARDED ? min(base + uint32_t(k) * kT + tid, cnt - 1u) : base + uint32_t(k) * kT + tid) * uint32_t(sizeof(Rec)), k);
+#ifdef NID_EXP_HANDOFF
+    double2 huv[kUnroll];
+#pragma unroll
+    for (int k = 0; k < kUnroll; k++) huv[k] = g_uv_handoff[rec0 + (GUARDED ? min(base + uint32_t(k) * kT + tid, cnt - 1u) : base + uint32_t(k) * kT + tid)];
+#endif
 #pragma unroll
     for (int k = 0; k < kUnroll; k++) rb.template get<real>(k, xs[k], ys[k], zs[k], bins_[k]);
 #pragma unroll
@@ -1178,6 +1192,9 @@ __device__ __forceinline__ void spline_grad_loop(
       real uu, vv;
       ProjCtx<real> ctx;
       project_fwd<MODEL, real>(cam, cx, cy, cz, uu, vv, ctx);
+#ifdef NID_EXP_HANDOFF
+      uu = real(huv[k].x), vv = real(huv[k].y);  // the value half of project_fwd above is dead code now
+#endif
       const bool in = (uu >= real(0)) && (uu < fW) && (vv >= real(0)) && (vv < fH);
       if (in) {
         const int kx = int(uu), ky = int(vv);  // uu, vv >= 0 here: truncation is the floor knot
@@ -1495,7 +1512,7 @@ __global__ __launch_bounds__(kThreads, grad_min_waves(MODEL, SEG, sizeof(Rec) ==
     }
     const uint32_t seg_end = SEG ? seg.seg_end() : seg.end;
     spline_grad_loop<MODEL, Rec, real, GW1 ? TAP_SINGLE : TAP_COPIES, kThreads, !SEG>(pts + seg.pos, seg_end - seg.pos, seg.g * uint32_t(GW), seg.pos - ch.start, ch.count, img, pitch, W, H, pose,
-                                                                               cam, B, cshift, gtile, acc, prio != 0);
+                                                                               cam, B, cshift, gtile, acc, prio != 0, seg.pos);
     stamp_stage(3);
     grad_reduce_store<kThreads>(acc, s_red, partials, slot, nslots);
     stamp_stage(4);

@@ -26,6 +26,10 @@ template <> hipError_t launch_project<double>(int model, const double* intr, con
   return hipGetLastError();
 }
 
+#ifdef NID_EXP_HANDOFF
+hipError_t set_handoff_buffer(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_uv_handoff), &p, sizeof(p)); }
+#endif
+
 // the same projection code on the HOST (nid_device.hpp's scalar math is __host__ __device__): for callers that project a
 // handful of points at a time -- estimate_camera_fov inverts the projection at three pixels with NelderMead<2>, ~240 probes
 // of ONE point (src/vlcal/common/estimate_fov.cpp:17-51), host work in the reference as well

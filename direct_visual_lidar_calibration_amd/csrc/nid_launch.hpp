@@ -75,6 +75,9 @@ template <typename real> int occupancy_spline_hist(const PassArgs& a);
 template <typename real> int occupancy_spline_grad(const PassArgs& a);
 template <typename real> hipError_t launch_project(int model, const double* intr, const double* dist, const double* p3, long long n, double* uv, double* jac, hipStream_t stream);
 
+#ifdef NID_EXP_HANDOFF
+hipError_t set_handoff_buffer(void* p);  // nid_kernels_f64.hip (experiment)
+#endif
 // the same scalar projection code run on the host (nid_kernels_f64.hip): host arrays, fp64, 0 = ok
 int project_host(int model, const double* intr, const double* dist, const double* p3, long long n, double* uv, double* jac);
 

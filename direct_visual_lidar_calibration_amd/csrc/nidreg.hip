@@ -492,11 +492,7 @@ int launch_hist_spline(nidreg_handle* h, const double* se3, bool alone = false) 
   HIP_TRY(begin_histogram(h));
   a.hist = h->d_hist;
   if (h->timing == 1) HIP_TRY(hipEventRecord(h->ev[1], h->stream));
-  if (h->precision == NIDREG_PREC_FP32) {
-    HIP_TRY(launch_spline_hist<float>(a));
-  } else {
-    HIP_TRY(launch_spline_hist<double>(a));
-  }
+  HIP_TRY(launch_spline_hist<double>(a));
   return NIDREG_OK;
 }
 
@@ -542,11 +538,7 @@ int launch_hist_nearest(nidreg_handle* h, const double* T) {
   HIP_TRY(begin_histogram(h));
   a.hist = h->d_hist;
   if (h->timing == 1) HIP_TRY(hipEventRecord(h->ev[1], h->stream));
-  if (h->precision == NIDREG_PREC_FP32) {
-    HIP_TRY(launch_nearest_hist<float>(a));
-  } else {
-    HIP_TRY(launch_nearest_hist<double>(a));
-  }
+  HIP_TRY(launch_nearest_hist<double>(a));
   return NIDREG_OK;
 }
 
@@ -594,11 +586,7 @@ int launch_grad(nidreg_handle* h, bool alone = false, int from_partials = 0) {
   // same pose as the histogram pass of this evaluation
   std::memcpy(a.R, h->last_R, sizeof(a.R));
   std::memcpy(a.t, h->last_t, sizeof(a.t));
-  if (h->precision == NIDREG_PREC_FP32) {
-    HIP_TRY(launch_spline_grad<float>(a));
-  } else {
-    HIP_TRY(launch_spline_grad<double>(a));
-  }
+  HIP_TRY(launch_spline_grad<double>(a));
   if (h->timing == 1) HIP_TRY(hipEventRecord(h->ev[4], h->stream));
   if (h->nchunks == 0) {  // empty cloud: no gradient workgroups ran, finalise (zeros) stand-alone
     hipLaunchKernelGGL(k_grad_final, dim3(1), dim3(kThreads), 0, h->stream, h->d_partials, 0, h->last_q[0], h->last_q[1], h->last_q[2], h->last_q[3], h->d_out, h->d_out_host, h->seq);
@@ -1068,7 +1056,10 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
   if (!master && !cloud && n_in > 0 && (!d->points || !d->intensities)) return fail(NIDREG_ERR_INVALID, "nidreg_create: null points");
   if (cloud && cloud->device != d->device_id) return fail(NIDREG_ERR_INVALID, "nidreg_create_from_cloud: cloud lives on another device");
   if (d->mode != NIDREG_MODE_SPLINE && d->mode != NIDREG_MODE_NEAREST) return fail(NIDREG_ERR_INVALID, "nidreg_create: bad mode");
-  if (d->precision != NIDREG_PREC_FP64 && d->precision != NIDREG_PREC_FP32) return fail(NIDREG_ERR_INVALID, "nidreg_create: bad precision");
+  // (NIDREG_PREC_FP32 -- float transform / projection, everything else as now -- existed until round 4: +8 % on the headline, for
+  // |dNID| <= 2e-5; a mode that cheap to lose was not worth its kernel instantiations and was removed rather than kept half-built)
+  if (d->precision != NIDREG_PREC_FP64)
+    return fail(NIDREG_ERR_INVALID, d->precision == NIDREG_PREC_FP32 ? "nidreg_create: NIDREG_PREC_FP32 was removed (it bought 8 %); the core computes in double" : "nidreg_create: bad precision");
 
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(NIDREG_ERR_NO_DEVICE, "nidreg_create: no HIP device (the NID core has no CPU path)");
@@ -1214,7 +1205,7 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
     // is pose independent -> records are bucketed by column group, so a workgroup owns GW histogram columns;
     // inside a group they follow a Morton curve of the LiDAR-frame bearing (any order gives the same bits -- the
     // sums are integers --, a spatially coherent one makes a wave's gathers share cache lines for ANY pose).
-    // Records are float32 when that is lossless or FP32 geometry was requested; otherwise double.
+    // Records are float32 when that is lossless (PLY data is float32 at source); otherwise double.
     CullArgs ca;
     if (T_cull) {
       ca.model = d->model_id;
@@ -1244,7 +1235,7 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
     }
     void* recs = nullptr;
     int rec64 = 0;
-    CREATE_TRY(build_records_device(d_cloud_pts, d_cloud_int, n_in, T_cull ? &ca : nullptr, Bsrc, d_lut_pts, GW, h->NG, d->precision == NIDREG_PREC_FP32, (d->flags & NIDREG_FLAG_INPUT_ORDER) != 0,
+    CREATE_TRY(build_records_device(d_cloud_pts, d_cloud_int, n_in, T_cull ? &ca : nullptr, Bsrc, d_lut_pts, GW, h->NG, false, (d->flags & NIDREG_FLAG_INPUT_ORDER) != 0,
                                     arena, &recs, &rec64, gcount, nullptr));
     h->d_pts = recs;
     h->rec64 = rec64;
@@ -1275,8 +1266,8 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
     if (d->mode == NIDREG_MODE_SPLINE) {
       PassArgs oa;
       fill_pass_args(h, oa);
-      const int og = h->precision == NIDREG_PREC_FP32 ? occupancy_spline_grad<float>(oa) : occupancy_spline_grad<double>(oa);
-      const int oh = h->precision == NIDREG_PREC_FP32 ? occupancy_spline_hist<float>(oa) : occupancy_spline_hist<double>(oa);
+      const int og = occupancy_spline_grad<double>(oa);
+      const int oh = occupancy_spline_hist<double>(oa);
       if (og > 0) per_cu_grad = std::min(og, 8);
       if (oh > 0) per_cu_hist = std::min(oh, 8);
     }
@@ -1308,6 +1299,14 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
     }
   }
 
+#ifdef NID_EXP_HANDOFF
+  {  // EXPERIMENT: the (u, v) hand-off buffer of the process' one handle (leaked at destruction: an experiment build)
+    void* uvb = nullptr;
+    CREATE_TRY(hipMalloc(&uvb, size_t(std::max<int64_t>(N, 1)) * 16 + 64));
+    CREATE_TRY(hipMemset(uvb, 0, size_t(std::max<int64_t>(N, 1)) * 16 + 64));
+    CREATE_TRY(set_handoff_buffer(uvb));
+  }
+#endif
   // ---- per-evaluation scratch
   h->hist_words = nidreg_hist_words(B);
   if (d->ext_stream || (d->flags & NIDREG_FLAG_EXT_STREAM)) {
@@ -1749,11 +1748,7 @@ int group_eval(MultiGroup* g, const double* se3, bool want_grad, double* costs, 
   a.chunks = h0->wide ? g->d_chunks_hist : g->d_chunks;
   a.nchunks = h0->wide ? g->nchunks_hist : g->nchunks;
   a.seg = h0->wide ? g->seg_hist : g->seg;
-  if (h0->precision == NIDREG_PREC_FP32) {
-    HIP_TRY(launch_spline_hist<float>(a));
-  } else {
-    HIP_TRY(launch_spline_hist<double>(a));
-  }
+  HIP_TRY(launch_spline_hist<double>(a));
   // entropy: NEB workgroups per pair -- none for small tables when every pair has gradient workgroups (they sum the table
   // themselves and clear the next evaluation's buffers, grad_sums_table)
   bool no_entropy_kernel = want_grad && grad_sums_table(h0);
@@ -1776,11 +1771,7 @@ int group_eval(MultiGroup* g, const double* se3, bool want_grad, double* costs, 
     a.seg = g->seg;
     a.lds_grad = g->lds_grad;
     a.gt_from_partials = no_entropy_kernel ? 2 : 1;
-    if (h0->precision == NIDREG_PREC_FP32) {
-      HIP_TRY(launch_spline_grad<float>(a));
-    } else {
-      HIP_TRY(launch_spline_grad<double>(a));
-    }
+    HIP_TRY(launch_spline_grad<double>(a));
     for (int i = 0; i < n; i++) {
       nidreg_handle* h = g->hs[size_t(i)];
       if (h->nchunks == 0 || h->num_points == 0) {  // an empty pair has no gradient workgroups: finalise (zeros) stand-alone
@@ -1987,11 +1978,7 @@ int group_eval_iso(MultiGroup* g, const double* T, double* costs) {
   a.chunks = g->d_chunks;
   a.nchunks = g->nchunks;
   a.seg = g->seg;
-  if (h0->precision == NIDREG_PREC_FP32) {
-    HIP_TRY(launch_nearest_hist<float>(a));
-  } else {
-    HIP_TRY(launch_nearest_hist<double>(a));
-  }
+  HIP_TRY(launch_nearest_hist<double>(a));
   hipLaunchKernelGGL(
     k_entropy<true>, dim3(h0->NEB * n), dim3(kEntropyThreads), 0, g->stream, static_cast<u64*>(nullptr), h0->bins, kEntropyCols, 0.0, static_cast<long long*>(nullptr),
     static_cast<u64*>(nullptr), static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<EntropyScalars*>(nullptr), static_cast<double*>(nullptr),
@@ -3035,7 +3022,7 @@ int nidreg_project(nidreg_handle* h, const double* p3, int64_t n, double* uv, do
     std::memcpy(sp.host, p3, size_t(n) * 3 * sizeof(double));
     double* d_uv = sp.dev + 3 * kSmallProject;
     double* d_j = jac ? sp.dev + 5 * kSmallProject : nullptr;
-    hipError_t e = h->precision == NIDREG_PREC_FP32 ? launch_project<float>(h->model, h->intr, h->dist, sp.dev, n, d_uv, d_j, h->stream) : launch_project<double>(h->model, h->intr, h->dist, sp.dev, n, d_uv, d_j, h->stream);
+    hipError_t e = launch_project<double>(h->model, h->intr, h->dist, sp.dev, n, d_uv, d_j, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) return fail(NIDREG_ERR_HIP, std::string("nidreg_project: ") + hipGetErrorString(e));
     std::memcpy(uv, sp.host + 3 * kSmallProject, size_t(n) * 2 * sizeof(double));
@@ -3048,7 +3035,7 @@ int nidreg_project(nidreg_handle* h, const double* p3, int64_t n, double* uv, do
   if (e == hipSuccess && jac) e = hipMalloc(&d_j, size_t(n) * 6 * sizeof(double));
   if (e == hipSuccess) e = hipMemcpy(d_p, p3, size_t(n) * 3 * sizeof(double), hipMemcpyHostToDevice);
   if (e == hipSuccess)
-    e = h->precision == NIDREG_PREC_FP32 ? launch_project<float>(h->model, h->intr, h->dist, d_p, n, d_uv, d_j, h->stream) : launch_project<double>(h->model, h->intr, h->dist, d_p, n, d_uv, d_j, h->stream);
+    e = launch_project<double>(h->model, h->intr, h->dist, d_p, n, d_uv, d_j, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   if (e == hipSuccess) e = hipMemcpy(uv, d_uv, size_t(n) * 2 * sizeof(double), hipMemcpyDeviceToHost);
   if (e == hipSuccess && jac) e = hipMemcpy(jac, d_j, size_t(n) * 6 * sizeof(double), hipMemcpyDeviceToHost);

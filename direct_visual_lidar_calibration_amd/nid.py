@@ -85,9 +85,9 @@ def create_camera(camera_model, intrinsics, distortion_coeffs):
 def _prec(precision):
     if precision in ("fp64", "f64", _lib.PREC_FP64):
         return _lib.PREC_FP64
-    if precision in ("fp32", "f32", _lib.PREC_FP32):
-        return _lib.PREC_FP32
-    raise ValueError(f"unknown precision {precision!r}")
+    if isinstance(precision, int):
+        return precision  # (passed through: nidreg_create refuses what it does not know, with its own message)
+    raise ValueError(f"unknown precision {precision!r} (the core computes in double; the float-geometry mode of rounds 1-4 bought 8 % and was removed)")
 
 
 class Cloud:

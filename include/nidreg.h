@@ -80,7 +80,7 @@ extern "C" {
 
 /* per-point arithmetic */
 #define NIDREG_PREC_FP64 0  /* transform / projection / weights in double (parity mode) */
-#define NIDREG_PREC_FP32 1  /* transform / projection / weights in float; histogram still 64-bit fixed point */
+#define NIDREG_PREC_FP32 1  /* REMOVED (round 5): float transform / projection bought 8 % for |dNID| <= 2e-5; refused with NIDREG_ERR_INVALID */
 
 #define NIDREG_IMAGE_F64 0  /* CV_64FC1 normalised to [0,1] (what NIDCost receives) */
 #define NIDREG_IMAGE_U8 1   /* CV_8UC1 (what CostCalculatorNID receives) */

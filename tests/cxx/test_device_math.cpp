@@ -238,28 +238,6 @@ int main() {
     std::printf("load_patch / load_pixel on the strip-tiled image: %d mismatches\n", wrong);
     if (wrong) bad++;
   }
-  // FP32 geometry instantiation of the projections (NIDREG_PREC_FP32): float-accurate against the oracle
-  {
-    const double intr[4] = {1100, 1100, 960, 540}, dist[5] = {-0.04, 0.08, 1e-4, -3e-4, -0.04};
-    CamParams<float> cf;
-    for (int i = 0; i < 5; i++) cf.intr[i] = i < 4 ? float(intr[i]) : 0.f;
-    for (int i = 0; i < 8; i++) cf.dist[i] = i < 5 ? float(dist[i]) : 0.f;
-    oracle::PinholeProjection P;
-    std::mt19937_64 rng(6);
-    std::uniform_real_distribution<double> U(-1.0, 1.0);
-    double e = 0, ej = 0;
-    for (int i = 0; i < 100000; i++) {
-      const float z = float(0.5 + 15 * (U(rng) + 1.0)), x = float(z * 0.8 * U(rng)), y = float(z * 0.45 * U(rng));
-      float u, v, du[3], dv[3];
-      project_jac<MODEL_PLUMB_BOB, float>(cf, x, y, z, u, v, du, dv);
-      oracle::V3<oracle::Jet7> pj{oracle::Jet7(double(x), 0), oracle::Jet7(double(y), 1), oracle::Jet7(double(z), 2)};
-      const oracle::V2<oracle::Jet7> r = P(intr, dist, pj);
-      e = std::fmax(e, std::fmax(std::fabs(u - r.x.a), std::fabs(v - r.y.a)));
-      for (int k = 0; k < 3; k++) ej = std::fmax(ej, std::fmax(std::fabs(du[k] - r.x.v[k]), std::fabs(dv[k] - r.y.v[k])) / (1.0 + std::fabs(r.x.v[k]) + std::fabs(r.y.v[k])));
-    }
-    std::printf("fp32 plumb_bob: max |uv - ref| %.3g px, jacobian rel %.3g\n", e, ej);
-    if (e > 2e-3 || ej > 2e-5) bad++;
-  }
   // fast_atan2 / fast_rcp / fast_rsq accuracy
   {
     std::mt19937_64 rng(99);

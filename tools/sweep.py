@@ -21,7 +21,7 @@ rng = np.random.default_rng(1)
 poses = [synth.random_pose_near(scene.T_camera_lidar_true, rng) for _ in range(12)]
 rows = []
 configs = []
-for prec in ("fp64", "fp32"):
+for prec in ("fp64",):
     for bins in (256, 16):
         for gw in (1, 4, 16, 32, 64):
             if gw > bins:
