@@ -20,6 +20,7 @@ PREC_FP64 = 0  # (1 = NIDREG_PREC_FP32: removed in round 5, refused by nidreg_cr
 IMAGE_F64, IMAGE_U8 = 0, 1
 FLAG_INPUT_ORDER = 1
 FLAG_EXT_STREAM = 2
+FLAG_NEAREST_EXACT = 4
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int64_p = ctypes.POINTER(ctypes.c_int64)

@@ -601,17 +601,32 @@ __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_spline_hist(
 // Every factor carries a margin of >= 2 over the first-order term; second-order terms are below 2^-20 of them whenever the
 // band is small enough to matter (a band >= 0.5 px sends the lane to the exact tier by itself).  NaN / inf anywhere compare
 // false, i.e. "inside the band": those points take the exact tier and behave like the reference.
+// Round 5: the three wide-angle models of the BASELINE configs have a fast tier as well -- the same structure (values by the SPLINE
+// kernels' cores, a per-point band, exact tier by ballot inside it), each with the band of its own chain rule:
+//   omnidir   m = c_xy / den, den = cz + xi |c|:  |d m| <= e1 (1 + |m| (1 + 1.74 xi)) / |den|, then the distortion as for plumb_bob
+//             with |m| <= mmax = sin(fov) / (cos(fov) + xi) inside the cone:      bu = A e1 / |den| + Bc,  A = 2 fmax K (1 + mmax (1 + 1.74 xi));
+//             Bc also carries the relative error of 1 / den (one rsqrt and one reciprocal with one Newton step each);
+//   fisheye   u - cx = fx s x, s = theta_d(theta) / r, theta = atan2(r, |z|):  |d (s x)| <= e1 (1.5 D / |c| + 2 s), D = sup |theta_d'|
+//             on [0, pi/2] (host):                                                  bu = e1 (A / |c| + C s) + Brel (|u - cx| + |v - cy| + 1);
+//   equirect  u = W (1/2 + atan2(x, z) / 2 pi), v = H (1/2 + atan2(y, rho) / pi):  |d lon| <= 2 e1 / rho, |d lat| <= 2 e1 / |c|;
+//             the REFERENCE's own latitude, -asin(y / |c|), carries its rounding amplified by |c| / rho towards the poles,
+//             which the band must cover too:                                        bu = A e1 / rho + Bc,  bv = C e1 / |c| + Bc2 + D |c| / rho;
+//             a point within 2e-3 m^2 of the |c|^2 < 1e-3 rule (equirectangular.hpp:16) or on the vertical axis goes to the exact tier.
 struct NearestFast {
   double er, et;  // 8 eps rmax, 8 eps tmax
   double A, Bc;
-  int on;         // 0: exact tier only (other camera models, max_fov close to 90 degrees, fp32 geometry)
+  double C, D, Bc2;  // (wide-angle models, see above)
+  int on;         // 0: exact tier only (atan / rational_polynomial, or a cone too wide for the model's bound)
 };
 
 // LDS of the NEAREST kernel: the tile counts POINTS, and a workgroup's chunk holds fewer than 2^32 of them -- 32-bit cells
 // (ds_add_u32, half the LDS of the SPLINE tiles: 16 KB at 256 cells x 16 copies), summed to 64 bits in the flush
 __host__ __device__ __forceinline__ size_t nearest_hist_lds_bytes(int B, int GW, int cshift) { return (((size_t(GW) * size_t(B) * 4 << cshift) + 7) & ~size_t(7)) + size_t(GW) * 8 + 16; }
-// five waves per SIMD for the fast-tier instantiation (96 VGPRs, nothing spilled; 104-106 without the bound)
-constexpr int nearest_min_waves(int model, bool is_double, bool rec32, bool seg) { return (model == MODEL_PLUMB_BOB && is_double && rec32 && !seg) ? 5 : 1; }
+// five waves per SIMD for the plumb_bob fast-tier instantiation (96 VGPRs, nothing spilled; 104-106 without the bound)
+// (round 5: fisheye lands at 132 and equirectangular at 173 by themselves -- asked for four and three waves)
+constexpr int nearest_min_waves(int model, bool is_double, bool rec32, bool seg) {
+  return (is_double && rec32 && !seg) ? (model == MODEL_PLUMB_BOB ? 5 : (model == MODEL_FISHEYE ? 4 : (model == MODEL_EQUIRECT ? 3 : 1))) : 1;
+}
 template <int MODEL, typename Rec, typename real, bool MULTI, bool SEG>
 __global__ __launch_bounds__(kThreads, nearest_min_waves(MODEL, std::is_same<real, double>::value, sizeof(Rec) == sizeof(Rec32), SEG)) void k_nearest_hist(
   const Rec* __restrict__ pts, const Chunk* __restrict__ chunks, const uint32_t* __restrict__ gend, const uint8_t* __restrict__ img, int pitch, int W, int H, IsoParams<real> iso,
@@ -639,7 +654,7 @@ __global__ __launch_bounds__(kThreads, nearest_min_waves(MODEL, std::is_same<rea
 
   const real fW = real(W), fH = real(H);
   unsigned int inl = 0;
-  constexpr bool kFastTier = MODEL == MODEL_PLUMB_BOB && std::is_same<real, double>::value;
+  constexpr bool kFastTier = (MODEL == MODEL_PLUMB_BOB || MODEL == MODEL_FISHEYE || MODEL == MODEL_OMNIDIR || MODEL == MODEL_EQUIRECT) && std::is_same<real, double>::value;
 
   // the reference's expression order (cost_calculator_nid.cpp:30-47): +, -, *, /, sqrt bit-identical to the CPU's
   auto exact = [&](real x, real y, real z, bool& in, int& px, int& py) {
@@ -705,9 +720,29 @@ __global__ __launch_bounds__(kThreads, nearest_min_waves(MODEL, std::is_same<rea
           const bool fov_safe = fabs(dz) > fma(8.0 * e1, rs, 4e-14);
           const bool in_fov = !(dz < 0.0);
           real u, v;
-          project<MODEL, real, real, true>(cam, real(cx), real(cy), real(cz), u, v);
-          const double bu = fma(fast.A * e1, fabs(fast_rcp(cz)), fast.Bc);
-          const bool uv_safe = bool(int(fabs(double(u) - rint(double(u))) > bu) & int(fabs(double(v) - rint(double(v))) > bu));
+          double bu, bv;
+          bool model_ok = true;  // (false: a rule of the model the bands do not cover -> exact tier)
+          if constexpr (MODEL == MODEL_OMNIDIR) {
+            const OmnidirCore<real> kc = omnidir_core<real>(cam, real(cx), real(cy), real(cz));
+            project<MODEL, real, real, true>(cam, real(cx), real(cy), real(cz), u, v);  // (the same core: computed once after inlining)
+            bu = bv = fma(fast.A * e1, fabs(double(kc.iden)), fast.Bc);
+            model_ok = n2 > 0.0;
+          } else if constexpr (MODEL == MODEL_FISHEYE) {
+            const FisheyeCore<real> kc = fisheye_core<real>(cam, real(cx), real(cy), real(cz));
+            u = fma(cam.intr[0], kc.s * real(cx), cam.intr[2]);
+            v = fma(cam.intr[1], kc.s * real(cy), cam.intr[3]);
+            bu = bv = fma(e1, fma(fast.A, rs, fast.C * fabs(double(kc.s))), fast.Bc * ((fabs(double(u) - double(cam.intr[2])) + fabs(double(v) - double(cam.intr[3]))) + 1.0));
+          } else if constexpr (MODEL == MODEL_EQUIRECT) {
+            const EquirectCore<real> kc = equirect_core<real>(cam, real(cx), real(cy), real(cz), u, v);
+            const double irho = double(kc.irho);  // 0 on the vertical axis (rho = 0): sent to the exact tier below
+            bu = fma(fast.A * e1, irho, fast.Bc);
+            bv = fma(fast.C * e1, rs, fast.Bc2) + fast.D * ((n2 * rs) * irho);
+            model_ok = bool(int(n2 > 2e-3) & int(double(kc.rho2) > 0.0));
+          } else {
+            project<MODEL, real, real, true>(cam, real(cx), real(cy), real(cz), u, v);
+            bu = bv = fma(fast.A * e1, fabs(fast_rcp(cz)), fast.Bc);
+          }
+          const bool uv_safe = bool(int(model_ok) & int(fabs(double(u) - rint(double(u))) > bu) & int(fabs(double(v) - rint(double(v))) > bv));
           const bool in_rng = bool(int(u > real(-1)) & int(u < fW) & int(v > real(-1)) & int(v < fH));
           // decided: safely outside the cone (u, v do not matter), or safely inside it with every pixel decision safe
           const bool decided = bool(int(fov_safe) & (int(!in_fov) | int(uv_safe)));

@@ -11,6 +11,7 @@ template <> hipError_t launch_nearest_hist<double>(const PassArgs& a) {
   if (a.nchunks == 0) return hipSuccess;
   return a.rec64 ? launch_nearest_hist_rec<double, Rec64>(a) : launch_nearest_hist_rec<double, Rec32>(a);
 }
+template <> int occupancy_nearest_hist<double>(const PassArgs& a) { return a.rec64 ? occupancy_nearest_hist_rec<double, Rec64>(a) : occupancy_nearest_hist_rec<double, Rec32>(a); }
 hipError_t launch_cull(int model, const double* intr, const double* dist, const double* d_pts, long long stride_d, long long n, const double* T, int W, int H, double min_z,
                        int depth, int* d_pix, unsigned int* d_zbuf, unsigned char* d_keep, hipStream_t stream) {
   if (n == 0) return hipSuccess;

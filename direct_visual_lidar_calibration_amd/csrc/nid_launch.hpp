@@ -20,6 +20,7 @@ struct ShardTable;
 // k_nearest_hist's fast decision tier (nid_kernels.hpp): error-bound coefficients of this pose and camera, from the host
 struct NearestFastArgs {
   double er, et, A, Bc;
+  double C, D, Bc2;
   int on;
 };
 
@@ -73,6 +74,7 @@ template <typename real> hipError_t launch_nearest_hist(const PassArgs& a);
 // (hipOccupancyMaxActiveBlocksPerMultiprocessor; 0 on error): a pass gets exactly one round of co-resident workgroups
 template <typename real> int occupancy_spline_hist(const PassArgs& a);
 template <typename real> int occupancy_spline_grad(const PassArgs& a);
+template <typename real> int occupancy_nearest_hist(const PassArgs& a);
 template <typename real> hipError_t launch_project(int model, const double* intr, const double* dist, const double* p3, long long n, double* uv, double* jac, hipStream_t stream);
 
 #ifdef NID_EXP_HANDOFF

@@ -228,12 +228,35 @@ static int occupancy_spline_grad_rec(const PassArgs& a) {
   return n;
 }
 
+// workgroups of the (straight-line, single-pair) NEAREST kernel of this model that fit on one CU at once
+template <typename real, typename Rec>
+static int occupancy_nearest_hist_rec(const PassArgs& a) {
+  int n = 0;
+#define NID_LAUNCH(M)                                                                                                                 \
+  {                                                                                                                                   \
+    auto k = k_nearest_hist<M, Rec, real, false, false>;                                                                              \
+    if (ensure_lds(k, a.lds_hist) != hipSuccess) return 0;                                                                            \
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(k), kThreads, a.lds_hist) != hipSuccess) n = 0; \
+  }
+  switch (a.model) {
+    case MODEL_PLUMB_BOB: NID_LAUNCH(MODEL_PLUMB_BOB); break;
+    case MODEL_FISHEYE: NID_LAUNCH(MODEL_FISHEYE); break;
+    case MODEL_OMNIDIR: NID_LAUNCH(MODEL_OMNIDIR); break;
+    case MODEL_EQUIRECT: NID_LAUNCH(MODEL_EQUIRECT); break;
+    case MODEL_ATAN: NID_LAUNCH(MODEL_ATAN); break;
+    case MODEL_RATIONAL: NID_LAUNCH(MODEL_RATIONAL); break;
+    default: return 0;
+  }
+#undef NID_LAUNCH
+  return n;
+}
+
 template <typename real, typename Rec>
 static hipError_t launch_nearest_hist_rec(const PassArgs& a) {
   const IsoParams<real> iso = make_iso<real>(a);
   const CamParams<real> cam = make_cam<real>(a.intr, a.dist);
   NearestFast fast;
-  fast.er = a.nfast.er, fast.et = a.nfast.et, fast.A = a.nfast.A, fast.Bc = a.nfast.Bc, fast.on = a.nfast.on;
+  fast.er = a.nfast.er, fast.et = a.nfast.et, fast.A = a.nfast.A, fast.Bc = a.nfast.Bc, fast.C = a.nfast.C, fast.D = a.nfast.D, fast.Bc2 = a.nfast.Bc2, fast.on = a.nfast.on;
 #define NID_LAUNCH_N(M, SEG)                                                                                                                           \
   if (a.multi) {                                                                                                                                       \
     auto k = k_nearest_hist<M, Rec, real, true, SEG>;                                                                                                       \

@@ -71,6 +71,7 @@ struct nidreg_handle {
   // caller's bin (the getters expand with them).  bins_user == 0: the two are the same.
   int bins_user = 0;
   std::vector<uint16_t> inv_img, inv_pts;
+  bool nearest_exact = false;  // NIDREG_FLAG_NEAREST_EXACT
   int W = 0, H = 0, pitch = 0;
   int GW = 0, NG = 0, cshift = 0;
   int wide = 0;  // k_spline_hist<.., WIDE>: B = 256, GW = 1, 32 copies, 512 threads
@@ -497,8 +498,9 @@ int launch_hist_spline(nidreg_handle* h, const double* se3, bool alone = false) 
 }
 
 // k_nearest_hist's fast decision tier (nid_kernels.hpp NearestFast): the coefficients of its error bound for this pose and
-// this camera.  plumb_bob in double precision only, and only for a FoV cone comfortably below 90 degrees (the bound on the
-// normalised image coordinates is tan(max_fov)); NIDREG_NEAREST_EXACT=1 switches the tier off (A/B runs, bisecting).
+// this camera (derivations at the kernel).  plumb_bob and omnidir: only for a FoV cone over which the normalised image
+// coordinates stay bounded (tan(max_fov), resp. sin / (cos + xi)); fisheye and equirectangular: any cone (their bands are
+// per point); atan and rational_polynomial keep the exact tier.  NIDREG_NEAREST_EXACT=1 switches the tier off (A/B runs).
 NearestFastArgs nearest_fast_args(const nidreg_handle* h, const double* T) {
   NearestFastArgs f;
   std::memset(&f, 0, sizeof(f));
@@ -506,27 +508,64 @@ NearestFastArgs nearest_fast_args(const nidreg_handle* h, const double* T) {
     const char* e = std::getenv("NIDREG_NEAREST_EXACT");
     return e && *e && *e != '0';
   }();
-  const double cos_fov = std::cos(h->max_fov);
-  if (off || h->model != NIDREG_MODEL_PLUMB_BOB || h->precision != NIDREG_PREC_FP64 || !(cos_fov > 0.1)) return f;
+  if (off || h->nearest_exact || h->precision != NIDREG_PREC_FP64) return f;
   const double eps = std::ldexp(1.0, -52);
+  const double pi = 3.14159265358979323846;
   double rmax = 0.0, tmax = 0.0;
   for (int r = 0; r < 3; r++) {
     for (int c = 0; c < 3; c++) rmax = std::max(rmax, std::fabs(T[4 * r + c]));
     tmax = std::max(tmax, std::fabs(T[4 * r + 3]));
   }
-  const double pmax = std::tan(h->max_fov) * 1.001 + 1e-6, r2 = pmax * pmax;
-  const double k1 = std::fabs(h->dist[0]), k2 = std::fabs(h->dist[1]), p1 = std::fabs(h->dist[2]), p2 = std::fabs(h->dist[3]), k3 = std::fabs(h->dist[4]);
-  const double R = 1.0 + r2 * (k1 + r2 * (k2 + r2 * k3));        // sup |1 + k1 r2 + k2 r4 + k3 r6|
-  const double Rp = k1 + r2 * (2.0 * k2 + r2 * 3.0 * k3);         // sup |d(radial factor) / d r2|
-  const double Kx = R + 4.0 * r2 * Rp + 4.0 * p1 * pmax + 8.0 * p2 * pmax;  // row sums of d(dx, dy)/d(px, py) on |px|, |py| <= pmax
-  const double Ky = R + 4.0 * r2 * Rp + 8.0 * p1 * pmax + 4.0 * p2 * pmax;
-  const double K = 1.5 * std::max(Kx, Ky);
-  const double fmax = std::max(std::fabs(h->intr[0]), std::fabs(h->intr[1]));
   f.er = 8.0 * eps * rmax;
   f.et = 8.0 * eps * tmax;
-  f.A = 2.0 * fmax * K * (1.0 + pmax);
-  f.Bc = fmax * (4e-14 * K * pmax + 2e-14 * R * pmax) + 1e-15 * (double(h->W) + double(h->H) + std::fabs(h->intr[2]) + std::fabs(h->intr[3]));
-  f.on = std::isfinite(f.A) && std::isfinite(f.Bc) && std::isfinite(f.er) && std::isfinite(f.et) ? 1 : 0;
+  const double cos_fov = std::cos(h->max_fov);
+  const double fmax = std::max(std::fabs(h->intr[0]), std::fabs(h->intr[1]));
+  const double frame = double(h->W) + double(h->H) + std::fabs(h->intr[2]) + std::fabs(h->intr[3]);
+  // sup of the radial factor, of its derivative and of the row sums of d(dx, dy)/d(px, py) of the radial-tangential distortion
+  // on |p| <= pmax (plumb_bob: k1 k2 p1 p2 k3; omnidir: k1 k2 p1 p2)
+  auto radtan_sup = [&](double pmax, double k3, double& R, double& K) {
+    const double r2 = pmax * pmax;
+    const double k1 = std::fabs(h->dist[0]), k2 = std::fabs(h->dist[1]), p1 = std::fabs(h->dist[2]), p2 = std::fabs(h->dist[3]);
+    R = 1.0 + r2 * (k1 + r2 * (k2 + r2 * k3));
+    const double Rp = k1 + r2 * (2.0 * k2 + r2 * 3.0 * k3);
+    const double Kx = R + 4.0 * r2 * Rp + 4.0 * p1 * pmax + 8.0 * p2 * pmax;
+    const double Ky = R + 4.0 * r2 * Rp + 8.0 * p1 * pmax + 4.0 * p2 * pmax;
+    K = 1.5 * std::max(Kx, Ky);
+  };
+  if (h->model == NIDREG_MODEL_PLUMB_BOB) {
+    if (!(cos_fov > 0.1)) return f;
+    const double pmax = std::tan(h->max_fov) * 1.001 + 1e-6;
+    double R, K;
+    radtan_sup(pmax, std::fabs(h->dist[4]), R, K);
+    f.A = 2.0 * fmax * K * (1.0 + pmax);
+    f.Bc = fmax * (4e-14 * K * pmax + 2e-14 * R * pmax) + 1e-15 * frame;
+  } else if (h->model == NIDREG_MODEL_OMNIDIR) {
+    const double xi = std::fabs(h->intr[4]);
+    if (!(cos_fov + xi > 0.1) || !(h->intr[4] >= 0.0)) return f;
+    // |m| = sin(theta) / (cos(theta) + xi) grows with theta on [0, max_fov] while the denominator stays positive
+    const double mmax = std::sin(std::min(h->max_fov, pi)) / (cos_fov + xi) * 1.001 + 1e-6;
+    double R, K;
+    radtan_sup(mmax, 0.0, R, K);
+    f.A = 2.0 * fmax * K * (1.0 + mmax * (1.0 + 1.74 * xi));
+    const double rel_m = 2.1e-14 * xi / (cos_fov + xi) + 1.4e-14 + 8.0 * eps;  // 1 / (cz + xi |c|): one-step rsqrt inside, one-step reciprocal
+    f.Bc = fmax * (4.0 * rel_m * K * mmax + 2e-14 * R * mmax) + 1e-15 * frame;
+  } else if (h->model == NIDREG_MODEL_FISHEYE) {
+    const double th = 0.5 * pi, t2 = th * th;
+    const double D = 1.0 + t2 * (3.0 * std::fabs(h->dist[0]) + t2 * (5.0 * std::fabs(h->dist[1]) + t2 * (7.0 * std::fabs(h->dist[2]) + t2 * 9.0 * std::fabs(h->dist[3]))));
+    f.A = 2.0 * 1.5 * fmax * D;  // e1 (1.5 D / |c| + 2 s) fmax, doubled
+    f.C = 2.0 * 2.0 * fmax;
+    f.Bc = 2e-13 * std::max(1.0, D);  // relative: the one-step rsqrt (2.1e-14), its share of theta through atan2, theta_d's four fmas, s x
+  } else if (h->model == NIDREG_MODEL_EQUIRECTANGULAR) {
+    const double Wd = std::fabs(h->intr[0]), Hd = std::fabs(h->intr[1]);
+    f.A = 2.0 * 2.0 * Wd / (2.0 * pi);  // |d lon| <= 2 e1 / rho, doubled
+    f.C = 2.0 * 2.0 * Hd / pi;         // |d lat| <= 2 e1 / |c|, doubled
+    f.Bc = Wd / (2.0 * pi) * 2e-14;    // fast_atan2 (3e-16) + libm's atan2 on the reference's side, the normalisations: < 1e-14 rad
+    f.Bc2 = Hd / pi * 3e-14;           // rho through a one-step rsqrt: <= 1.1e-14 rad at 45 degrees
+    f.D = Hd / pi * 16.0 * eps;        // the reference's asin(y / |c|): its argument's rounding amplified by |c| / rho
+  } else {
+    return f;
+  }
+  f.on = std::isfinite(f.A) && std::isfinite(f.Bc) && std::isfinite(f.C) && std::isfinite(f.D) && std::isfinite(f.Bc2) && std::isfinite(f.er) && std::isfinite(f.et) ? 1 : 0;
   return f;
 }
 
@@ -1072,6 +1111,7 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
   h->mode = d->mode;
   h->precision = d->precision;
   h->bins = d->bins;
+  h->nearest_exact = (d->flags & NIDREG_FLAG_NEAREST_EXACT) != 0;
   if (wide) {
     h->bins_user = wide->user_bins;
     h->inv_img = wide->inv_img;
@@ -1270,6 +1310,11 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
       const int oh = occupancy_spline_hist<double>(oa);
       if (og > 0) per_cu_grad = std::min(og, 8);
       if (oh > 0) per_cu_hist = std::min(oh, 8);
+    } else {  // NEAREST: the fast-tier kernels of the wide-angle models hold three (equirectangular) or four waves per SIMD
+      PassArgs oa;
+      fill_pass_args(h, oa);
+      const int on = occupancy_nearest_hist<double>(oa);
+      if (on > 0) per_cu_grad = per_cu_hist = std::min(on, 4);
     }
     h->gcount = gcount;
     h->num_cus = num_cus;

@@ -26,8 +26,8 @@
  *                            all-reduces the fixed-point histogram (RCCL) between the phases.
  *   desc.num_devices /       (no reference counterpart) one pair over several GPUs inside ONE process: nidreg_create /
  *   NIDREG_DEVICES           nidreg_create_from_cloud cut the cloud along the histogram column (every GPU owns a range of
- *                            column groups and the points that fall into them) and nidreg_eval* exchange inlier counts,
- *                            entropy partials and marginal sums GPU to GPU themselves (the reference's calibrate is a
+ *                            column groups and the points that fall into them) and every GPU stores its columns of the
+ *                            integer histogram into every other GPU's replica, once per evaluation (the reference's calibrate is a
  *                            single process, src/calibrate.cpp:117-120)
  *   nidreg_destroy           ~NIDCost / ~CostCalculatorNID
  *
@@ -49,6 +49,12 @@
  *     evaluations that share a device (concurrent callers) run without it.  The cost and the histograms do not depend
  *     on it, nor on the chunk tables or the GPU count (fixed-point histogram, fixed-point entropy sums: bit-identical);
  *     the gradient is equal up to the order of the workgroup partials, which is a fixed function of the handle.
+ *   - NEAREST handles (nidreg_eval_iso*): the integer histogram is the reference's, count for count, for every point whose
+ *     decisions (inside the FoV cone, inside the image, which pixel) the arithmetic fixes -- +, -, *, /, sqrt follow the
+ *     reference's expression order without contraction.  Three camera models put a libm function between the point and its
+ *     pixel (fisheye, atan: atan2 / atan; equirectangular: asin, atan2): there the pixel is exact up to the last place in which
+ *     the device's libm and the host's agree, i.e. a point within ~3e-14 px of a pixel boundary may fall on either side
+ *     (two CPU builds with different libms disagree in the same way); none of the 10^7 points of the full-size test clouds does.
  *   - the caller keeps ownership of every host buffer; nidreg_create copies what it needs.
  */
 #ifndef NIDREG_H
@@ -99,6 +105,9 @@ extern "C" {
 /* nidreg_desc.flags */
 #define NIDREG_FLAG_EXT_STREAM 2  /* launch on desc.ext_stream even when it is NULL (= the legacy default
                                      stream, e.g. torch's current stream); otherwise NULL means "own stream" */
+#define NIDREG_FLAG_NEAREST_EXACT 4 /* NEAREST handles: every point through the exact decision tier (the reference's expression
+                                     order), none through the fast one -- for A/B runs and bisecting; the environment variable
+                                     NIDREG_NEAREST_EXACT=1 does the same for every handle of the process */
 #define NIDREG_FLAG_INPUT_ORDER 1 /* keep the caller's point order inside each column group instead of the
                                      default Morton order of the LiDAR-frame bearing (results are
                                      bit-identical either way; the default gathers ~2x faster) */

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Diagnostic: where the NEAREST twin's integer histogram differs from the oracle's on the adversarial point set of
+tests/test_gpu_parity._wide_angle_boundary_points -- point by point, fast tier against exact tier against oracle."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib  # noqa: E402
+import test_gpu_parity as t  # noqa: E402
+from direct_visual_lidar_calibration_amd import nid  # noqa: E402
+
+
+def hist_of(proj, s, p, i, fov, T, flags):
+    c = nid.CostCalculatorNID(proj, s.image_u8, p, i, nid.NIDCostParams(256), max_fov=fov, flags=flags)
+    c.calculate(T)
+    fx = c.histogram_fixed()[0]
+    c.close()
+    return fx
+
+
+for model in sys.argv[1:] or ("fisheye", "equirectangular", "omnidir"):
+    s, W, H, intr, dist, T, pts, ints, max_fov = t._wide_angle_boundary_points(model, "general")
+    proj = nid.create_camera(model, intr, dist)
+    full = oracle_lib.estimate_camera_fov(model, intr, dist, W, H)
+    for fov in (max_fov, full):
+        n_fast_vs_exact = n_exact_vs_oracle = 0
+        shown = 0
+        for lo in range(0, pts.shape[0], 400):
+            p, i = pts[lo:lo + 400], ints[lo:lo + 400]
+            _, rh = oracle_lib.cost_calculator_nid(model, intr, dist, s.image_u8, p, i, 256, fov, T, want_hist=True)
+            hf, he = hist_of(proj, s, p, i, fov, T, 1), hist_of(proj, s, p, i, fov, T, 1 | 4)
+            if np.array_equal(hf, he) and np.array_equal(he, rh):
+                continue
+            for k in range(p.shape[0]):
+                _, r1 = oracle_lib.cost_calculator_nid(model, intr, dist, s.image_u8, p[k:k + 1], i[k:k + 1], 256, fov, T, want_hist=True)
+                f1, e1 = hist_of(proj, s, p[k:k + 1], i[k:k + 1], fov, T, 0), hist_of(proj, s, p[k:k + 1], i[k:k + 1], fov, T, 4)
+                fe, eo = not np.array_equal(f1, e1), not np.array_equal(e1, r1)
+                n_fast_vs_exact += fe
+                n_exact_vs_oracle += eo
+                if (fe or eo) and shown < 10:
+                    shown += 1
+                    pc = T[:3, :3] @ p[k, :3] + T[:3, 3]
+                    uv = oracle_lib.project(model, intr, dist, pc[None])[0]
+                    zn = pc[2] / np.linalg.norm(pc) if np.linalg.norm(pc) > 0 else pc[2]
+                    print(f"   #{lo + k} fast!=exact {fe} exact!=oracle {eo} p_cam {pc.tolist()} uv {uv.tolist()} zn-cos {zn - np.cos(fov):.3e} counts o/e/f {int(r1.sum())}/{int(e1.sum())}/{int(f1.sum())}")
+        print(f"{model} fov {fov:.4f}: {pts.shape[0]} points, fast != exact tier at {n_fast_vs_exact}, exact tier != oracle at {n_exact_vs_oracle}")
