@@ -47,7 +47,15 @@ def algorithmic_bytes(n_points, width, height, bins):
     return 16 * n_points + width * height + 8 * (bins * bins + 2 * bins) + 64
 
 
-def _matching_pmc(n_points, width, height, bins, precision, build=None):
+def _same_workload(t, n_points, width, height, bins, precision, camera):
+    w = t.get("workload", {})
+    if (w.get("points"), w.get("width"), w.get("height"), w.get("bins"), w.get("precision")) != (n_points, width, height, bins, precision):
+        return False
+    # (summaries of rounds 1-4 carry no camera: they are the headline's; two config cameras share 10M points / 2048 x 2048)
+    return camera is None or w.get("camera", "pinhole_1080p") == camera
+
+
+def _matching_pmc(n_points, width, height, bins, precision, build=None, camera=None):
     """The newest committed rocprofv3 PMC summary (profiles/*_traffic.json) of this workload; with `build`, only
     one stamped with the same kernel-source hash (a summary of another kernel build is not evidence)."""
     import glob
@@ -59,8 +67,7 @@ def _matching_pmc(n_points, width, height, bins, precision, build=None):
                 t = json.load(f)
         except (OSError, ValueError):
             continue
-        w = t.get("workload", {})
-        if (w.get("points"), w.get("width"), w.get("height"), w.get("bins"), w.get("precision")) != (n_points, width, height, bins, precision):
+        if not _same_workload(t, n_points, width, height, bins, precision, camera):
             continue
         if build is not None and t.get("kernel_build") != build:
             continue
@@ -69,7 +76,7 @@ def _matching_pmc(n_points, width, height, bins, precision, build=None):
     return best
 
 
-def _matching_kernel_stats(n_points, width, height, bins, precision, build):
+def _matching_kernel_stats(n_points, width, height, bins, precision, build, camera=None):
     """The newest committed rocprofv3 kernel-stats summary (profiles/*_kernel_stats.json, tools/kernel_stats_json.py) of this
     workload measured on THIS kernel build: average kernel durations without HIP-event markers inside them."""
     import glob
@@ -81,8 +88,7 @@ def _matching_kernel_stats(n_points, width, height, bins, precision, build):
                 t = json.load(f)
         except (OSError, ValueError):
             continue
-        w = t.get("workload", {})
-        if (w.get("points"), w.get("width"), w.get("height"), w.get("bins"), w.get("precision")) != (n_points, width, height, bins, precision) or t.get("kernel_build") != build:
+        if not _same_workload(t, n_points, width, height, bins, precision, camera) or t.get("kernel_build") != build:
             continue
         best = t
         best["_file"] = os.path.basename(path)
@@ -305,7 +311,7 @@ def main():
         whole_ms = float(np.mean(whole))
         n_local = pts.shape[0]
         build = _lib.kernel_source_hash()
-        kstats = _matching_kernel_stats(n_local, scene.width, scene.height, args.bins, args.precision, build)
+        kstats = _matching_kernel_stats(n_local, scene.width, scene.height, args.bins, args.precision, build, camera=args.camera)
         ks = {k_: v["avg_ns"] * 1e-6 for k_, v in kstats["kernels"].items()} if kstats else {}
         eval_bytes = algorithmic_bytes(n_local, scene.width, scene.height, args.bins)
         eval_achieved = eval_bytes / (ms_per_step * 1e-3) / 1e9
@@ -315,7 +321,7 @@ def main():
         launch_bytes = 16 * n_local + scene.width * scene.height + 8 * args.bins * args.bins
         dom_ms = ks.get(dom, dom_ms_events)  # rocprof average of this kernel build when committed, else the event-timed one
         kernel_achieved = launch_bytes / (dom_ms * 1e-3) / 1e9
-        pmc = _matching_pmc(n_local, scene.width, scene.height, args.bins, args.precision, build)
+        pmc = _matching_pmc(n_local, scene.width, scene.height, args.bins, args.precision, build, camera=args.camera)
         pk = pmc.get("kernels", {}) if pmc else {}
         traffic = pk[dom]["hbm_bytes_corrected"] if dom in pk else None
         route = ["k_spline_hist", "k_entropy", "k_spline_grad"]
@@ -355,6 +361,9 @@ def main():
             "kernel": dom,
             "kernel_achieved": round(kernel_achieved, 1),
             "kernel_frac": round(kernel_achieved / HBM_PEAK_GBS, 4),
+            # the same fraction from THIS run's own HIP events around the launch (a few us of event markers included): what the
+            # driver's run measures by itself, beside the figure read from the committed rocprofv3 pass of the same kernel build
+            "kernel_frac_events": round(launch_bytes / (dom_ms_events * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "kernel_ms_used": round(dom_ms, 4),
             "kernel_ms_source": (kstats["_file"] + " (rocprofv3 --kernel-trace --stats average, same kernel build)") if dom in ks else "HIP events around the launch, this run (a few us of event markers included)",
             "launch_bytes": launch_bytes,
@@ -554,6 +563,21 @@ def main():
                 ab = algorithmic_bytes(s_.points.shape[0], s_.width, s_.height, bins_)
                 configs[key] = {"pts": int(s_.points.shape[0]), "cam": camera, "bins": bins_, "ms_per_step": round(msl, 5), "evals_per_s": round(1e3 / msl, 1), "gbs": round(ab / (msl * 1e-3) / 1e9, 1),
                                 "frac": round(ab / (msl * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                # this camera model's kernels from the committed rocprofv3 passes of THIS kernel build (profiles/*_<camera>_*_kernel_stats.json,
+                # *_traffic.json; tools/round_pass.sh stats= / pmc=): average kernel durations, VALU wave-instructions per point
+                bld = _lib.kernel_source_hash()
+                ks_ = _matching_kernel_stats(int(s_.points.shape[0]), s_.width, s_.height, bins_, args.precision, bld, camera=camera)
+                if ks_:
+                    configs[key]["kernel_ms"] = {k_: round(v["avg_ns"] * 1e-6, 5) for k_, v in ks_["kernels"].items() if k_ in ("k_spline_hist", "k_entropy", "k_spline_grad")}
+                    configs[key]["kernel_ms_source"] = "profiles/" + ks_["_file"]
+                pm_ = _matching_pmc(int(s_.points.shape[0]), s_.width, s_.height, bins_, args.precision, bld, camera=camera)
+                if pm_:
+                    vi = {k_: round(v["valu_insts"] * 64.0 / s_.points.shape[0], 1) for k_, v in pm_.get("kernels", {}).items() if k_ in ("k_spline_hist", "k_spline_grad") and v.get("valu_insts")}
+                    if vi:
+                        configs[key]["valu_insts_per_point"] = vi
+                    tr = {k_: v["hbm_bytes_corrected"] for k_, v in pm_.get("kernels", {}).items() if "hbm_bytes_corrected" in v}
+                    if tr:
+                        configs[key]["traffic_bytes"] = tr
                 c_.close()
                 del s_, c_
                 torch.cuda.empty_cache()

@@ -2,7 +2,7 @@
 """profiles/<tag>_kernel_stats.json from a rocprofv3 --kernel-trace --stats run: average duration per nidreg kernel,
 stamped with the kernel-source hash and the workload like *_traffic.json, so that bench.py can quote rocprof kernel
 durations (no HIP-event markers inside them) only when they were measured on the kernel build it runs.
-Usage: kernel_stats_json.py <kernel_stats.csv> <out.json> points width height bins precision [note]"""
+Usage: kernel_stats_json.py <kernel_stats.csv> <out.json> points width height bins precision [note] [camera]"""
 import csv
 import json
 import os
@@ -16,6 +16,7 @@ src, dst = sys.argv[1], sys.argv[2]
 points, width, height, bins = (int(v) for v in sys.argv[3:7])
 precision = sys.argv[7]
 note = sys.argv[8] if len(sys.argv) > 8 else ""
+camera = sys.argv[9] if len(sys.argv) > 9 else "pinhole_1080p"  # a key of synth.CONFIG_CAMERAS
 kernels = {}
 for r in csv.DictReader(open(src)):
     m = re.search(r"nidreg::(k_\w+)", r["Name"])
@@ -30,6 +31,6 @@ for r in csv.DictReader(open(src)):
     k["instantiations"].append({"name": r["Name"][:160], "calls": calls, "avg_ns": float(r["AverageNs"])})
 for k in kernels.values():
     k["avg_ns"] = k["total_ns"] / max(k["calls"], 1)
-json.dump({"source": src, "note": note, "kernel_build": _lib.kernel_source_hash(), "workload": dict(points=points, width=width, height=height, bins=bins, precision=precision), "kernels": kernels},
+json.dump({"source": src, "note": note, "kernel_build": _lib.kernel_source_hash(), "workload": dict(points=points, width=width, height=height, bins=bins, precision=precision, camera=camera), "kernels": kernels},
           open(dst, "w"), indent=1)
 print(json.dumps({k: round(v["avg_ns"] / 1e3, 2) for k, v in kernels.items()}))

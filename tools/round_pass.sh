@@ -54,7 +54,7 @@ for STEP in "$@"; do
       F=$(find $O/trace_$N -name "*kernel_stats.csv" | head -1)
       if [ -n "$F" ]; then
         grep -E "Name|nidreg" $F > $O/${A1}_${A2}_kernel_stats.csv
-        python tools/kernel_stats_json.py $F $O/${A1}_${A2}_kernel_stats.json $A2 $W $H $B fp64 "rocprofv3 --kernel-trace --stats -- python tools/run_scene.py (scene $A1, $A2 points, seed 20250530)"
+        python tools/kernel_stats_json.py $F $O/${A1}_${A2}_kernel_stats.json $A2 $W $H $B fp64 "rocprofv3 --kernel-trace --stats -- python tools/run_scene.py (scene $A1, $A2 points, seed 20250530)" $A1
       fi
       rm -rf $O/trace_$N; tail -c 600 $O/${A1}_${A2}_run.json ;;
     pmc)
@@ -62,7 +62,7 @@ for STEP in "$@"; do
       PASSES=${A3:-fetch+write+sq1+sq2}
       SCENE_NPZ=$S PMC_PASSES="${PASSES//+/ }" timeout 900 bash tools/profile_pmc.sh ${TAG}_${A1} > $O/${A1}_${A2}_pmc.log 2>&1; echo "rc=$?"
       cp gpurun_out/pmc_${TAG}_${A1}/summary.txt $O/${A1}_${A2}_pmc_summary.txt
-      python tools/traffic_from_pmc.py gpurun_out/pmc_${TAG}_${A1} $O/${A1}_${A2}_traffic.json $A2 $W $H 256 fp64 > /dev/null 2>&1; echo "traffic rc=$?"
+      python tools/traffic_from_pmc.py gpurun_out/pmc_${TAG}_${A1} $O/${A1}_${A2}_traffic.json $A2 $W $H 256 fp64 $A1 > /dev/null 2>&1; echo "traffic rc=$?"
       rm -rf gpurun_out/pmc_${TAG}_${A1} ;;
     run)
       S=$(scene $A1 $A2)

@@ -3,7 +3,7 @@
 launch.  FETCH_SIZE / WRITE_SIZE are KiB from separate --pmc passes; on gfx950 FETCH_SIZE counts a wide
 (16 B/lane) coalesced stream at half its bytes (MI355X_MICROARCH.md, HBM section), and the point
 stream is >97 % of what these kernels read, so the corrected figure is 2*FETCH + WRITE.
-Usage: traffic_from_pmc.py gpurun_out/pmc_<tag> profiles/<tag>_traffic.json points width height bins precision"""
+Usage: traffic_from_pmc.py gpurun_out/pmc_<tag> profiles/<tag>_traffic.json points width height bins precision [camera]"""
 import json
 import re
 import sys
@@ -24,9 +24,11 @@ for line in open(f"{src}/summary.txt"):
     kernels.setdefault(cur, {})[f[0]] = float(f[2])  # every counter of the passes (per-launch means)
 out = {}
 for k, v in kernels.items():
-    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-        out[k] = {"fetch_kib": v["FETCH_SIZE"], "write_kib": v["WRITE_SIZE"], "hbm_bytes_raw": int((v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024),
-                  "hbm_bytes_corrected": int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)}
+    if ("FETCH_SIZE" in v and "WRITE_SIZE" in v) or "SQ_INSTS_VALU" in v:  # (a pass set without the byte counters still yields the instruction counts)
+        out[k] = {}
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            out[k] = {"fetch_kib": v["FETCH_SIZE"], "write_kib": v["WRITE_SIZE"], "hbm_bytes_raw": int((v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024),
+                      "hbm_bytes_corrected": int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)}
         # wave-instruction counts per launch (the VALU-issue roof bench.py reports next to the HBM one)
         for name, key in (("SQ_INSTS_VALU", "valu_insts"), ("SQ_INSTS_LDS", "lds_insts"), ("SQ_INSTS_SALU", "salu_insts"), ("SQ_INSTS_VMEM_RD", "vmem_rd_insts"),
                           ("SQ_ACTIVE_INST_VALU", "valu_active_quad_cycles"), ("GRBM_GUI_ACTIVE", "gui_active_cycles_all_xcd"), ("SQ_LDS_BANK_CONFLICT", "lds_bank_conflict_cycles"),
@@ -38,6 +40,6 @@ for k, v in kernels.items():
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from direct_visual_lidar_calibration_amd import _lib  # noqa: E402
 
-json.dump({"source": src, "kernel_build": _lib.kernel_source_hash(), "workload": dict(points=points, width=width, height=height, bins=bins, precision=precision), "kernels": out},
+json.dump({"source": src, "kernel_build": _lib.kernel_source_hash(), "workload": dict(points=points, width=width, height=height, bins=bins, precision=precision, camera=sys.argv[8] if len(sys.argv) > 8 else "pinhole_1080p"), "kernels": out},
           open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1))
