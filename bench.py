@@ -61,7 +61,8 @@ def _matching_pmc(n_points, width, height, bins, precision, build=None, camera=N
     import glob
 
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
+    # (profiles/ holds the current round's passes, profiles/archive/ those of earlier rounds -- earlier kernel builds)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "archive", "*_traffic.json"))) + sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
         try:
             with open(path) as f:
                 t = json.load(f)
@@ -82,7 +83,7 @@ def _matching_kernel_stats(n_points, width, height, bins, precision, build, came
     import glob
 
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kernel_stats.json"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "archive", "*_kernel_stats.json"))) + sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kernel_stats.json"))):
         try:
             with open(path) as f:
                 t = json.load(f)
@@ -412,6 +413,21 @@ def main():
         again.close()
         if python_call_rate:
             extra["python_call_evals_per_s"] = round(python_call_rate, 1)
+        # the in-library RCCL route (nidreg_shard_comm_init; what a C++ caller of the drop-in gets for one pair over several GPUs)
+        # with a ONE-rank communicator on this GPU: the all-reduce of one rank moves nothing, so what this measures is the chain
+        # histogram -> ncclAllReduce(int64) -> entropy -> gradient -> ncclAllReduce(f64 x 7) itself -- the floor the collectives put
+        # under a sharded evaluation whatever the link speed.  Informational; NIDREG_BENCH_NO_INLIB_RCCL=1 skips it.
+        if not os.environ.get("NIDREG_BENCH_NO_INLIB_RCCL"):
+            try:
+                from direct_visual_lidar_calibration_amd import parallel as _par
+
+                one = _par.InLibShardedNIDCost(proj, scene.image_f64, pts, ints, args.bins, device=local_rank, precision=args.precision, total_points=pts.shape[0])
+                okr, cr, _gr = one(poses[0])
+                okp, cp_, _gp = cost(poses[0])
+                extra["inlib_rccl_world1"] = {"evals_per_s": round(rate(lambda k: one(poses[k % len(poses)]), n=20), 1), "cost_equals_plain_handle": bool(okr and okp and cr == cp_)}
+                one.close()
+            except Exception as exc:
+                extra["inlib_rccl_world1"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
 
     # ---- the same workload with the evaluations queued ahead (nidreg_submit / nidreg_wait): what a caller with independent
     # poses in hand gets -- Nelder-Mead's initial simplex, multi-start, batches; `value` stays the synchronous rate

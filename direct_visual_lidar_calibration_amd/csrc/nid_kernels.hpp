@@ -254,14 +254,14 @@ __device__ __forceinline__ void grad_final_body(const double* partials, int nblo
 // co-resident on a CU the first-dispatched one runs at its solo speed and the last one is left to finish alone, at
 // single-wave issue rate (PMC: on average only 2.4 of the 4 resident waves per SIMD are alive over the gradient kernel).
 // A wave that has done less of its chunk gets the higher priority: the waves of a SIMD stay within a quarter of a chunk
-// of each other.  Measured on cfg 2 (profiles/r02g_variants_prio.txt): histogram pass 57.5 -> 53.0 us, gradient pass
+// of each other.  Measured on cfg 2 (profiles/archive/r02g_variants_prio.txt): histogram pass 57.5 -> 53.0 us, gradient pass
 // 84.0 -> 78.6 us; the thresholds hardly matter (quarters, 1/2-3/4-7/8, per point instead of per batch: all within 1 us); a
 // purely phase-based toggle (either direction) or a rotating priority gain half as much -- what helps is that co-resident
 // waves stop being served strictly by age.
 // `done` / `total` are uniform: scalar compares only.  -DNID_NO_PRIO builds the kernels without it (A/B runs).
 // `on` (uniform, a kernel argument): the host sets it when the evaluation is the only one in flight on its device -- with
 // several callers' kernels sharing the GPU (the reference's OpenMP loop over pairs, visual_camera_calibration.cpp:161) the
-// rule made the last kernels 5-16 % slower (profiles/r02h_multi_pair_threads.txt), so they run without it.
+// rule made the last kernels 5-16 % slower (profiles/archive/r02h_multi_pair_threads.txt), so they run without it.
 __device__ __forceinline__ void set_progress_priority(bool on, uint32_t done, uint32_t total) {
 #ifndef NID_NO_PRIO
   if (!on) return;
@@ -410,7 +410,7 @@ __device__ __forceinline__ void spline_hist_body(
   Segments seg(gend, ch);
   // (Requesting the chunk's first batch of records before the tile is zeroed -- and, in the gradient kernel, before the
   // entropy tail / G tile -- was measured in round 4: histogram kernel unchanged, gradient kernel +2 us (the compiler peels
-  // the first iteration: 3963 instead of 2960 instructions); profiles/r04d_variants.txt.  Not kept.)
+  // the first iteration: 3963 instead of 2960 instructions); profiles/archive/r04d_variants.txt.  Not kept.)
   RawBatch<Rec, kUnroll> rb;
   for (;;) {
     // a zeroed tile for every segment (coalesced stores; zeroing inside the flush below -- 32 more LDS addresses per thread in the
@@ -465,7 +465,7 @@ __device__ __forceinline__ void spline_hist_body(
     // GUARDED = the batch may reach past the end of the segment (clamped loads, per-slot validity).  -DNID_EXP_NOCLAMP runs
     // every full batch without the checks and only the last one with them, as the gradient loop does: no gain HERE (the
     // compiler restructures the two tap paths: 927 against 887 instructions per batch; 51.2-52.1 us either way,
-    // profiles/r04g_variants.txt)
+    // profiles/archive/r04g_variants.txt)
     auto batch = [&](uint32_t base, auto guarded) {
       constexpr bool GUARDED = decltype(guarded)::value;
       set_progress_priority(prio, seg.pos - ch.start + base, ch.count);
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(kThreads, nearest_min_waves(MODEL, std::is_same<rea
     // kUnroll records per thread are fetched before any of them is processed, the decisions of all of them come before the
     // first pixel gather, and the gathers before the first LDS add: every memory latency of an iteration is paid once.
     // (Until round 3 the four points ran one after the other, each through its own gather: 40 % of the wave cycles waited
-    // on memory, profiles/r04a_pmc_summary_nearest.txt.)  No progress priority here (profiles/r02g_kernel_gaps.txt).
+    // on memory, profiles/archive/r04a_pmc_summary_nearest.txt.)  No progress priority here (profiles/archive/r02g_kernel_gaps.txt).
     for (uint32_t base = 0; base < cnt; base += kThreads * kUnroll) {
       real xs[kUnroll], ys[kUnroll], zs[kUnroll];
       uint32_t bins_[kUnroll];
@@ -879,7 +879,7 @@ __device__ __forceinline__ void entropy_final_body(
 // columns 4q .. 4q+3, i.e. 4 loads and 4 logs per thread (with one 256-thread workgroup per 16 columns the 16 dependent log
 // chains of a wave ran at single-wave latency: 13.8 us); the quarter-row partials meet in LDS.
 // Round 4: 8 columns x 512 threads (32 workgroups at B = 256) instead of 16 x 1024 (16 workgroups): 8.8 -> 7.2 us event-timed
-// on cfg 2, 4 x 256 (64 workgroups) the same (profiles/r04d_variants.txt).
+// on cfg 2, 4 x 256 (64 workgroups) the same (profiles/archive/r04d_variants.txt).
 #ifndef NID_ENTROPY_COLS
 #define NID_ENTROPY_COLS 8
 #endif
@@ -970,7 +970,7 @@ __global__ __launch_bounds__(kEntropyThreads) void k_entropy(
   (void)row_part;
   // cost + Jacobian: the tail (three entropies -> NID, coefficients, phi(q_r)) is run by every workgroup of k_spline_grad in
   // its prologue, in parallel on all CUs, from the partials stored above (grad_scalars_from_partials) -- the ticket, the
-  // acquire and one workgroup's serial tail (~6.8 us of this kernel, profiles/r02g_variants_prio.txt) leave the critical path
+  // acquire and one workgroup's serial tail (~6.8 us of this kernel, profiles/archive/r02g_variants_prio.txt) leave the critical path
   if (!tail) return;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's atomics have been performed
   const u64* col_sum = hist + size_t(B) * size_t(B) + kTailWords;  // accumulated by the histogram kernels' flush
@@ -993,7 +993,7 @@ __global__ __launch_bounds__(kEntropyThreads) void k_entropy(
 // Round 5: ONE exchange per evaluation (replicated histogram).  Rounds 3-4 kept the B x B table at home and exchanged
 // (2 + B + B/n) words of partial sums instead -- but the inlier count S sits inside every logarithm (p = h / S), so that took
 // TWO dependent exchanges (S first, then the partials) and two more kernels; their round trips were the whole protocol cost
-// (32 -> 50-55 us per evaluation at 2-3 shards, profiles/r04k_shard_phases.json).  Now every shard holds a replica of the whole
+// (32 -> 50-55 us per evaluation at 2-3 shards, profiles/archive/r04k_shard_phases.json).  Now every shard holds a replica of the whole
 // integer histogram (fine-grained device memory, mapped into every peer):
 //   k_*_hist          the shard's own points into its own columns of its own replica (as an unsharded handle does)
 //   k_entropy_repl    one workgroup per block of CB columns, as k_entropy.  PUSH: the workgroups whose block this shard owns
@@ -1291,7 +1291,7 @@ __device__ __forceinline__ void spline_grad_loop(
     }
   };
   // every full batch without the bounds checks, the last one with them: 18 of ~920 instructions per batch less, 75.3-75.8 ->
-  // 74.8-75.0 us on cfg 2 (profiles/r04g_variants.txt; -DNID_GRAD_ALWAYS_GUARDED: the single loop)
+  // 74.8-75.0 us on cfg 2 (profiles/archive/r04g_variants.txt; -DNID_GRAD_ALWAYS_GUARDED: the single loop)
   // (SPLIT = false: the looped kernel instantiations, which have no registers to spare for a second copy of the body)
 #ifdef NID_GRAD_ALWAYS_GUARDED
   constexpr bool kSplit = false;
@@ -1506,7 +1506,7 @@ __global__ __launch_bounds__(kThreads, grad_min_waves(MODEL, SEG, sizeof(Rec) ==
           for (long long k = (long long)my_block * kThreads + tid; k < zero_words; k += (long long)my_blocks * kThreads) zero_buf[k] = 0;
         // (Requesting everything the three prologue steps read -- the cells, S, the column sums, the G tile's cells -- at
         // entry, in one round trip, changed nothing: stage stamps 2.8 + 0.9 us before, 3.4 + 0.2 us after.  The prologue is a
-        // chain of dependent fp64 logarithms / divisions at one wave per SIMD, not of loads; profiles/r04n_stage_times*.json.)
+        // chain of dependent fp64 logarithms / divisions at one wave per SIMD, not of loads; profiles/archive/r04n_stage_times*.json.)
         const EntropyScalars es = grad_scalars_from_partials<kThreads, true>(hist, B, inv_unit, gt, s_phi, reinterpret_cast<long long*>(s_red), my_block == 0, out);
         coefA = es.coefA, coefB = es.coefB, S = es.S;
         phi_q = s_phi;

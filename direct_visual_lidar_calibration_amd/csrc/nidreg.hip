@@ -232,7 +232,7 @@ std::atomic<int> g_inflight[NIDREG_MAX_DEVICES];  // evaluations in flight per d
 // ---- streams and host-mapped result blocks are kept between handles ---------------------------------------------------------
 // The reference builds a new NIDCost per pair in every outer iteration (visual_camera_calibration.cpp:199-208).  Creating and
 // destroying a handle for a 100k-point cloud took 0.98 ms, of which hipStreamCreate + hipStreamDestroy 0.5 + 0.4 ms and
-// hipHostFree 0.2 ms (rocprofv3 --hip-trace, profiles/r04m_hip_api_stats.csv) -- thirty evaluations' worth.  A destroyed
+// hipHostFree 0.2 ms (rocprofv3 --hip-trace, profiles/archive/r04m_hip_api_stats.csv) -- thirty evaluations' worth.  A destroyed
 // handle's stream (idle: free_handle synchronises it) and result blocks go to a per-device free list and the next handle on
 // that device takes them; nidreg_trim() releases them.
 struct ResourcePool {
@@ -418,7 +418,7 @@ inline void bump_seq(nidreg_handle* h) {
 // Evaluations in flight per device (this process).  An evaluation that has its device to itself runs with progress
 // priority in the spline passes; with several callers on one GPU (the reference's OpenMP loop over pairs,
 // visual_camera_calibration.cpp:161) it is off: the rule made competing kernels 5-16 % slower
-// (profiles/r02h_multi_pair_threads.txt).
+// (profiles/archive/r02h_multi_pair_threads.txt).
 struct InflightGuard {
   int dev;
   bool alone;
@@ -826,7 +826,7 @@ namespace {
 // exact on a cloud whose columns are equally full -- the rank equalisation of preprocess.cpp:464-473 makes them so for a
 // WHOLE cloud --, but the clouds `calibrate` evaluates are view-culled (visual_camera_calibration.cpp:201-206) and a pair of
 // a multi-pair set is a subset: with columns of 0.5 ... 1.5 x the mean an integer split leaves chunks of 3/4 ... 3/2 of the
-// mean (measured: +20 % per point, profiles/r03r_culled_cloud_ab*.json).  Since round 4 a chunk is a CONTIGUOUS RANGE of
+// mean (measured: +20 % per point, profiles/archive/r03r_culled_cloud_ab*.json).  Since round 4 a chunk is a CONTIGUOUS RANGE of
 // records that may run across group boundaries (nid_kernels.hpp Segments): the workgroup flushes / rebuilds its tile at
 // every boundary, which costs about `overhead` records' worth of time (pipeline drain, 64 KB of LDS traffic, the first
 // load latency of the next segment).  The table minimises the longest chunk under that cost model:
@@ -919,7 +919,7 @@ int64_t split_groups(const int64_t* gcount, int NG, int64_t target, int64_t over
   int segs = 1;
   if (max_segs > 1) {
     // Chunks across groups only where they PAY: the looped kernel instantiations run 2-6 % slower per point than the
-    // straight-line ones (measured, profiles/r04c_culled_cloud_ab.jsonl: on clouds whose columns are nearly equally full the
+    // straight-line ones (measured, profiles/archive/r04c_culled_cloud_ab.jsonl: on clouds whose columns are nearly equally full the
     // better balance did not make up for it), so the segmented table must beat the best one-group-per-chunk table by
     // NIDREG_SEG_MIN_GAIN (default 10 %) in the cost model -- rounds x longest chunk -- to be chosen.
     const char* mg = std::getenv("NIDREG_SEG_MIN_GAIN");
@@ -954,7 +954,7 @@ int64_t segment_overhead(bool wide_hist) {
 // costs a fixed prologue + epilogue (tile zeroing, the G columns' logarithms, the flush's atomics on the cells every other
 // workgroup flushes too, the partial reduction), and the workgroups of a CU share its issue slots, so a pass costs about
 //     a x chunks / CUs  +  b x points / chunks          (prologues on the busiest CU + the sweeps of one workgroup's slice),
-// smallest at chunks ~ sqrt(points).  Measured (profiles/r04i_small_cloud_sweep.jsonl, synchronous cost+Jacobian evaluation,
+// smallest at chunks ~ sqrt(points).  Measured (profiles/archive/r04i_small_cloud_sweep.jsonl, synchronous cost+Jacobian evaluation,
 // best chunk count against the full round's): 30k points 64-128 chunks, 28 us against 37; 100k 128, 29 against 48; 300k
 // 192-256, 35 against 51; 1M 384-512, 45 against 54; 3M 512-768, 71 against 76; 10M 1024 (the full round).  The rule is the
 // square root through those points -- CUs/2 chunks at 100k points --, capped by the full round (reached at 6.4M points).
@@ -1295,8 +1295,8 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
     if (hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || num_cus <= 0) num_cus = 256;
     // (Tried and dropped: emitting a group's parts part-major -- part j of every group in dispatch slot j of the CUs -- and
     // sizing them by slot weights.  The first-dispatched workgroup of a CU does run ~8 % faster than the second, systematically
-    // (profiles/r03d_workgroup_spread.txt), but the workgroups of one CU share its issue capacity: what ends a pass is the
-    // slowest CU, not the slowest workgroup, and no weighting moved the kernel times (profiles/r03e_slot_weights_no_gain.txt;
+    // (profiles/archive/r03d_workgroup_spread.txt), but the workgroups of one CU share its issue capacity: what ends a pass is the
+    // slowest CU, not the slowest workgroup, and no weighting moved the kernel times (profiles/archive/r03e_slot_weights_no_gain.txt;
     // the part-major order itself cost 3 us in the gradient pass).)
     const int max_segs = max_segments(d->mode, GW);
     auto build_chunks = [&](int target, bool wide_hist, std::vector<Chunk>& chunks) { return split_groups(gcount.data(), h->NG, target, segment_overhead(wide_hist), max_segs, -1, chunks); };
@@ -1430,7 +1430,7 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
   }
   for (int i = 0; i < 6; i++) CREATE_TRY(hipEventCreate(&h->ev[i]));
   // The clears above (result block, histogram buffers, scratch incl. the ticket counters) are hipMemset calls on the null
-  // stream, which return before they have run (2.9 us per call in the API trace, profiles/r04m_hip_api_stats.csv), and the
+  // stream, which return before they have run (2.9 us per call in the API trace, profiles/archive/r04m_hip_api_stats.csv), and the
   // handle's own stream is non-blocking: the first evaluation must not be able to overtake them.
   CREATE_TRY(hipStreamSynchronize(nullptr));
 #undef CREATE_TRY
@@ -1726,7 +1726,7 @@ MultiGroup* find_or_make_group(nidreg_handle* const* handles, int n) {
   }
   // the pairs' chunks one after the other.  (An XCD-aware order -- workgroup b runs on XCD b mod 8, so XCD x would only see
   // the bin image of pair floor(x n / 8) -- was measured and changed nothing: 2 / 4 / 8 pairs 204 / 183 / 176 us against
-  // 191 / 185 / 178 us, profiles/r03g_multi_pair_patterns.jsonl: the images' L2 footprint is not what slows the group down.)
+  // 191 / 185 / 178 us, profiles/archive/r03g_multi_pair_patterns.jsonl: the images' L2 footprint is not what slows the group down.)
   std::vector<Chunk> chunks, wide_chunks;
   for (int i = 0; i < n; i++) chunks.insert(chunks.end(), pair_grad[size_t(i)].begin(), pair_grad[size_t(i)].end());
   for (int i = 0; i < n; i++) wide_chunks.insert(wide_chunks.end(), pair_hist[size_t(i)].begin(), pair_hist[size_t(i)].end());
@@ -2042,7 +2042,7 @@ int group_eval_iso(MultiGroup* g, const double* T, double* costs) {
 
 // handles[0..n) all distinct, compatible and on one device?
 // Measured on the same clouds in one harness (tools/omp_pairs.cpp on the 10M-point scene split into n pairs,
-// profiles/r03q_omp_pairs.jsonl), microseconds per evaluation of all pairs: single grid 152 / 149 / 172 at 2 / 4 / 8
+// profiles/archive/r03q_omp_pairs.jsonl), microseconds per evaluation of all pairs: single grid 152 / 149 / 172 at 2 / 4 / 8
 // pairs, per-pair launches 154 / 198 / 274, one OpenMP caller per pair 173 / 215 / 282.  (Until the chunk tables were made
 // to fit one round -- split_groups -- the single grid took 191 / 185 / 178 and two or three pairs ran as per-pair launches.)
 // The single grid (three launches instead of 3 n) is therefore used from two pairs on; NIDREG_MULTI_GRID_MIN=n moves the
@@ -3049,7 +3049,7 @@ int nidreg_project(nidreg_handle* h, const double* p3, int64_t n, double* uv, do
     // A handful of points (estimate_camera_fov inverts the projection at three pixels with NelderMead<2>: ~240 calls of ONE
     // point, src/vlcal/common/estimate_fov.cpp:17-51): the same kernel on a host-mapped staging block kept per device -- no
     // hipMalloc / hipMemcpy / hipFree per call (60 -> ~15 us; those calls were 16 of the 24 ms a whole configs[0] calibration
-    // took, profiles/r04q_profile_1bag_bfgs.txt).
+    // took, profiles/archive/r04q_profile_1bag_bfgs.txt).
     SmallProject& sp = g_small_project[h->device];
     std::lock_guard<std::mutex> lk(sp.mu);
     if (!sp.host) {

@@ -3,7 +3,7 @@
 Every oracle comparison of the ``-m gpu`` suite goes through ``check_cost`` / ``check_grad`` / ``check_hist``: they assert
 the bar and remember the observed difference.  ``conftest.py`` writes the session's maxima (and the worst few cases per
 quantity) to ``$NIDREG_MARGINS_OUT`` (default ``gpurun_out/parity_margins.json``); the copy committed as
-``profiles/r04a_parity_margins.json`` (the full suite on the round's first GPU pass: 124 cost, 112 gradient, 38 histogram
+``profiles/archive/r04a_parity_margins.json`` (the full suite on the round's first GPU pass: 124 cost, 112 gradient, 38 histogram
 comparisons) is what the bars below were set from -- about 10x the largest difference observed (VERDICT r3 "tighten the
 parity bars to what the kernels deliver"):
 

@@ -132,7 +132,7 @@ def test_bench_helpers_algorithmic_bytes_labels_and_committed_traffic():
     assert "configs[3]" in bench.baseline_config_label(ns)
     ns.points = 123
     assert bench.baseline_config_label(ns) == "custom workload"
-    files = sorted(glob.glob(os.path.join(root, "profiles", "*_traffic.json")))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "archive", "*_traffic.json"))) + sorted(glob.glob(os.path.join(root, "profiles", "*_traffic.json")))
     assert files, "a PMC traffic summary must be committed under profiles/"
     headline = [f for f in files if json.load(open(f)).get("workload", {}).get("width") == 1920 and json.load(open(f))["workload"].get("points") == 10_000_000]
     t = json.load(open(headline[-1]))  # (other camera models' summaries are committed next to it since round 5)
@@ -260,7 +260,7 @@ def test_chunk_tables_fit_one_round_of_workgroups():
 def test_small_clouds_get_fewer_chunks_than_a_full_round():
     """The number of chunks of a pass (csrc/nidreg.hip round_chunks / snap_to_groups, through a test hook): CUs/2 at 100k points,
     growing with the square root of the cloud, the full round of co-resident workgroups from 6.4M points on; whole multiples of
-    the non-empty column groups and never fewer chunks than groups (profiles/r04i_small_cloud_sweep.jsonl: what each of
+    the non-empty column groups and never fewer chunks than groups (profiles/archive/r04i_small_cloud_sweep.jsonl: what each of
     these choices was measured against)."""
     import ctypes
 
@@ -289,7 +289,7 @@ def test_small_clouds_get_fewer_chunks_than_a_full_round():
 
 
 def test_chunk_rule_lands_near_the_best_measured_count():
-    """The rule against the sweep it was drawn through (profiles/r04i_small_cloud_sweep.jsonl: microseconds per synchronous
+    """The rule against the sweep it was drawn through (profiles/archive/r04i_small_cloud_sweep.jsonl: microseconds per synchronous
     cost+Jacobian evaluation on an MI355X with the number of chunks forced, 30k ... 3M points, 16 / 64 / 256 bins): at the rule's
     count the measured time -- interpolated between the two nearest measured counts -- is within 8 % of the best measured one."""
     import ctypes
@@ -300,7 +300,7 @@ def test_chunk_rule_lands_near_the_best_measured_count():
 
     lib = _lib.load()
     lib.nidreg_debug_round_chunks.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.c_int]
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04i_small_cloud_sweep.jsonl")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "archive", "r04i_small_cloud_sweep.jsonl")
     rows = [json.loads(line) for line in open(path)]
     assert len(rows) == 15
     worst = 0.0

@@ -1,7 +1,7 @@
 """BASELINE.json configs[0] end to end -- `calibrate <dir>` on a preprocessed directory of 100k-point bags, VGA pinhole, 16 bins:
 wall time of the whole calibration on the GPU engine against the same host driver on the CPU oracle (the reference's serial
 cost functors), and the final extrinsics within 1e-3 m / 1e-3 rad of each other.  Opt-in (the CPU side takes about a minute
-per case): NIDREG_TIME_TO_SOLUTION=1; writes gpurun_out/time_to_solution.json (committed as profiles/r04q_time_to_solution.json)."""
+per case): NIDREG_TIME_TO_SOLUTION=1; writes gpurun_out/time_to_solution.json (committed as profiles/archive/r04q_time_to_solution.json)."""
 import json
 import os
 import time

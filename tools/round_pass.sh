@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU pass of a round: `gpurun -- bash tools/round_pass.sh <tag> <step> [<step> ...]` (replaces the per-pass scripts of
-# rounds 3-4, tools/rounds/ -- their measurements live on in profiles/r03*_*, r04*_*).  Everything lands in gpurun_out/<tag>/;
+# rounds 3-4, tools/rounds/ -- their measurements live on in profiles/archive/r03*_*, r04*_*).  Everything lands in gpurun_out/<tag>/;
 # what is to be judged is copied to profiles/ by hand afterwards.  Steps (run in the order given):
 #   tests[=<pytest -k expression>]      the -m gpu suite (or a subset) with the parity-margin recorder
 #   stats=<camera>:<points>[:<bins>]    rocprofv3 --kernel-trace --stats around tools/run_scene.py on a cached scene
