@@ -1462,7 +1462,7 @@ struct MultiGroup {
 // short list of handle lists that cannot be grouped (a pair's partial buffer too small for its share of the table) so that
 // the chunk tables are not rebuilt on every call.  A group in use is never freed: acquire_group / release_group count the
 // evaluations running on it, and a handle's destruction waits for them.
-constexpr size_t kMaxGroups = 16, kMaxRejected = 32;
+constexpr size_t kMaxGroups = 64, kMaxRejected = 32;  // (a cohort of k members may be evaluated as any of its subsets: 16 entries thrashed at k >= 5)
 std::mutex g_groups_mu;
 std::vector<MultiGroup*> g_groups;
 std::vector<std::vector<nidreg_handle*>> g_rejected;
@@ -1651,6 +1651,15 @@ void cohort_leave(nidreg_handle* h) {
 
 // returns the group with its use count raised (release_group when the evaluation is over), or nullptr
 MultiGroup* find_or_make_group(nidreg_handle* const* handles, int n) {
+  // evicted groups are drained and freed AFTER the lock is released (free_group synchronises a stream: with the lock held every
+  // concurrent caller on the device waited behind it -- ADVICE r4)
+  std::vector<MultiGroup*> evicted;
+  struct FreeEvicted {
+    std::vector<MultiGroup*>& v;
+    ~FreeEvicted() {
+      for (MultiGroup* g : v) free_group(g);
+    }
+  } free_evicted{evicted};  // (declared before the lock: destroyed after it)
   std::lock_guard<std::mutex> lk(g_groups_mu);
   for (MultiGroup* g : g_groups)
     if (int(g->hs.size()) == n && std::equal(g->hs.begin(), g->hs.end(), handles)) {
@@ -1741,7 +1750,7 @@ MultiGroup* find_or_make_group(nidreg_handle* const* handles, int n) {
     if (err == hipSuccess && !wide_chunks.empty()) err = hipMemcpy(g->d_chunks_hist, wide_chunks.data(), wide_chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice);
   }
   if (err != hipSuccess) {
-    free_group(g);
+    evicted.push_back(g);  // (freed once the lock is released)
     return nullptr;
   }
   g->nchunks = int(chunks.size());
@@ -1753,7 +1762,7 @@ MultiGroup* find_or_make_group(nidreg_handle* const* handles, int n) {
     for (size_t i = 0; i < g_groups.size(); i++)
       if (g_groups[i]->users.load(std::memory_order_acquire) == 0 && (victim == g_groups.size() || g_groups[i]->last_use < g_groups[victim]->last_use)) victim = i;
     if (victim == g_groups.size()) break;
-    free_group(g_groups[victim]);
+    evicted.push_back(g_groups[victim]);
     g_groups.erase(g_groups.begin() + long(victim));
   }
   g->users.store(1, std::memory_order_release);
