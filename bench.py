@@ -175,6 +175,12 @@ def main():
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(relaunch_one_process_per_gpu(args.gpus))
+    # stdout carries exactly ONE line, the JSON line of rank 0: everything else that writes to file descriptor 1 while the bench
+    # runs -- RCCL prints a five-line version banner there when the first communicator of a process is created (torch's "nccl"
+    # backend at N > 1, the in-library route's world-1 communicator at N = 1) -- goes to stderr instead
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
 
@@ -737,7 +743,8 @@ def main():
         }
         if cpu:
             line["speedup_vs_cpu_port"] = round(value / cpu["value"], 1)
-        print(json.dumps(line))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.barrier(group=cpu_group)
         dist.destroy_process_group()

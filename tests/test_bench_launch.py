@@ -42,6 +42,7 @@ def test_two_ranks_on_one_gpu_produce_the_full_line():
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
+    assert r.stdout.strip() == lines[0]  # stdout is the ONE JSON line: banners of libraries (RCCL prints one on stdout) go to stderr
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["ranks_seen"] == 2
     mg = d["multi_gpu"]
@@ -52,3 +53,16 @@ def test_two_ranks_on_one_gpu_produce_the_full_line():
     sp = mg["single_process_sharded"]
     assert "error" not in sp, sp
     assert sp["configs2"]["devices"] == [0, 0] and sp["configs2"]["value"] > 0 and sp["configs4"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_one_gpu_bench_stdout_is_exactly_one_json_line():
+    """`python bench.py` at N = 1 creates a one-rank RCCL communicator inside the library (other_entry_points.inlib_rccl_world1):
+    RCCL's version banner must not reach stdout, which carries the JSON line and nothing else."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--blocks", "3", "--points", "300000", "--no-cpu-baseline", "--no-config-legs"],
+                       capture_output=True, text=True, env=_env(), timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.stdout.count("\n") == 1 and r.stdout.startswith("{"), r.stdout[-2000:]
+    d = json.loads(r.stdout)
+    rc = d["other_entry_points"]["inlib_rccl_world1"]
+    assert "error" not in rc and rc["cost_equals_plain_handle"] and rc["evals_per_s"] > 0

@@ -291,7 +291,7 @@ def test_create_camera_error_behaviour():
     with pytest.raises(RuntimeError):
         s = scene_for("plumb_bob", n=2000)
         proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
-        nid.NIDCost(proj, s.image_f64, s.points, s.intensities, 1000)  # bins > 256 unsupported
+        nid.NIDCost(proj, s.image_f64, s.points, s.intensities, 5000)  # bins > 4096 unsupported (257 ... 4096: the occupied bins)
 
 
 def test_full_size_properties_cfg2_like():
