@@ -20,7 +20,9 @@
 
 #include <type_traits>
 
+#include <cstring>
 #include "nid_atan_table.hpp"
+#include "nid_log_table.hpp"
 
 namespace nidreg {
 
@@ -252,6 +254,50 @@ NID_HD double fast_atan2(double y, double x) {
   return copysign(a, y);
 }
 NID_HD float fast_atan2(float y, float x) { return atan2f(y, x); }
+
+// Natural logarithm for the entropy terms and the G tile (p log(p + 1e-6), log(q + 1e-6): arguments in [1e-6, 1.000001]; any
+// positive normal double works).  The library's log is ~95 dependent VALU instructions, 44 of them double-double additions,
+// and the entropy tail that every gradient workgroup runs in its prologue is a chain of three to four of them at one wave per
+// SIMD (2.8 + 0.9 us of a small evaluation, profiles/archive/r04n_stage_times.json).  Here: x = 2^k m with m in [0.6875, 1.375) --
+// so that x near 1 gives k = 0 and no cancellation against k ln 2 --, a 128-entry table (nid_log_table.hpp: r_i = 1 / centre of
+// m's sub-interval, -log(r_i) correctly rounded; 2 KB, read through the vector L1 like the atan table),
+//   log(x) = k ln 2 - log(r_i) + log1p(z),   z = m r_i - 1 (one fma: |z| <= 0.004),
+//   log1p(z) = z - z^2/2 + z^3/3 - z^4/4 + z^5/5 - z^6/6   (next term z^7/7 < 2.4e-18):
+// ~19 instructions, absolute error < 3e-16 on the host against a 60-digit reference over [1e-9, 4] (test_device_math), i.e.
+// 1e-5 of the cost's parity bar.  Every route of the entropy work calls this one function: the cost stays bit-identical across
+// routes.  x <= 0, inf, NaN (only reached when there is no inlier, where entropy_scalars overrides the result): some finite or
+// NaN value, never a trap.
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ const double g_log_tab[2 * kLogTableN] = {NID_LOG_TABLE_VALUES};
+#else
+static const double g_log_tab[2 * kLogTableN] = {NID_LOG_TABLE_VALUES};
+#endif
+NID_HD double fast_log(double x) {
+  uint32_t hi, lo;
+#if defined(__HIP_DEVICE_COMPILE__)
+  hi = uint32_t(__double2hiint(x)), lo = uint32_t(__double2loint(x));
+#else
+  uint64_t bits;
+  std::memcpy(&bits, &x, sizeof(bits));
+  hi = uint32_t(bits >> 32), lo = uint32_t(bits);
+#endif
+  const uint32_t tmp = hi - 0x3fe60000u;
+  const int k = int(tmp) >> 20;                 // (arithmetic shift: x < 0.6875 gives negative k)
+  const uint32_t i = (tmp >> 13) & 127u;
+  const uint32_t mhi = hi - (tmp & 0xfff00000u);  // exponent of m: 0x3fe or 0x3ff
+  double m;
+#if defined(__HIP_DEVICE_COMPILE__)
+  m = __hiloint2double(int(mhi), int(lo));
+#else
+  bits = (uint64_t(mhi) << 32) | lo;
+  std::memcpy(&m, &bits, sizeof(m));
+#endif
+  const double r = g_log_tab[2 * i], t = g_log_tab[2 * i + 1];
+  const double z = fma(m, r, -1.0);
+  const double q = fma(fma(fma(fma(-1.0 / 6.0, z, 0.2), z, -0.25), z, 1.0 / 3.0), z, -0.5);
+  const double l1p = fma(z * z, q, z);
+  return fma(double(k), 0.69314718055994530942, t + l1p);
+}
 
 // perspective division: exact x/z, y/z (NEAREST path) or one reciprocal and two multiplies (SPLINE
 // kernels; both passes use the same form, so they agree on every knot)

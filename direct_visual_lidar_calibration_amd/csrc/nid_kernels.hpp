@@ -833,14 +833,14 @@ __device__ __forceinline__ void entropy_final_body(
     for (int g = 0; g < NG; g++) t += row_part[size_t(g) * size_t(B) + r];
     const double raw = double(t) * inv_unit;  // raw (un-normalised) hist_image[r]
     const double q = raw / S;
-    hi_acc += ent_fixed(q * log(q + 1e-6));
-    phi_q[r] = log(q + 1e-6) + q / (q + 1e-6);
+    hi_acc += ent_fixed(q * fast_log(q + 1e-6));
+    phi_q[r] = fast_log(q + 1e-6) + q / (q + 1e-6);
     hist_image_out[r] = raw;
   }
   for (int c = tid; c < B; c += kThreads) {
     const double cnt = rint(double(col_sum[c]) * inv_unit);  // exact inlier count of column c
     const double p = cnt / S;
-    hp_acc += ent_fixed(p * log(p + 1e-6));
+    hp_acc += ent_fixed(p * fast_log(p + 1e-6));
     hist_points_out[c] = cnt;
   }
   for (int g = tid; g < NG; g += kThreads) hj_acc += part_hj[g];
@@ -944,7 +944,7 @@ __global__ __launch_bounds__(kEntropyThreads) void k_entropy(
   for (int c = 0; c < kPer; c++) {
     if (v[c]) {
       const double p = double(v[c]) * scale;
-      acc += ent_fixed(p * log(p + 1e-6));
+      acc += ent_fixed(p * fast_log(p + 1e-6));
     }
     row += v[c];
   }
@@ -1139,7 +1139,7 @@ __global__ __launch_bounds__(kEntropyThreads) void k_entropy_repl(
   for (int c = 0; c < kPer; c++) {
     if (v[c]) {
       const double p = double(v[c]) * scale;
-      acc += ent_fixed(p * log(p + 1e-6));
+      acc += ent_fixed(p * fast_log(p + 1e-6));
     }
     row += v[c];
   }
@@ -1354,7 +1354,7 @@ __device__ __forceinline__ void grad_entropy_partials(const u64* __restrict__ hi
     const u64 v = hist[k];
     if (v) {
       const double p = double(v) * scale;
-      acc += ent_fixed(p * log(p + 1e-6));
+      acc += ent_fixed(p * fast_log(p + 1e-6));
       atomicAdd(&s_rows[k % B], (unsigned long long)v);  // device layout [bin_points][bin_image]: k % B = the image bin
     }
   }
@@ -1386,13 +1386,13 @@ __device__ __forceinline__ EntropyScalars grad_scalars_from_partials(const u64* 
   for (int r = tid; r < B; r += kT) {
     const double raw = double(row_sum[r]) * inv_unit;  // raw (un-normalised) hist_image[r]
     const double qv = raw / S;
-    const double lq = log(qv + 1e-6);
+    const double lq = fast_log(qv + 1e-6);
     hi_k += ent_fixed(qv * lq);
     const double ph = lq + qv / (qv + 1e-6);
     s_phi[r] = ph;
     const double cnt = rint(double(col_sum[r]) * inv_unit);  // exact inlier count of column r
     const double p = cnt / S;
-    hp_k += ent_fixed(p * log(p + 1e-6));
+    hp_k += ent_fixed(p * fast_log(p + 1e-6));
     if (writer) {
       gt.phi_q[r] = ph;
       gt.hist_image[r] = raw;
@@ -1433,7 +1433,7 @@ __device__ __forceinline__ void build_gtile(const u64* __restrict__ hist, uint32
   const int n = ncols * B;
   for (int k = tid; k < n; k += kThreads) {
     const double p = double(src[k]) * scale;
-    const double gval = (coefA * (log(p + 1e-6) + p / (p + 1e-6)) + coefB * phi_q[k % B]) * (1.0 / 12.0);
+    const double gval = (coefA * (fast_log(p + 1e-6) + p / (p + 1e-6)) + coefB * phi_q[k % B]) * (1.0 / 12.0);
     for (uint32_t j = 0; j <= cmask; j++) gtile[(uint32_t(k) << cshift) + ((j + uint32_t(k)) & cmask)] = gval;
   }
 }

@@ -73,20 +73,20 @@ static int run(const CamParams<double>& cam, int W, int H, int B, const std::vec
     u64 t = 0;
     for (int c = 0; c < B; c++) t += hist[size_t(c) * B + r];
     const double q = double(t) * inv_unit / S;
-    hi += q * std::log(q + 1e-6);
-    phi_q[size_t(r)] = std::log(q + 1e-6) + q / (q + 1e-6);
+    hi += q * fast_log(q + 1e-6);
+    phi_q[size_t(r)] = fast_log(q + 1e-6) + q / (q + 1e-6);
   }
   for (int c = 0; c < B; c++) {
     u64 t = 0;
     for (int r = 0; r < B; r++) t += hist[size_t(c) * B + r];
     const double p = std::rint(double(t) * inv_unit) / S;  // exact inlier count of the column (partition of unity)
-    hp += p * std::log(p + 1e-6);
+    hp += p * fast_log(p + 1e-6);
   }
   const double scale = inv_unit / S;
   for (size_t k = 0; k < hist.size(); k++)
     if (hist[k]) {
       const double p = double(hist[k]) * scale;
-      hj += p * std::log(p + 1e-6);
+      hj += p * fast_log(p + 1e-6);
     }
   const double Hi = -hi, Hp = -hp, Hj = -hj;
   const double MI = Hi + Hp - Hj, nid = (Hj - MI) / Hj;
@@ -97,7 +97,7 @@ static int run(const CamParams<double>& cam, int W, int H, int B, const std::vec
   for (int c = 0; c < B; c++)
     for (int r = 0; r < B; r++) {
       const double p = double(hist[size_t(c) * B + r]) * scale;
-      G[size_t(c) * B + r] = (coefA * (std::log(p + 1e-6) + p / (p + 1e-6)) + coefB * phi_q[size_t(r)]) * (1.0 / 12.0);  // the taps use 6 b and 2 db/ds
+      G[size_t(c) * B + r] = (coefA * (fast_log(p + 1e-6) + p / (p + 1e-6)) + coefB * phi_q[size_t(r)]) * (1.0 / 12.0);  // the taps use 6 b and 2 db/ds
     }
   double acc[12] = {0};
   for (int64_t i = 0; i < N; i++) {

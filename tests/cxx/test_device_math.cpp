@@ -256,5 +256,29 @@ int main() {
     if (ea > 1e-15 + tol || er > tol || es > tol) bad++;
     if (fast_atan2(0.0, 0.0) != 0.0 || fast_atan2(0.0, -1.0) != std::atan2(0.0, -1.0) || fast_atan2(-0.0, 1.0) != 0.0) bad++;
   }
+  // fast_log (the entropy terms' and the G tile's logarithm): against the long-double library logarithm over [1e-9, 4], dense
+  // around 1 (where k = 0 must leave no cancellation) and on the arguments the kernels really pass (p + 1e-6, p in [0, 1])
+  {
+    std::mt19937_64 rng(123);
+    std::uniform_real_distribution<double> U(0.0, 1.0);
+    double erel = 0, eabs1 = 0;
+    for (int i = 0; i < 3000000; i++) {
+      double x;
+      switch (i % 4) {
+        case 0: x = std::exp(std::log(1e-9) + U(rng) * (std::log(4.0) - std::log(1e-9))); break;
+        case 1: x = U(rng) + 1e-6; break;
+        case 2: x = 1.0 + (U(rng) - 0.5) * 1e-3; break;
+        default: x = 0.6875 + U(rng) * 0.6875; break;
+      }
+      const long double ref = logl((long double)x);
+      const double got = fast_log(x);
+      const long double d = fabsl((long double)got - ref);
+      erel = std::fmax(erel, double(d / std::fmax(1e-2L, fabsl(ref))));
+      if (std::fabs(x - 1.0) < 1e-3) eabs1 = std::fmax(eabs1, double(d));
+    }
+    std::printf("fast_log: max error relative to max(|log x|, 1e-2) %.3g; absolute within 1e-3 of x = 1: %.3g\n", erel, eabs1);
+    if (erel > 4e-16 || eabs1 > 1e-17) bad++;
+    if (std::fabs(fast_log(1.0)) > 5e-18) bad++;  // (x = 1 sits at the edge of a table interval: the two halves cancel to ~2e-18, not to 0)
+  }
   return bad ? 1 : 0;
 }
