@@ -190,7 +190,8 @@ __device__ __forceinline__ bool last_workgroup_arrives(unsigned int* counter, un
 // out[1..7] = d NID / d [qx qy qz qw tx ty tz]; out_host (nullable) = host-mapped mirror.
 // s_red: kWaves * 12 doubles of LDS.
 template <int kT>
-__device__ __forceinline__ void grad_final_body(const double* partials, int nblocks, double qx, double qy, double qz, double qw, double* out, double* out_host, double tag, double* s_red) {
+__device__ __forceinline__ void grad_final_body(const double* partials, int nblocks, double qx, double qy, double qz, double qw, double* out, double* out_host, double tag, double* s_red,
+                                                const double* s_fin = nullptr) {
   const int tid = threadIdx.x;
   double acc[12];
 #pragma unroll
@@ -240,9 +241,17 @@ __device__ __forceinline__ void grad_final_body(const double* partials, int nblo
       // trip -- 3.0 -> 2.7 us for the final stage: with five callers on the GPU a host saw the tag BEFORE the cost once in a
       // full suite -- test_concurrent_callers, the previous pose's cost.  Writes of different workgroups (different XCDs) to
       // one host block are not ordered on their way to the host by the writer's s_waitcnt + the ticket.  Reverted.)
-      out_host[0] = __hip_atomic_load(&out[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      out_host[8] = __hip_atomic_load(&out[8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      out_host[9] = __hip_atomic_load(&out[9], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // Round 5: when this kernel ran the tail, the finalising workgroup holds the same three values itself (s_fin: computed in its
+      // own prologue from the same integers) -- no re-read.
+      if (s_fin) {
+        out_host[0] = s_fin[0];
+        out_host[8] = s_fin[1];
+        out_host[9] = s_fin[2];
+      } else {
+        out_host[0] = __hip_atomic_load(&out[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        out_host[8] = __hip_atomic_load(&out[8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        out_host[9] = __hip_atomic_load(&out[9], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       __threadfence_system();
       // completion tag of this evaluation: the host polls this word instead of synchronising the stream
       __hip_atomic_store(&out_host[15], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1442,9 +1451,9 @@ __device__ __forceinline__ void build_gtile(const u64* __restrict__ hist, uint32
 // (the looped instantiations on float records are told to stay at four -- they land at 126-130 by themselves)
 constexpr int grad_min_waves(int model, bool seg = false, bool rec32 = false) { return model == MODEL_ATAN ? 3 : ((seg && rec32) ? 4 : NID_GRAD_MIN_WAVES); }
 // LDS of the gradient kernel: G tile (one copy of one column when GW = 1, else 2^cshift copies of GW columns), reduction scratch,
-// phi(q_r), flag; SEG (GW = 1 only): kMaxSegs - 1 staged G columns behind them
+// phi(q_r), flag, the workgroup's own copy of cost / status / inlier count (s_fin); SEG (GW = 1 only): kMaxSegs - 1 staged G columns behind them
 __host__ __device__ __forceinline__ size_t spline_grad_lds_bytes(int B, int GW, int cshift, bool seg) {
-  return (GW == 1 ? size_t(B) * 8 : (size_t(GW) * size_t(B) * 8 << cshift)) + size_t(kWaves) * 12 * 8 + 256 * 8 + 16 + (seg && GW == 1 ? size_t(kMaxSegs - 1) * size_t(B) * 8 : 0);
+  return (GW == 1 ? size_t(B) * 8 : (size_t(GW) * size_t(B) * 8 << cshift)) + size_t(kWaves) * 12 * 8 + 256 * 8 + 16 + 32 + (seg && GW == 1 ? size_t(kMaxSegs - 1) * size_t(B) * 8 : 0);
 }
 template <int MODEL, typename Rec, typename real, bool GW1, bool MULTI, bool SEG>
 __global__ __launch_bounds__(kThreads, grad_min_waves(MODEL, SEG, sizeof(Rec) == sizeof(Rec32))) void k_spline_grad(
@@ -1460,7 +1469,11 @@ __global__ __launch_bounds__(kThreads, grad_min_waves(MODEL, SEG, sizeof(Rec) ==
   double* s_red = gtile + (tile_n << cshift);
   double* s_phi = s_red + kWaves * 12;  // [256] phi(q_r) when this kernel runs the entropy tail itself
   int* s_flag = reinterpret_cast<int*>(s_phi + 256);
-  double* s_stage = reinterpret_cast<double*>(s_flag + 4);  // SEG: [kMaxSegs - 1][B] G columns of the chunk's later segments
+  // cost, status, inlier count as THIS workgroup's prologue computed them (the same integers everywhere: identical bits): the
+  // workgroup that ends up finalising writes them to the host from here instead of re-reading what the pair's first workgroup
+  // stored (three dependent agent-scope loads, ~1 us of the final stage; round 5)
+  double* s_fin = reinterpret_cast<double*>(s_flag + 4);
+  double* s_stage = s_fin + 4;  // SEG: [kMaxSegs - 1][B] G columns of the chunk's later segments
 
   const int tid = threadIdx.x;
   stamp_stage(0);
@@ -1509,11 +1522,13 @@ __global__ __launch_bounds__(kThreads, grad_min_waves(MODEL, SEG, sizeof(Rec) ==
         // chain of dependent fp64 logarithms / divisions at one wave per SIMD, not of loads; profiles/archive/r04n_stage_times*.json.)
         const EntropyScalars es = grad_scalars_from_partials<kThreads, true>(hist, B, inv_unit, gt, s_phi, reinterpret_cast<long long*>(s_red), my_block == 0, out);
         coefA = es.coefA, coefB = es.coefB, S = es.S;
+        if (tid == 0) s_fin[0] = es.nid, s_fin[1] = es.status, s_fin[2] = es.S;
         phi_q = s_phi;
       }
     } else if (gt.from_partials) {
       const EntropyScalars es = grad_scalars_from_partials<kThreads, false>(hist, B, inv_unit, gt, s_phi, reinterpret_cast<long long*>(s_red), my_block == 0, out);
       coefA = es.coefA, coefB = es.coefB, S = es.S;
+      if (tid == 0) s_fin[0] = es.nid, s_fin[1] = es.status, s_fin[2] = es.S;
       phi_q = s_phi;  // LDS through a generic pointer: B reads per tile
     } else {
       coefA = scal->coefA, coefB = scal->coefB, S = scal->S;
@@ -1561,7 +1576,7 @@ __global__ __launch_bounds__(kThreads, grad_min_waves(MODEL, SEG, sizeof(Rec) ==
   const bool last = last_workgroup_arrives<true>(counter, my_blocks, s_flag);
   stamp_stage(5);
   if (last) {
-    grad_final_body<kThreads>(partials, int(nslots), qx, qy, qz, qw, out, out_host, tag, s_red);
+    grad_final_body<kThreads>(partials, int(nslots), qx, qy, qz, qw, out, out_host, tag, s_red, gt.from_partials ? s_fin : nullptr);
     stamp_stage(6);
   }
 }
