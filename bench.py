@@ -678,6 +678,9 @@ def main():
         def single_process_leg():
             out = {}
             if rank == 0:
+                # (the first time this route meets two physical GPUs should say WHICH exchange path fails, if one does: every ordered
+                # pair of shards ping-pongs once at creation, 200 ms timeout, report on stderr)
+                os.environ.setdefault("NIDREG_SHARD_SELFTEST", "1")
                 devs = [0] * world if one_gpu else list(range(world))
                 for camera, n_points, key, seed in (("equirect_2k", int(10_000_000 * ps), "configs2", 20250523 + 3), ("pinhole_4k", int(50_000_000 * ps), "configs4", 20250523 + 5)):
                     s = synth.make_scene(camera, num_points=n_points, seed=seed, device="cuda:0")
@@ -696,7 +699,7 @@ def main():
                     out[key] = {"value": round(1.0 / med, 2), "unit": "evals/s", "ms_per_step": round(1e3 * med, 5), "points": n_points, "devices": c.shard_devices(), "setup_s": round(setup, 3)}
                     c.close()
                     del s
-                out["route"] = "one process, desc.device_ids: the cloud cut along the histogram column, inlier counts / entropy partials / marginal sums exchanged GPU to GPU inside nidreg_eval, host sums the gradient partials"
+                out["route"] = "one process, desc.device_ids: the cloud cut along the histogram column, every GPU stores its columns of the integer histogram into every other GPU's replica inside nidreg_eval (one exchange), host sums the gradient partials"
             return out
 
         leg("single_process_sharded", single_process_leg)
