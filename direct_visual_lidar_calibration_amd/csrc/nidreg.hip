@@ -778,7 +778,7 @@ bool trust_gate_ok(const double* init, const double* se3) {
 extern "C" {
 
 const char* nidreg_last_error(void) { return g_last_error.c_str(); }
-const char* nidreg_version(void) { return "nidreg 0.4 (gfx950, hand-written HIP)"; }
+const char* nidreg_version(void) { return "nidreg 0.5 (gfx950, hand-written HIP)"; }
 
 int nidreg_model_from_name(const char* name, int* num_intrinsics, int* num_distortion) {
   if (!name) return -1;
