@@ -1314,10 +1314,19 @@ __device__ __forceinline__ void spline_grad_loop(
 }
 
 // the workgroup's 12 sums -> partials[k][my_block] ([12][nchunks]: coalesced for the final reduction), stored write-through
-// at agent scope.  s_red: (kT / 64) * 12 doubles of LDS.
+// at agent scope.
+// Round 5: through LDS, transposed.  Until round 4 every wave summed each of its 12 accumulators over its 64 lanes by DPP (twelve
+// wave_sums = 314 VALU instructions per thread) and 12 threads added the four waves' results -- the largest single item of the
+// per-workgroup overhead (8 instructions per point at 10M points, 30 % of a small evaluation's workgroup).  Now every thread
+// stores its 12 accumulators ([12][kT], conflict-free), 12 x 16 threads each add 16 of them (stride 16: conflict-free reads)
+// and finish inside their DPP row of 16 lanes (row_shr 1 / 2 / 4 / 8): ~60 instructions per thread, a fixed association like
+// before.  `scratch`: 12 * kT doubles of LDS that may alias the G tile (dead once every wave has left the point loop: hence the
+// barrier up front).  -DNID_GRAD_REDUCE_DPP restores the round-4 reduction (A/B).
+constexpr int kGradScratchDoubles = 12 * kThreads;
 template <int kT>
-__device__ __forceinline__ void grad_reduce_store(const double* acc, double* s_red, double* partials, unsigned int my_block, unsigned int my_blocks) {
+__device__ __forceinline__ void grad_reduce_store(const double* acc, double* s_red, double* scratch, double* partials, unsigned int my_block, unsigned int my_blocks) {
   const int tid = threadIdx.x;
+#ifdef NID_GRAD_REDUCE_DPP
 #pragma unroll
   for (int k = 0; k < 12; k++) {
     const double t = wave_sum(acc[k]);
@@ -1329,6 +1338,25 @@ __device__ __forceinline__ void grad_reduce_store(const double* acc, double* s_r
     for (int w = 0; w < kT / 64; w++) t += s_red[w * 12 + tid];
     __hip_atomic_store(&partials[size_t(tid) * my_blocks + my_block], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+#else
+  static_assert(kT == 256, "12 accumulators x 16 lanes = 192 threads of the workgroup's 256");
+  __syncthreads();  // every wave has left the point loop: the G tile under `scratch` is dead
+#pragma unroll
+  for (int k = 0; k < 12; k++) scratch[k * kT + tid] = acc[k];
+  __syncthreads();
+  if (tid < 12 * 16) {
+    const int k = tid >> 4, j = tid & 15;
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < kT / 16; i++) t += scratch[k * kT + i * 16 + j];
+    t += dpp_move<0x111, 0xf, true>(t);  // row_shr:1, 2, 4, 8: lane 15 of the row of 16 holds the row's sum
+    t += dpp_move<0x112, 0xf, true>(t);
+    t += dpp_move<0x114, 0xf, true>(t);
+    t += dpp_move<0x118, 0xf, true>(t);
+    if (j == 15) __hip_atomic_store(&partials[size_t(k) * my_blocks + my_block], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  (void)s_red;
+#endif
 }
 
 // what the gradient kernel needs to run the entropy tail itself (k_entropy launched with tail = 0)
@@ -1452,8 +1480,17 @@ __device__ __forceinline__ void build_gtile(const u64* __restrict__ hist, uint32
 constexpr int grad_min_waves(int model, bool seg = false, bool rec32 = false) { return model == MODEL_ATAN ? 3 : ((seg && rec32) ? 4 : NID_GRAD_MIN_WAVES); }
 // LDS of the gradient kernel: G tile (one copy of one column when GW = 1, else 2^cshift copies of GW columns), reduction scratch,
 // phi(q_r), flag, the workgroup's own copy of cost / status / inlier count (s_fin); SEG (GW = 1 only): kMaxSegs - 1 staged G columns behind them
+// the region at the start of the gradient kernel's LDS: the G tile during the point loop, the reduction's scratch after it
+__host__ __device__ __forceinline__ size_t grad_tile_region_bytes(int B, int GW, int cshift) {
+  const size_t tile = GW == 1 ? size_t(B) * 8 : (size_t(GW) * size_t(B) * 8 << cshift);
+#ifdef NID_GRAD_REDUCE_DPP
+  return tile;
+#else
+  return tile > size_t(12 * 256 * 8) ? tile : size_t(12 * 256 * 8);
+#endif
+}
 __host__ __device__ __forceinline__ size_t spline_grad_lds_bytes(int B, int GW, int cshift, bool seg) {
-  return (GW == 1 ? size_t(B) * 8 : (size_t(GW) * size_t(B) * 8 << cshift)) + size_t(kWaves) * 12 * 8 + 256 * 8 + 16 + 32 + (seg && GW == 1 ? size_t(kMaxSegs - 1) * size_t(B) * 8 : 0);
+  return grad_tile_region_bytes(B, GW, cshift) + size_t(kWaves) * 12 * 8 + 256 * 8 + 16 + 32 + (seg && GW == 1 ? size_t(kMaxSegs - 1) * size_t(B) * 8 : 0);
 }
 template <int MODEL, typename Rec, typename real, bool GW1, bool MULTI, bool SEG>
 __global__ __launch_bounds__(kThreads, grad_min_waves(MODEL, SEG, sizeof(Rec) == sizeof(Rec32))) void k_spline_grad(
@@ -1464,9 +1501,8 @@ __global__ __launch_bounds__(kThreads, grad_min_waves(MODEL, SEG, sizeof(Rec) ==
   static_assert(!SEG || GW1, "a chunk runs across column groups only in the single-column kernels (the host builds one-segment tables otherwise)");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* gtile = reinterpret_cast<double*>(smem);
-  const int tile_n = GW * B;
   if (GW1) cshift = 0;
-  double* s_red = gtile + (tile_n << cshift);
+  double* s_red = reinterpret_cast<double*>(smem + grad_tile_region_bytes(B, GW, cshift));  // (cshift = 0 for GW1 above)
   double* s_phi = s_red + kWaves * 12;  // [256] phi(q_r) when this kernel runs the entropy tail itself
   int* s_flag = reinterpret_cast<int*>(s_phi + 256);
   // cost, status, inlier count as THIS workgroup's prologue computed them (the same integers everywhere: identical bits): the
@@ -1564,7 +1600,7 @@ __global__ __launch_bounds__(kThreads, grad_min_waves(MODEL, SEG, sizeof(Rec) ==
     spline_grad_loop<MODEL, Rec, real, GW1 ? TAP_SINGLE : TAP_COPIES, kThreads, !SEG>(pts + seg.pos, seg_end - seg.pos, seg.g * uint32_t(GW), seg.pos - ch.start, ch.count, img, pitch, W, H, pose,
                                                                                cam, B, cshift, gtile, acc, prio != 0, seg.pos);
     stamp_stage(3);
-    grad_reduce_store<kThreads>(acc, s_red, partials, slot, nslots);
+    grad_reduce_store<kThreads>(acc, s_red, gtile, partials, slot, nslots);
     stamp_stage(4);
     if (!SEG || !seg.advance(seg_end)) break;
     slot++;

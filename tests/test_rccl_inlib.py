@@ -87,3 +87,16 @@ def test_inlib_sharded_cost_python_world1():
         assert ok3 and c3 == c
     sh.close()
     plain.close()
+    # the derivative-free twin through the same route: histogram -> all-reduce -> entropy tail
+    import oracle_lib
+    from direct_visual_lidar_calibration_amd import se3
+
+    max_fov = oracle_lib.estimate_camera_fov(s.model, s.intrinsics, s.distortion, s.width, s.height)
+    T = se3.to_matrix(s.T_camera_lidar_init)
+    a = nid.CostCalculatorNID(proj, s.image_u8, s.points, s.intensities, nid.NIDCostParams(64), max_fov=max_fov)
+    b = nid.CostCalculatorNID(proj, s.image_u8, s.points, s.intensities, nid.NIDCostParams(64), max_fov=max_fov)
+    b.comm_init(1, 0, nid.NIDCost.rccl_unique_id())
+    assert b.calculate(T) == a.calculate(T)
+    assert np.array_equal(b.histogram_fixed()[0], a.histogram_fixed()[0])
+    a.close()
+    b.close()
