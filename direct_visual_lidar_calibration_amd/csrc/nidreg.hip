@@ -3267,6 +3267,8 @@ int nidreg_shard_comm_init(nidreg_handle* h, int world_size, int rank, const uns
   ncclComm_t comm = nullptr;
   RCCL_TRY(api->CommInitRank(&comm, world_size, id, rank));
   rccl_release(h);
+  cohort_leave(h);  // (NIDREG_COHORT=1: a handle that evaluates collectively is nobody's sibling on this GPU)
+  drop_groups_of(h);
   h->rccl_comm = comm;
   h->rccl_owned = true;
   return NIDREG_OK;
@@ -3284,6 +3286,8 @@ int nidreg_shard_attach_rccl(nidreg_handle* h, void* nccl_comm) {
   int count = 0;
   RCCL_TRY(api->CommCount(static_cast<ncclComm_t>(nccl_comm), &count));  // (also rejects a pointer that is not a communicator of this RCCL)
   rccl_release(h);
+  cohort_leave(h);
+  drop_groups_of(h);
   h->rccl_comm = nccl_comm;
   h->rccl_owned = false;
   return NIDREG_OK;
