@@ -149,9 +149,9 @@ typedef struct nidreg_desc {
   void* ext_out;            /* device buffer of NIDREG_OUT_DOUBLES doubles */
   /* one pair spread over several GPUs inside the library (single process): num_devices > 1 cuts the cloud along the
      pose-independent histogram column -- device_ids[k] owns a contiguous range of column groups, balanced by their point
-     counts, and holds the points that fall into them -- so the GPUs' joint histograms have disjoint support and an
-     evaluation exchanges only inlier counts, entropy partials, row sums and column sums (2 + bins + bins/n words per GPU)
-     directly between the GPUs.  Cost and histograms are bit-identical to the unsharded handle's, the gradient differs by
+     counts, and holds the points that fall into them -- so the GPUs' joint histograms have disjoint support: every GPU keeps
+     a replica of the whole integer histogram and stores its own columns into every other GPU's replica, directly between the
+     GPUs, once per evaluation (plain stores: no two GPUs write the same word).  Cost and histograms are bit-identical to the unsharded handle's, the gradient differs by
      summation order only.  The same device may be listed several times (a 1-GPU box exercising the protocol).
      0 = device_id alone, unless the environment variable NIDREG_DEVICES="0,1,..." is set -- which shards every handle
      (nidreg_create and nidreg_create_from_cloud), so a caller that knows nothing about GPUs (the reference's

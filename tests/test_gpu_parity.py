@@ -815,7 +815,7 @@ def test_in_library_sharding_matches_plain_handle(nshards):
         ok1, c1, g1 = sh(poses[1])
         parity.check_cost(c1, ref["cost"])
         parity.check_grad(g1, ref["grad"])
-        # nothing projects: every shard announces zero inliers, the functor returns false like the reference's 0 / 0
+        # nothing projects: every shard reports zero inliers, the functor returns false like the reference's 0 / 0
         far = np.array(poses[1], dtype=np.float64).copy()
         far[4:7] += 1.0e4
         okf, cf, gf = sh(far)

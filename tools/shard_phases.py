@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where a sharded evaluation's time goes on ONE GPU (one-GPU protocol measurement): event times of the leader shard's phases
-(histogram + announce, owned entropy [+ gathered tail], gradient) for a 4096-point cloud, plain handle against n co-located
+(histogram, k_entropy_repl = push / wait / entropy, gradient) for a 4096-point cloud, plain handle against n co-located
 shards driven by their worker threads.  Usage: shard_phases.py [bins] [shards,shards,...]"""
 import json
 import os
