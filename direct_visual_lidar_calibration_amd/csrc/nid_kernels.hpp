@@ -633,8 +633,11 @@ struct NearestFast {
 __host__ __device__ __forceinline__ size_t nearest_hist_lds_bytes(int B, int GW, int cshift) { return (((size_t(GW) * size_t(B) * 4 << cshift) + 7) & ~size_t(7)) + size_t(GW) * 8 + 16; }
 // five waves per SIMD for the plumb_bob fast-tier instantiation (96 VGPRs, nothing spilled; 104-106 without the bound)
 // (round 5: fisheye lands at 132 and equirectangular at 173 by themselves -- asked for four and three waves)
+#ifndef NID_NEAREST_EQUIRECT_WAVES
+#define NID_NEAREST_EQUIRECT_WAVES 3
+#endif
 constexpr int nearest_min_waves(int model, bool is_double, bool rec32, bool seg) {
-  return (is_double && rec32 && !seg) ? (model == MODEL_PLUMB_BOB ? 5 : (model == MODEL_FISHEYE ? 4 : (model == MODEL_EQUIRECT ? 3 : 1))) : 1;
+  return (is_double && rec32 && !seg) ? (model == MODEL_PLUMB_BOB ? 5 : (model == MODEL_FISHEYE ? 4 : (model == MODEL_EQUIRECT ? NID_NEAREST_EQUIRECT_WAVES : 1))) : 1;
 }
 template <int MODEL, typename Rec, typename real, bool MULTI, bool SEG>
 __global__ __launch_bounds__(kThreads, nearest_min_waves(MODEL, std::is_same<real, double>::value, sizeof(Rec) == sizeof(Rec32), SEG)) void k_nearest_hist(
@@ -1366,7 +1369,7 @@ struct GradTail {
   double* hist_points;
   EntropyScalars* scal;
   int from_partials;         // 1: run the tail on the row sums / Hj k_entropy left behind the histogram; 0: read scal / phi_q
-                             // as k_entropy's own tail (or k_entropy_gather) wrote them; 2: no k_entropy ran at all -- the
+                             // as k_entropy's own tail wrote them; 2: no k_entropy ran at all -- the
                              // workgroup sums the B x B cells itself (small tables only, grad_entropy_partials)
   u64* zero_buf;             // from_partials == 2: the histogram buffer of the NEXT evaluation, cleared here (k_entropy's other duty)
   long long zero_words;
