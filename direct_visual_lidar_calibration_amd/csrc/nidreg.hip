@@ -966,7 +966,17 @@ int64_t round_chunks(int per_cu, int num_cus, int64_t points) {
     return e && *e && *e != '0';
   }();
   if (always_full) return full;
-  const double t = 0.5 * double(num_cus) * std::sqrt(double(std::max<int64_t>(points, 1)) / 1.0e5);
+  double t = 0.5 * double(num_cus) * std::sqrt(double(std::max<int64_t>(points, 1)) / 1.0e5);
+  // Round 5: from 0.6 CUs on, whole multiples of the CU count (the nearest one on a logarithmic scale).  With the per-workgroup
+  // overhead of this round's kernels (fast_log, the reduction through LDS) a count between two multiples -- 569 chunks on 256 CUs
+  // -- leaves some CUs a workgroup more than the others and loses 3-8 % against the multiple next to it: 500k points 280 -> 256
+  // chunks 35.5 -> 32.7 us, 2M 569 -> 512 57.3 -> 53.6, 3M 700 -> 768 70.9 -> 67.1, 4M 802 -> 768 80.3 -> 77.1
+  // (profiles/r05z_small_cloud_sweep_b16.jsonl; 256-bin tables were multiples of their 256 column groups already).
+  if (t >= 0.6 * double(num_cus)) {
+    int k = 1;
+    while (t > double(num_cus) * std::sqrt(double(k) * double(k + 1))) k++;
+    t = double(k) * double(num_cus);
+  }
   return std::max<int64_t>(1, std::min<int64_t>(full, int64_t(t + 0.5)));
 }
 // ... for a handle's own tables, in whole multiples of its non-empty column groups where it has several: a target between

@@ -274,7 +274,7 @@ def test_small_clouds_get_fewer_chunks_than_a_full_round():
         return lib.nidreg_debug_round_chunks(per_cu, cus, g.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), len(counts))
 
     one = [chunks([n]) for n in (1, 30_000, 100_000, 300_000, 1_000_000, 3_000_000, 6_400_000, 10_000_000, 50_000_000)]
-    assert one == [1, 70, 128, 222, 405, 701, 1024, 1024, 1024]
+    assert one == [1, 70, 128, 256, 512, 768, 1024, 1024, 1024]  # (from 0.6 CUs on: whole multiples of the CU count, round 5)
     assert chunks([10_000_000], per_cu=2) == 512 and chunks([10_000_000], per_cu=3) == 768  # the WIDE histogram kernel / the fisheye gradient kernel
     for bins_groups in (16, 64, 256):  # B = 64 / 128 / 256
         for n in (30_000, 100_000, 1_000_000, 3_000_000, 10_000_000):
@@ -289,9 +289,10 @@ def test_small_clouds_get_fewer_chunks_than_a_full_round():
 
 
 def test_chunk_rule_lands_near_the_best_measured_count():
-    """The rule against the sweep it was drawn through (profiles/archive/r04i_small_cloud_sweep.jsonl: microseconds per synchronous
-    cost+Jacobian evaluation on an MI355X with the number of chunks forced, 30k ... 3M points, 16 / 64 / 256 bins): at the rule's
-    count the measured time -- interpolated between the two nearest measured counts -- is within 8 % of the best measured one."""
+    """The rule against the sweep it was drawn through (profiles/r05z_small_cloud_sweep_b16.jsonl: microseconds per synchronous
+    cost+Jacobian evaluation on an MI355X with the number of chunks forced, 100k ... 6.4M points, 16 bins, this round's kernels;
+    round 4's sweep of the earlier kernels: profiles/archive/r04i_small_cloud_sweep.jsonl): at the rule's count the measured time
+    -- interpolated between the two nearest measured counts -- is within 5 % of the best measured one."""
     import ctypes
     import json
     import os
@@ -300,9 +301,9 @@ def test_chunk_rule_lands_near_the_best_measured_count():
 
     lib = _lib.load()
     lib.nidreg_debug_round_chunks.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.c_int]
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "archive", "r04i_small_cloud_sweep.jsonl")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05z_small_cloud_sweep_b16.jsonl")
     rows = [json.loads(line) for line in open(path)]
-    assert len(rows) == 15
+    assert len(rows) == 11
     worst = 0.0
     for r in rows:
         n, bins = r["points"], r["bins"]
@@ -314,7 +315,7 @@ def test_chunk_rule_lands_near_the_best_measured_count():
         at_rule = float(np.interp(chosen, xs, ys))
         best = float(ys.min())
         worst = max(worst, at_rule / best)
-        assert at_rule <= 1.08 * best, (n, bins, chosen, at_rule, best)
+        assert at_rule <= 1.05 * best, (n, bins, chosen, at_rule, best)
     assert worst > 1.0  # (the table is real data: the rule is not the argmin of every row)
 
 
