@@ -51,6 +51,48 @@ class _Multi:
         return self.m(x, want_grad)
 
 
+def calibrate_pairs(proj, pairs, init_x, params, precision="fp64", stats=None):
+    """The in-memory body of the command: ``pairs`` = [(image_u8 (H, W), points (N, 4), intensities (N,)), ...] as
+    ``VisualLiDARData`` holds them, ``init_x`` the Sophus-order ``T_camera_lidar`` 7-vector.  One upload per pair; every outer
+    iteration culls + rebuilds its cost object on the device (visual_camera_calibration.cpp:76-85 / :201-206); every cost
+    evaluation runs on the GPU.  Returns ``(x, VisualCameraCalibration)``; ``stats`` (optional dict) receives the wall-clock
+    split: ``upload_s`` (clouds to HBM), ``build_s`` (culling + record build of every outer iteration), ``evaluations``."""
+    ndev = _lib.load().nidreg_device_count()
+    if ndev <= 0:
+        raise SystemExit("error: no MI355X / HIP device visible (the NID core has no CPU fallback)")
+    t0 = time.perf_counter()
+    clouds = [nid.Cloud(p[1], p[2], device=k % ndev) for k, p in enumerate(pairs)]
+    images_f64 = [p[0].astype(np.float64) * (1.0 / 255.0) for p in pairs]  # convertTo(CV_64FC1, 1/255), :204
+    upload_s = time.perf_counter() - t0
+    size = (pairs[0][0].shape[1], pairs[0][0].shape[0])
+    max_fov = nid.estimate_camera_fov(proj, size)
+    min_z = math.cos(max_fov)
+    depth = not params.disable_z_buffer_culling
+    build_s = [0.0]
+
+    def fused_nid(k, T, bins):
+        t1 = time.perf_counter()
+        c = nid.NIDCost.from_cloud(proj, images_f64[k], clouds[k], bins, cull=(T, min_z, depth), precision=precision)
+        build_s[0] += time.perf_counter() - t1
+        return c
+
+    def fused_nearest(k, T, bins):
+        t1 = time.perf_counter()
+        c = nid.CostCalculatorNID.from_cloud(proj, pairs[k][0], clouds[k], nid.NIDCostParams(bins), max_fov=max_fov, cull=(T, min_z, depth), precision=precision)
+        build_s[0] += time.perf_counter() - t1
+        return c
+
+    cal = calibration.VisualCameraCalibration(
+        [(p[0], None, None) for p in pairs], params, fused_nid_factory=fused_nid, fused_nearest_factory=fused_nearest, multi_factory=lambda init, costs: _Multi(init, costs))
+    x = cal.calibrate(init_x)
+    for c in clouds:
+        c.close()
+    if stats is not None:
+        stats.update(devices=min(ndev, len(pairs)), upload_s=upload_s, build_s=build_s[0], evaluations=int(sum(e.get("evaluations", 0) for e in cal.log)),
+                     outer_iterations=len(cal.log))
+    return x, cal
+
+
 def run(args, log=print):
     config, bags = dataset.load_dataset(args.data_path, args.first_n_bags)
     if args.first_n_bags is not None:
@@ -76,30 +118,11 @@ def run(args, log=print):
     if args.dry_run:
         return config, init_x, None
 
-    ndev = _lib.load().nidreg_device_count()
-    if ndev <= 0:
-        raise SystemExit("error: no MI355X / HIP device visible (the NID core has no CPU fallback)")
-    # one upload per pair; every outer iteration culls + rebuilds its cost object on the device
-    clouds = [nid.Cloud(b.points, b.intensities, device=k % ndev) for k, b in enumerate(bags)]
-    images_f64 = [b.image.astype(np.float64) * (1.0 / 255.0) for b in bags]  # convertTo(CV_64FC1, 1/255), :204
-    size = (bags[0].image.shape[1], bags[0].image.shape[0])
-    max_fov = nid.estimate_camera_fov(proj, size)
-    min_z = math.cos(max_fov)
-    depth = not args.disable_culling
-
-    def fused_nid(k, T, bins):
-        return nid.NIDCost.from_cloud(proj, images_f64[k], clouds[k], bins, cull=(T, min_z, depth), precision=args.precision)
-
-    def fused_nearest(k, T, bins):
-        return nid.CostCalculatorNID.from_cloud(proj, bags[k].image, clouds[k], nid.NIDCostParams(bins), max_fov=max_fov, cull=(T, min_z, depth), precision=args.precision)
-
-    cal = calibration.VisualCameraCalibration(
-        [(b.image, None, None) for b in bags], params, fused_nid_factory=fused_nid, fused_nearest_factory=fused_nearest, multi_factory=lambda init, costs: _Multi(init, costs))
+    stats = {}
     t0 = time.time()
-    x = cal.calibrate(init_x)
+    x, cal = calibrate_pairs(proj, [(b.image, b.points, b.intensities) for b in bags], init_x, params, precision=args.precision, stats=stats)
     elapsed = time.time() - t0
-    for c in clouds:
-        c.close()
+    ndev = stats["devices"]
     for entry in cal.log:
         log(f"outer {entry['outer']}: {entry['inner']} cost {entry.get('initial_cost', float('nan')):.6f} -> {entry['final_cost']:.6f}, "
             f"delta {entry['delta_t']:.5f} m / {entry['delta_r'] * 180.0 / math.pi:.4f} deg, {entry.get('evaluations', 0)} evaluations")
@@ -109,7 +132,7 @@ def run(args, log=print):
     dataset.write_calib(args.data_path, config)
     log("--- T_lidar_camera ---")
     log(str(np.linalg.inv(se3.to_matrix(x))))
-    log(f"saved to {args.data_path}/calib.json  ({elapsed:.2f} s on {min(ndev, len(bags))} GPU(s))")
+    log(f"saved to {args.data_path}/calib.json  ({elapsed:.2f} s on {ndev} GPU(s))")
     return config, init_x, x
 
 

@@ -66,3 +66,41 @@ def test_one_gpu_bench_stdout_is_exactly_one_json_line():
     d = json.loads(r.stdout)
     rc = d["other_entry_points"]["inlib_rccl_world1"]
     assert "error" not in rc and rc["cost_equals_plain_handle"] and rc["evals_per_s"] > 0
+
+
+@pytest.mark.gpu
+def test_watchdog_prints_the_headline_line_when_a_leg_hangs():
+    """A multi_gpu leg that never returns (a collective that hangs) must not cost the driver its JSON line: the watchdog prints the
+    headline with the leg marked and every rank leaves."""
+    r = subprocess.run(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--blocks", "3", "--points", "300000", "--extra-points-scale", "0.02", "--no-cpu-baseline"],
+        capture_output=True, text=True, env=_env(NIDREG_BENCH_ONE_GPU="1", NIDREG_BENCH_BACKEND="gloo", NIDREG_BENCH_TEST_HANG_LEG="shard_configs2", NIDREG_BENCH_LEG_WATCHDOG_S="20"), timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    mg = d["multi_gpu"]
+    assert "error" not in mg["pairs_configs3"] and mg["shard_configs2"]["error"].startswith("watchdog")
+
+
+@pytest.mark.gpu
+def test_one_gpu_bench_carries_shard_proxy_and_time_to_solution():
+    """The N = 1 line's strong-scaling inputs (one GPU's eighth of configs[1] / [2] / [4], the exchange cost of co-located shards, the
+    RCCL chain's floor, the projection that follows from them) and the end-to-end records (dT of GPU vs CPU `calibrate`), at reduced sizes."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--blocks", "3", "--points", "300000", "--extra-points-scale", "0.02", "--cpu-sample", "100000"],
+                       capture_output=True, text=True, env=_env(NIDREG_BENCH_FORCE_LEGS="1"), timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.stdout.count("\n") == 1 and r.stdout.startswith("{"), r.stdout[-2000:]
+    d = json.loads(r.stdout)
+    sp = d["shard_proxy"]
+    for key in ("c2", "c3", "c5"):
+        assert "error" not in sp[key] and sp[key]["ms"] > 0 and sp[key]["parts"] == 8, sp[key]
+        assert sp["projected_8gpu"][key]["no_exchange_bound"] > 0
+    assert "exchange_error" not in sp and sp["exchange_us_3_colocated"] > 0 and sp["rccl_world1_overhead_us"] > 0, sp
+    tt = d["time_to_solution"]
+    assert "error" not in tt, tt
+    for key in ("configs0", "configs1"):
+        dt, dr = tt[key]["dT"]
+        assert dt <= 1e-3 and dr <= 1e-3 and tt[key]["evals"] > 0 and tt[key]["cpu_wall_s"] > 0, tt[key]
+    assert d["timing"]["distinct_poses_in_window"] >= 12 and d["roofline"]["kernel_ms_source"].startswith("HIP events")

@@ -5,7 +5,7 @@ is negligible, the time per evaluation beyond the plain handle's is the protocol
 blocks into every replica, its one flag wait, the host-thread hand-off.
 Also the 10M-point case for the record (there the shards' kernels share the one GPU, so nothing is gained -- it only shows
 the protocol at full size).
-Usage: shard_cost.py [bins]"""
+Usage: shard_cost.py [bins] [--tiny-only]"""
 import json
 import os
 import sys
@@ -21,14 +21,15 @@ sys.path.insert(0, ROOT)
 from direct_visual_lidar_calibration_amd import nid, synth  # noqa: E402
 
 bins = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+tiny_only = "--tiny-only" in sys.argv  # bench.py's shard_proxy leg: the protocol cost alone, 2 and 3 shards
 out = {}
-for label, n_points in (("tiny", 4096), ("10M", 10_000_000)):
+for label, n_points in ((("tiny", 4096),) if tiny_only else (("tiny", 4096), ("10M", 10_000_000))):
     s = synth.make_scene("pinhole_1080p", num_points=n_points, seed=5, device="cuda:0")
     proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
     rng = np.random.default_rng(3)
     poses = np.ascontiguousarray([synth.random_pose_near(s.T_camera_lidar_true, rng) for _ in range(40)])
     row = {}
-    for n in (1, 2, 3, 4, 8):
+    for n in ((1, 2, 3) if tiny_only else (1, 2, 3, 4, 8)):
         c = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, bins, devices=None if n <= 1 else [0] * n)
         c.eval_batch(poses[:5])
         ts = []
