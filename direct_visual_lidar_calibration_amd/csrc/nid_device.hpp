@@ -263,10 +263,13 @@ NID_HD float fast_atan2(float y, float x) { return atan2f(y, x); }
 // m's sub-interval, -log(r_i) correctly rounded; 2 KB, read through the vector L1 like the atan table),
 //   log(x) = k ln 2 - log(r_i) + log1p(z),   z = m r_i - 1 (one fma: |z| <= 0.004),
 //   log1p(z) = z - z^2/2 + z^3/3 - z^4/4 + z^5/5 - z^6/6   (next term z^7/7 < 2.4e-18):
-// ~19 instructions, absolute error < 3e-16 on the host against a 60-digit reference over [1e-9, 4] (test_device_math), i.e.
-// 1e-5 of the cost's parity bar.  Every route of the entropy work calls this one function: the cost stays bit-identical across
-// routes.  x <= 0, inf, NaN (only reached when there is no inlier, where entropy_scalars overrides the result): some finite or
-// NaN value, never a trap.
+// ~19 instructions.  Accuracy (test_device_math, on the host against a 60-digit reference): RELATIVE error of about one ulp of
+// the result (<= 2.6e-16) over [1e-9, 4]; in absolute terms < 3e-16 only where |log x| <= 1 -- half an ulp of log(1e-9) = -20.7 is
+// already 1.8e-15, and the single-double ln 2 adds |k| x 2.3e-17.  What matters downstream is p log(p + 1e-6) with p <= 1, whose
+// absolute error stays below 4e-16: 1e-5 of the cost's parity bar.  Every route of the entropy work calls this one function: the
+// cost stays bit-identical across routes.  PRECONDITION: x positive and NORMAL (the callers add 1e-6 first); zero, subnormals,
+// negatives, inf, NaN (only reached when there is no inlier, where entropy_scalars overrides the result) make the exponent /
+// table split below meaningless: some finite or NaN value comes back, never a trap.
 #if defined(__HIP_DEVICE_COMPILE__)
 static __device__ const double g_log_tab[2 * kLogTableN] = {NID_LOG_TABLE_VALUES};
 #else
@@ -836,6 +839,7 @@ struct RawBatch<Rec32, N> {
   __device__ __forceinline__ void get(int k, real& x, real& y, real& z, uint32_t& bin) const {
     x = real(v[k].x), y = real(v[k].y), z = real(v[k].z), bin = __float_as_uint(v[k].w);
   }
+  __device__ __forceinline__ void store(int k, Rec32* dst) const { *reinterpret_cast<float4*>(dst) = v[k]; }  // the raw record, as loaded (nid_fused.hpp: into LDS)
 };
 template <int N>
 struct RawBatch<Rec64, N> {
@@ -847,6 +851,10 @@ struct RawBatch<Rec64, N> {
   template <typename real>
   __device__ __forceinline__ void get(int k, real& x, real& y, real& z, uint32_t& bin) const {
     x = real(a[k].x), y = real(a[k].y), z = real(b[k].x), bin = uint32_t(__double_as_longlong(b[k].y));
+  }
+  __device__ __forceinline__ void store(int k, Rec64* dst) const {
+    reinterpret_cast<double2*>(dst)[0] = a[k];
+    reinterpret_cast<double2*>(dst)[1] = b[k];
   }
 };
 

@@ -1380,18 +1380,29 @@ struct GradTail {
 // fixed-point cells: the order does not matter).  One launch and one kernel boundary less per evaluation.
 constexpr int kSelfEntropyCells = 1024;
 
+// A histogram word as the prologue of a gradient workgroup reads it.  COH = false: a plain load -- the words were written by an
+// EARLIER kernel, the kernel boundary made them visible.  COH = true (nid_fused.hpp: the same kernel's other workgroups wrote them
+// with device-scope atomics, a grid barrier lies in between): an agent-scope load, served at the coherence point -- no cache of this
+// CU / XCD is consulted, and none needs to be invalidated (an acquire fence would drop the XCD's whole L2, records and image included,
+// once per workgroup).
+template <bool COH>
+__device__ __forceinline__ u64 ld_hist(const u64* p) {
+  if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+
 // row sums (into s_rows[B], LDS) and the fixed-point sum of p log(p + eps) over ALL cells of a small table, by every thread of
 // the workgroup; s_redk: kT / 64 words.  The caller's next barrier publishes both.
-template <int kT>
+template <int kT, bool COH = false>
 __device__ __forceinline__ void grad_entropy_partials(const u64* __restrict__ hist, int B, double inv_unit, unsigned long long* s_rows, long long* s_redk) {
   const int tid = threadIdx.x;
   for (int r = tid; r < B; r += kT) s_rows[r] = 0;
   __syncthreads();
-  const double S = double(hist[size_t(B) * size_t(B) + kTailInliers]);
+  const double S = double(ld_hist<COH>(&hist[size_t(B) * size_t(B) + kTailInliers]));
   const double scale = inv_unit / S;  // the same two operations as k_entropy: identical terms
   long long acc = 0;
   for (int k = tid; k < B * B; k += kT) {
-    const u64 v = hist[k];
+    const u64 v = ld_hist<COH>(&hist[k]);
     if (v) {
       const double p = double(v) * scale;
       acc += ent_fixed(p * fast_log(p + 1e-6));
@@ -1406,17 +1417,18 @@ __device__ __forceinline__ void grad_entropy_partials(const u64* __restrict__ hi
 // left behind the histogram (integers: identical bits everywhere), NID, coefA / coefB, and phi(q_r) into s_phi.  `writer` (one
 // workgroup per pair) publishes hist_image / hist_points / phi_q / scal and -- at agent scope, read by grad_final_body in
 // another workgroup -- cost, status and inlier count.  s_redk: 3 * (kT / 64) words of LDS.
-template <int kT, bool SELF>
+template <int kT, bool SELF, bool COH = false>
 __device__ __forceinline__ EntropyScalars grad_scalars_from_partials(const u64* hist, int B, double inv_unit, const GradTail& gt, double* s_phi, long long* s_redk, bool writer, double* out) {
+  static_assert(!COH || SELF, "coherent loads are wired for the small-table path only (column sums below; the row sums come from LDS there)");
   const int tid = threadIdx.x;
-  const double S = double(hist[size_t(B) * size_t(B) + kTailInliers]);
+  const double S = double(ld_hist<COH>(&hist[size_t(B) * size_t(B) + kTailInliers]));
   const u64* col_sum = hist + size_t(B) * size_t(B) + kTailWords;
   const u64* row_sum = hist + hist_row_sums_at(B);
   long long hi_k = 0, hp_k = 0;
   long long hj_all = 0;
   if constexpr (SELF) {  // no k_entropy ran: row sums in LDS (behind phi: B <= 32), wave partials of Hj in s_redk[2 kT/64 ...]
     unsigned long long* s_rows = reinterpret_cast<unsigned long long*>(s_phi + 128);
-    grad_entropy_partials<kT>(hist, B, inv_unit, s_rows, s_redk + 2 * (kT / 64));
+    grad_entropy_partials<kT, COH>(hist, B, inv_unit, s_rows, s_redk + 2 * (kT / 64));
     __syncthreads();
     row_sum = reinterpret_cast<const u64*>(s_rows);
     for (int w = 0; w < kT / 64; w++) hj_all += s_redk[2 * (kT / 64) + w];
@@ -1430,7 +1442,7 @@ __device__ __forceinline__ EntropyScalars grad_scalars_from_partials(const u64* 
     hi_k += ent_fixed(qv * lq);
     const double ph = lq + qv / (qv + 1e-6);
     s_phi[r] = ph;
-    const double cnt = rint(double(col_sum[r]) * inv_unit);  // exact inlier count of column r
+    const double cnt = rint(double(ld_hist<COH>(&col_sum[r])) * inv_unit);  // exact inlier count of column r
     const double p = cnt / S;
     hp_k += ent_fixed(p * fast_log(p + 1e-6));
     if (writer) {
@@ -1464,6 +1476,7 @@ __device__ __forceinline__ EntropyScalars grad_scalars_from_partials(const u64* 
 // The G columns of column group g into the workgroup's LDS tile: G[c][r] = (coefA phi(h[c][r] / S) + coefB phi(q_r)) / 12 --
 // the 1/12 because the tap loop works with 6 b and 2 db/ds (bspline6 / bspline_deriv2) --, every cell in 2^cshift copies.
 // (dst: the tile, or a staging area of the same layout)
+template <bool COH = false>
 __device__ __forceinline__ void build_gtile(const u64* __restrict__ hist, uint32_t g, int B, int GW, int cshift, double scale, double coefA, double coefB, const double* phi_q, double* gtile) {
   const int tid = threadIdx.x;
   const uint32_t cmask = (1u << cshift) - 1u;
@@ -1472,7 +1485,7 @@ __device__ __forceinline__ void build_gtile(const u64* __restrict__ hist, uint32
   const int ncols = min(GW, B - int(g) * GW);
   const int n = ncols * B;
   for (int k = tid; k < n; k += kThreads) {
-    const double p = double(src[k]) * scale;
+    const double p = double(ld_hist<COH>(&src[k])) * scale;
     const double gval = (coefA * (fast_log(p + 1e-6) + p / (p + 1e-6)) + coefB * phi_q[k % B]) * (1.0 / 12.0);
     for (uint32_t j = 0; j <= cmask; j++) gtile[(uint32_t(k) << cshift) + ((j + uint32_t(k)) & cmask)] = gval;
   }

@@ -75,6 +75,20 @@ template <typename real> hipError_t launch_nearest_hist(const PassArgs& a);
 template <typename real> int occupancy_spline_hist(const PassArgs& a);
 template <typename real> int occupancy_spline_grad(const PassArgs& a);
 template <typename real> int occupancy_nearest_hist(const PassArgs& a);
+// ONE launch per cost+Jacobian evaluation (nid_fused.hpp; small tables, grids of co-resident workgroups): a.chunks / a.nchunks =
+// the fused table, a.hist = this evaluation's histogram buffer, a.gt_zero_buf the next one's
+struct FusedArgs {
+  unsigned long long* barrier;         // arrival counter of the grid barrier (device memory, counts over the handle's lifetime)
+  unsigned long long barrier_target;   // arrivals once every workgroup of THIS launch has arrived
+  unsigned long long* flags;           // one release word per workgroup, kFusedFlagStride (16) words apart
+  unsigned long long epoch;            // this launch's number: what the releasing workgroup stores into the flags
+  unsigned long long timeout_ticks;    // 100 MHz wall-clock ticks a workgroup waits at the barrier before it gives up
+  int cap;                             // points of LDS stash per workgroup (>= the longest chunk)
+  int full;                            // 1: (u, v) + projection context + patch + record per point, 0: (u, v) only
+};
+size_t fused_lds_bytes_for(const PassArgs& a, int full, int cap);
+hipError_t launch_spline_fused(const PassArgs& a, const FusedArgs& f);
+int occupancy_spline_fused(const PassArgs& a, const FusedArgs& f);  // workgroups of that instantiation per CU (0 on error)
 template <typename real> hipError_t launch_project(int model, const double* intr, const double* dist, const double* p3, long long n, double* uv, double* jac, hipStream_t stream);
 
 #ifdef NID_EXP_HANDOFF

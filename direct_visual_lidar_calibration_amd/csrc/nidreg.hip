@@ -26,7 +26,24 @@
 #include <vector>
 
 #include <dlfcn.h>
-#include <rccl/rccl.h>  // types and enums only: the library is opened at run time (nidreg_shard_attach_rccl), never linked
+// RCCL is an OPTIONAL, run-time dependency (dlopen in rccl_api below): the handful of types and enumerator values of its public C
+// ABI (rccl/rccl.h = NCCL 2.x: stable across releases) are declared here, so that libnidreg.so builds on a ROCm install without
+// the RCCL development headers.  Where the header is present the values are checked against it at compile time.
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+typedef int ncclRedOp_t;
+enum { ncclSuccess = 0, ncclSum = 0, ncclMax = 2, ncclInt64 = 4, ncclFloat64 = 8 };
+#if __has_include(<rccl/rccl.h>)
+#include <hip/hip_fp16.h>  // (what rccl.h includes itself: seen here first so that the namespace below holds RCCL's declarations only)
+#include <limits.h>
+namespace rccl_header_check {
+#include <rccl/rccl.h>
+static_assert(int(ncclSuccess) == 0 && int(ncclSum) == 0 && int(ncclMax) == 2 && int(ncclInt64) == 4 && int(ncclFloat64) == 8 && sizeof(ncclUniqueId) == 128,
+              "the RCCL ABI values declared above differ from this install's rccl/rccl.h");
+}  // namespace rccl_header_check
+#endif
 
 #include "../../include/nidreg.h"
 
@@ -156,6 +173,16 @@ struct nidreg_handle {
   int64_t hist_words = 0;
   std::vector<int64_t> gcount;  // record offsets of the column groups (host copy: multi-pair groups build their chunk tables from it)
   int num_cus = 256, per_cu_grad = 4, per_cu_hist = 2;
+
+  // one launch per cost+Jacobian evaluation (nid_fused.hpp): small tables, clouds whose chunks fit the LDS stash
+  int fused = 0;               // 0: not planned yet, 1: usable, -1: not applicable / switched off (a barrier that timed out)
+  int fused_cap = 0, fused_full = 0; // points of LDS stash per workgroup; 1: full stash format, 0: (u, v) only
+  int64_t longest_chunk = 0;         // records of the longest chunk of the gradient-pass table (0: unknown -> no fused route)
+  void* d_fused_scratch = nullptr;   // the grid barrier's arrival counter (256 B), then its per-workgroup release words (128 B each)
+  u64* d_fused_barrier = nullptr;
+  uint64_t fused_arrivals = 0;       // arrivals the counter holds once every launch so far has passed its barrier
+  uint64_t fused_launches = 0;       // fused launches so far (the barrier's epoch)
+  bool fused_last = false;           // the evaluation in flight (or last finished) ran on the fused route
 
   int timing = 0;  // 1: per-kernel events (three-kernel path), 2: events around whichever path runs
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -335,6 +362,7 @@ void free_handle(nidreg_handle* h) {
   if (h->d_pts) (void)hipFree(h->d_pts);
   if (h->d_chunks) (void)hipFree(h->d_chunks);
   if (h->d_chunks_hist) (void)hipFree(h->d_chunks_hist);
+  if (h->d_fused_scratch) (void)hipFree(h->d_fused_scratch);
   if (h->d_gend) (void)hipFree(h->d_gend);
   if (h->d_img) (void)hipFree(h->d_img);
   if (h->own_hist) {
@@ -542,8 +570,13 @@ NearestFastArgs nearest_fast_args(const nidreg_handle* h, const double* T) {
   } else if (h->model == NIDREG_MODEL_OMNIDIR) {
     const double xi = std::fabs(h->intr[4]);
     if (!(cos_fov + xi > 0.1) || !(h->intr[4] >= 0.0)) return f;
-    // |m| = sin(theta) / (cos(theta) + xi) grows with theta on [0, max_fov] while the denominator stays positive
-    const double mmax = std::sin(std::min(h->max_fov, pi)) / (cos_fov + xi) * 1.001 + 1e-6;
+    // |m| = sin(theta) / (cos(theta) + xi): d/dtheta = (1 + xi cos(theta)) / (cos(theta) + xi)^2.  For xi <= 1 it grows with theta
+    // on [0, max_fov] while the denominator stays positive; for xi > 1 it peaks at theta* = acos(-1 / xi) with the value
+    // 1 / sqrt(xi^2 - 1), and a cone that reaches past theta* has THAT as its supremum, not the value at its rim
+    const double fov_c = std::min(h->max_fov, pi);
+    const double m_rim = std::sin(fov_c) / (cos_fov + xi);
+    const double m_sup = (xi > 1.0 && fov_c > std::acos(-1.0 / xi)) ? 1.0 / std::sqrt(xi * xi - 1.0) : m_rim;
+    const double mmax = m_sup * 1.001 + 1e-6;
     double R, K;
     radtan_sup(mmax, 0.0, R, K);
     f.A = 2.0 * fmax * K * (1.0 + mmax * (1.0 + 1.74 * xi));
@@ -666,13 +699,104 @@ int eval_launch_rest(nidreg_handle* h, bool want_grad, bool alone = false) {
   return NIDREG_OK;
 }
 
+// ---- one launch per cost+Jacobian evaluation (nid_fused.hpp) -----------------------------------------------------------------
+// Planned at the handle's first eligible evaluation.  The fused kernel runs over the handle's OWN gradient-pass chunk table with
+// the thread <-> point mapping, per-point arithmetic and reductions of k_spline_grad, so the route changes nothing in the results:
+// cost AND gradient have the bits of the three-kernel route (which route runs depends on whether the evaluation has its device to
+// itself -- results must not).  Usable when every chunk lies inside one column group, the whole table is one round of
+// co-resident workgroups of the fused kernel, and the longest chunk fits the LDS stash (the full format where it does, (u, v)
+// only otherwise).  NIDREG_FUSED=0 switches the route off, NIDREG_FUSED_STASH=uv|full forces a format (A/B runs).
+void plan_fused(nidreg_handle* h) {
+  h->fused = -1;
+  const char* off = std::getenv("NIDREG_FUSED");
+  if (off && *off == '0') return;
+  if (h->mode != NIDREG_MODE_SPLINE || !grad_sums_table(h) || h->is_shard || h->set || !h->own_hist || h->cohort || h->nchunks <= 0 || h->seg || h->nslots != h->nchunks ||
+      h->longest_chunk <= 0)
+    return;
+  if (hipSetDevice(h->device) != hipSuccess) return;
+  int lds_max = 64 * 1024;
+  if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, h->device) != hipSuccess) return;
+  PassArgs a;
+  fill_pass_args(h, a);
+  const char* st = std::getenv("NIDREG_FUSED_STASH");
+  const int cap = int((uint32_t(h->longest_chunk) + 63u) & ~63u);
+  for (int f = 1; f >= 0; f--) {
+    if (st && ((f == 1 && st[0] == 'u') || (f == 0 && st[0] == 'f'))) continue;
+    if (fused_lds_bytes_for(a, f, cap) > size_t(lds_max)) continue;
+    const FusedArgs fa{nullptr, 0, nullptr, 0, 0, cap, f};
+    const int occ = occupancy_spline_fused(a, fa);
+    if (occ <= 0 || int64_t(occ) * h->num_cus < int64_t(h->nchunks)) continue;
+    const size_t sbytes = 256 + size_t(h->nchunks) * 128;  // the arrival counter, then one release word per workgroup in a line of its own
+    if (hipMalloc(&h->d_fused_scratch, sbytes) != hipSuccess) return;
+    if (hipMemset(h->d_fused_scratch, 0, sbytes) != hipSuccess) return;
+    if (hipDeviceSynchronize() != hipSuccess) return;  // (the null-stream memset against the handle's non-blocking stream)
+    h->d_fused_barrier = static_cast<u64*>(h->d_fused_scratch);
+    h->fused_launches = 0;
+    h->fused_cap = cap;
+    h->fused_full = f;
+    h->fused_arrivals = 0;
+    h->fused = 1;
+    return;
+  }
+}
+bool fused_planned(nidreg_handle* h) {
+  if (h->fused == 0) plan_fused(h);
+  return h->fused == 1;
+}
+bool fused_usable(nidreg_handle* h) {
+  if (h->fused == 0) plan_fused(h);
+  return h->fused == 1 && h->timing != 1 && !h->cohort && !h->rccl_comm && h->d_out_host != nullptr;
+}
+// after a barrier that timed out (nid_fused.hpp: two half-resident grids of different processes): the route is off for this
+// handle, its counters are cleared (workgroups that gave up never drew their tickets)
+void fused_give_up(nidreg_handle* h) {
+  h->fused = -1;
+  h->fused_last = false;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  (void)hipMemsetAsync(h->d_counters, 0, 8 * sizeof(unsigned int), h->stream);
+  h->hist_zeroed[0] = h->hist_zeroed[1] = false;  // (whatever the aborted kernel cleared or did not: memset before use)
+  (void)hipStreamSynchronize(h->stream);
+}
+int eval_launch_fused(nidreg_handle* h, const double* se3) {
+  HIP_TRY(hipSetDevice(h->device));
+  bump_seq(h);
+  if (h->timing) HIP_TRY(hipEventRecord(h->ev[0], h->stream));
+  for (int k = 0; k < 4; k++) h->last_q[k] = se3[k];
+  pose_from_se3(se3, h->last_R, h->last_t);
+  HIP_TRY(begin_histogram(h));
+  PassArgs a;
+  fill_pass_args(h, a);  // (after begin_histogram: a.hist = this evaluation's buffer; a.q = the pose's quaternion; a.tag = its sequence number)
+  std::memcpy(a.R, h->last_R, sizeof(a.R));
+  std::memcpy(a.t, h->last_t, sizeof(a.t));
+  a.gt_zero_buf = h->d_hist_buf[h->hist_cur ^ 1];
+  a.gt_zero_words = h->hist_words;
+  h->hist_zeroed[h->hist_cur ^ 1] = true;  // cleared by this launch for the next evaluation
+  h->zero_stream = h->stream;
+  h->fused_arrivals += uint64_t(h->nchunks);
+  h->fused_launches += 1;
+  const char* tmo = std::getenv("NIDREG_FUSED_TIMEOUT_US");  // (default 5 ms: far beyond any barrier wait of a co-resident grid)
+  const unsigned long long timeout_ticks = (unsigned long long)(100.0 * (tmo ? std::max(10.0, std::strtod(tmo, nullptr)) : 5000.0));
+  // test hook (tests/test_gpu_parity.py): a barrier target no launch can reach -- every workgroup times out, the kernel ends without
+  // its tag, eval_one falls back to the three kernels
+  const char* hang = std::getenv("NIDREG_FUSED_TEST_HANG");
+  const FusedArgs f{h->d_fused_barrier, h->fused_arrivals + ((hang && *hang == '1') ? 1u : 0u), h->d_fused_barrier + 32, h->fused_launches, timeout_ticks, h->fused_cap, h->fused_full};
+  HIP_TRY(launch_spline_fused(a, f));
+  if (h->timing) HIP_TRY(hipEventRecord(h->ev[5], h->stream));
+  h->ev_grad = true;
+  h->fused_last = true;
+  return NIDREG_OK;
+}
+
 int eval_launch(nidreg_handle* h, const double* se3, bool want_grad, bool alone = false) {
+  h->fused_last = false;
   const int rc = eval_launch_first(h, se3, alone);
   if (rc) return rc;
   return eval_launch_rest(h, want_grad, alone);
 }
 
 int eval_finish_block(nidreg_handle* h, hipStream_t stream, const double* block, uint64_t seq_bits, bool polled, double* cost, double* grad7);
+int eval_one(nidreg_handle* h, const double* se3, double* cost, double* grad7);
 // `stream` = the stream the evaluation's kernels were queued on (the handle's own, or a multi-pair group's)
 int eval_finish_on(nidreg_handle* h, hipStream_t stream, double* cost, double* grad7) { return eval_finish_block(h, stream, h->h_out, h->seq_bits, h->d_out_host != nullptr, cost, grad7); }
 int eval_finish(nidreg_handle* h, double* cost, double* grad7) { return eval_finish_on(h, h->stream, cost, grad7); }
@@ -730,6 +854,23 @@ int eval_finish_block(nidreg_handle* h, hipStream_t stream, const double* block,
   if (grad7)
     for (int k = 0; k < 7; k++) grad7[k] = block[1 + k];
   return block[8] != 0.0 ? NIDREG_FALSE : NIDREG_OK;
+}
+
+// one synchronous evaluation of a plain handle: the fused single launch when the evaluation is a cost+Jacobian one on a small
+// table, has its device to itself and fits on chip; the three-kernel route otherwise -- and again when the fused kernel's grid
+// barrier gave up (the kernel then ends without its completion tag: eval_finish_block reports the drained stream)
+int eval_one(nidreg_handle* h, const double* se3, double* cost, double* grad7) {
+  InflightGuard guard(h->device);
+  if (grad7 && guard.alone && h->async_outstanding == 0 && fused_usable(h)) {
+    int rc = eval_launch_fused(h, se3);
+    if (rc) return rc;
+    rc = eval_finish(h, cost, grad7);
+    if (rc >= 0) return rc;
+    fused_give_up(h);  // ... and fall through to the three kernels
+  }
+  const int rc = eval_launch(h, se3, grad7 != nullptr, guard.alone);
+  if (rc) return rc;
+  return eval_finish(h, cost, grad7);
 }
 
 int iso_launch(nidreg_handle* h, const double* T) {
@@ -1338,6 +1479,7 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
     };
     h->nslots = int(build_chunks(own_target(h->per_cu_grad), false, chunks));
     h->nchunks = int(chunks.size());
+    for (const Chunk& c : chunks) h->longest_chunk = std::max<int64_t>(h->longest_chunk, c.count);
     h->seg = h->nslots > h->nchunks ? 1 : 0;
     if (h->seg && GW == 1) h->lds_grad = spline_grad_lds_bytes(B, GW, cshift, true);
     h->chunks_cap = std::max<size_t>(chunks.size(), 1);
@@ -1582,6 +1724,7 @@ int cohort_reshape(nidreg_handle* h, int64_t total_points) {
   int rc = upload(grad_chunks, h->d_chunks, h->chunks_cap);
   if (rc) return rc;
   h->nchunks = int(grad_chunks.size());
+  h->fused = -1;  // (a cohort member's table is the cohort's: the fused single launch is for handles on their own)
   h->nslots = int(slots);
   h->seg = h->nslots > h->nchunks ? 1 : 0;
   h->lds_grad = spline_grad_lds_bytes(h->bins, h->GW, h->cshift, h->seg != 0);
@@ -2153,6 +2296,33 @@ void rccl_release(nidreg_handle* h) {
   h->rccl_owned = false;
 }
 
+// Every rank of the communicator must run the SAME fixed-point histogram: the all-reduce adds the ranks' int64 words as they are.
+// One collective at attach time -- max over the ranks of {v, -v} for the handle's table parameters -- and a refusal on every rank
+// alike when they differ (a rank created without desc.scale_points = the pair's total, or with other bins / mode, would
+// otherwise produce a silently wrong cost, identical on all ranks).
+int rccl_check_agreement(nidreg_handle* h, ncclComm_t comm, const char* who) {
+  RcclApi* api = rccl_api();
+  const int kN = 5;
+  long long v[2 * kN] = {h->frac_bits, h->bins, (long long)h->hist_words, h->mode, h->bins_user};
+  for (int k = 0; k < kN; k++) v[kN + k] = -v[k];
+  long long* d = nullptr;
+  HIP_TRY(hipMalloc(&d, sizeof(v)));
+  hipError_t e = hipMemcpyAsync(d, v, sizeof(v), hipMemcpyHostToDevice, h->stream);
+  ncclResult_t r = ncclSuccess;
+  if (e == hipSuccess) r = api->AllReduce(d, d, size_t(2 * kN), ncclInt64, ncclMax, comm, h->stream);
+  if (e == hipSuccess && r == ncclSuccess) e = hipMemcpyAsync(v, d, sizeof(v), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess && r == ncclSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(d);
+  if (r != ncclSuccess) return rccl_fail(who, r);
+  if (e != hipSuccess) return fail(NIDREG_ERR_HIP, std::string(who) + ": " + hipGetErrorString(e));
+  static const char* names[kN] = {"frac_bits (desc.scale_points must be the pair's TOTAL point count on every rank)", "bins", "hist_words", "mode", "bins (caller's count)"};
+  for (int k = 0; k < kN; k++)
+    if (v[k] != -v[kN + k])
+      return fail(NIDREG_ERR_INVALID, std::string(who) + ": the ranks of the communicator disagree on " + names[k] + ": max " + std::to_string(v[k]) + ", min " + std::to_string(-v[kN + k]) +
+                                        "; the handle stays detached");
+  return NIDREG_OK;
+}
+
 int rccl_attachable(const nidreg_handle* h, const char* who) {
   if (!h) return fail(NIDREG_ERR_INVALID, std::string(who) + ": null handle");
   if (h->set || h->is_shard) return fail(NIDREG_ERR_INVALID, std::string(who) + ": the handle is already sharded inside the library (desc.device_ids / NIDREG_DEVICES)");
@@ -2174,6 +2344,7 @@ int rccl_eval(nidreg_handle* h, int mode, const double* pose, double* cost, doub
   if (h->timing) HIP_TRY(hipEventRecord(h->ev[0], h->stream));
   if (h->num_points == 0) {  // a rank without points launches no histogram kernel: its (cleared) buffer still takes part in the sum
     HIP_TRY(begin_histogram(h));
+    if (h->timing == 1) HIP_TRY(hipEventRecord(h->ev[1], h->stream));  // (the marker launch_hist_* would have recorded: nidreg_get_timing reads it)
     if (mode == NIDREG_MODE_SPLINE) {
       for (int k = 0; k < 4; k++) h->last_q[k] = pose[k];
       pose_from_se3(pose, h->last_R, h->last_t);
@@ -2741,10 +2912,7 @@ int nidreg_eval(nidreg_handle* h, const double* se3, double* cost, double* grad7
     const int rc = cohort_eval(h, se3, grad7 != nullptr, cost, grad7);
     if (rc != kNotJoined) return rc;
   }
-  InflightGuard guard(h->device);
-  const int rc = eval_launch(h, se3, grad7 != nullptr, guard.alone);
-  if (rc) return rc;
-  return eval_finish(h, cost, grad7);
+  return eval_one(h, se3, cost, grad7);
 }
 
 // ---- asynchronous evaluations: nidreg_submit* queue the kernels of one evaluation and return, nidreg_wait collects.  The
@@ -2923,6 +3091,7 @@ int nidreg_eval_multi(nidreg_handle* const* handles, int n, const double* init_s
       }
     }
   }
+  if (n == 1 && !handles[0]->set && handles[0]->mode == NIDREG_MODE_SPLINE) return eval_one(handles[0], se3, cost, grad7);  // (the trust gate has passed above)
   // progress priority only for a pair that is alone on its device
   std::vector<std::unique_ptr<InflightGuard>> guards(static_cast<size_t>(n));
   std::vector<char> alone(static_cast<size_t>(n), 0);
@@ -3184,8 +3353,8 @@ int nidreg_estimate_camera_fov(int model_id, const double* intrinsics, const dou
         }
       }
     }
-    // (the loop leaves the rows sorted when it converges; after 1024 iterations without convergence the best row may not be first)
-    std::stable_sort(x.begin(), x.end(), [](const std::array<double, 3>& a, const std::array<double, 3>& b) { return a[0] < b[0]; });
+    // result.x = x[0] of the LAST SORT INSIDE the loop (nelder_mead.hpp:97-98): after 1024 iterations without convergence the
+    // reference does not sort again, and neither does this
     double d[3];
     to_dir(&x[0][1], d);
     const double n = std::sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
@@ -3276,6 +3445,11 @@ int nidreg_shard_comm_init(nidreg_handle* h, int world_size, int rank, const uns
   std::memcpy(&id, id128, sizeof(id));
   ncclComm_t comm = nullptr;
   RCCL_TRY(api->CommInitRank(&comm, world_size, id, rank));
+  rc = rccl_check_agreement(h, comm, "nidreg_shard_comm_init");
+  if (rc) {
+    if (api->CommDestroy) (void)api->CommDestroy(comm);
+    return rc;
+  }
   rccl_release(h);
   cohort_leave(h);  // (NIDREG_COHORT=1: a handle that evaluates collectively is nobody's sibling on this GPU)
   drop_groups_of(h);
@@ -3295,6 +3469,9 @@ int nidreg_shard_attach_rccl(nidreg_handle* h, void* nccl_comm) {
   if (!api->lib || !api->error.empty()) return fail(NIDREG_ERR_HIP, "nidreg_shard_attach_rccl: " + api->error);
   int count = 0;
   RCCL_TRY(api->CommCount(static_cast<ncclComm_t>(nccl_comm), &count));  // (also rejects a pointer that is not a communicator of this RCCL)
+  HIP_TRY(hipSetDevice(h->device));
+  rc = rccl_check_agreement(h, static_cast<ncclComm_t>(nccl_comm), "nidreg_shard_attach_rccl");
+  if (rc) return rc;
   rccl_release(h);
   cohort_leave(h);
   drop_groups_of(h);
@@ -3429,7 +3606,8 @@ int nidreg_get_info(nidreg_handle* h, int64_t* info8) {
   }
   const double ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
   const int nfast = h->mode == NIDREG_MODE_NEAREST ? nearest_fast_args(h, ident).on : 0;
-  info8[7] = (h->rec64 ? 0 : 1) | (h->seg ? 2 : 0) | (h->seg_hist ? 4 : 0) | (nfast ? 8 : 0) | (grad_sums_table(h) ? 16 : 0) | (int64_t(1 << h->cshift) << 8);
+  info8[7] = (h->rec64 ? 0 : 1) | (h->seg ? 2 : 0) | (h->seg_hist ? 4 : 0) | (nfast ? 8 : 0) | (grad_sums_table(h) ? 16 : 0) | (int64_t(1 << h->cshift) << 8) |
+             (fused_planned(h) ? (int64_t(32) | (int64_t(h->nchunks) << 16) | (int64_t(h->fused_full) << 28)) : 0);
   return NIDREG_OK;
 }
 

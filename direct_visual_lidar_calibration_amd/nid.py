@@ -263,7 +263,10 @@ class _Handle:
         _lib.check(self._lib.nidreg_get_info(self.h, v), "nidreg_get_info")
         keys = ["record_bytes", "num_chunks", "columns_per_group", "frac_bits", "lds_bytes", "image_pitch", "num_points", "float32_records"]
         out = dict(zip(keys, [int(x) for x in v]))
-        out["lds_copies"] = out["float32_records"] >> 8
+        out["lds_copies"] = (out["float32_records"] >> 8) & 0xFF
+        out["fused"] = (out["float32_records"] >> 5) & 1          # cost+Jacobian evaluations that have the device to themselves run as ONE launch (csrc/nid_fused.hpp)
+        out["fused_chunks"] = (out["float32_records"] >> 16) & 0xFFF
+        out["fused_full_stash"] = (out["float32_records"] >> 28) & 1
         out["segmented"] = (out["float32_records"] >> 1) & 1       # gradient-pass table: chunks run across column groups (looped kernels)
         out["segmented_hist"] = (out["float32_records"] >> 2) & 1  # the WIDE histogram kernel's table
         out["nearest_fast"] = (out["float32_records"] >> 3) & 1    # NEAREST: the fast decision tier is in use

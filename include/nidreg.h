@@ -120,10 +120,11 @@ typedef struct nidreg_desc {
   int32_t model_id;         /* NIDREG_MODEL_* */
   int32_t mode;             /* NIDREG_MODE_* */
   int32_t precision;        /* NIDREG_PREC_* */
-  int32_t bins;             /* nid_bins, 2..256.  The reference takes any int (src/calibrate.cpp:175, nid_cost.hpp:23), but its data path
-                               quantises both inputs to 256 levels (8-bit images, visual_camera_calibration.cpp:204; intensities equalised to
-                               floor(256 i / n) / 256, preprocess.cpp:464-473): more bins only add empty rows / columns.  Larger values are
-                               REFUSED with NIDREG_ERR_INVALID (tests/test_abi.py), never truncated. */
+  int32_t bins;             /* nid_bins, 2..NIDREG_MAX_BINS_WIDE (4096), see above: beyond NIDREG_MAX_BINS (256) the handle runs on the
+                               OCCUPIED bins (the reference's data path quantises both inputs to 256 levels: 8-bit images,
+                               visual_camera_calibration.cpp:204; intensities equalised to floor(256 i / n) / 256, preprocess.cpp:464-473);
+                               an input that occupies more than 256 bins on an axis, or bins outside the range, is REFUSED with
+                               NIDREG_ERR_INVALID (tests/test_abi.py), never truncated. */
   double intrinsics[5];     /* exactly the model's count is read */
   double distortion[8];     /* already zero-padded / truncated like create_camera.cpp:24-27 */
   int32_t width, height;    /* image cols, rows */
@@ -324,7 +325,14 @@ int nidreg_shard_finish(nidreg_handle* h, double* cost, double* grad7);
  *                             torch.distributed -- any way it likes)
  *   nidreg_shard_comm_init    every rank: ncclCommInitRank(world_size, id, rank) on the handle's device; the handle owns the
  *                             communicator and destroys it with itself
- *   nidreg_shard_attach_rccl  a communicator the caller owns (an ncclComm_t, passed as void*); NULL detaches */
+ *   nidreg_shard_attach_rccl  a communicator the caller owns (an ncclComm_t, passed as void*); NULL detaches
+ * Both run ONE collective themselves before they accept the communicator: the ranks' table parameters (fixed-point fraction bits --
+ * i.e. desc.scale_points --, bins, nidreg_hist_words, mode) are max-/min-reduced and every rank refuses alike
+ * (NIDREG_ERR_INVALID, the handle stays detached) when they differ; a rank created with another unit would otherwise add
+ * incompatible integers into a cost that is wrong yet identical on every rank.
+ * FAILURE SEMANTICS: an evaluation is a sequence of collectives.  A rank that returns early with a negative status (a launch error,
+ * a lost device) leaves its peers inside ncclAllReduce; the caller must then abort the communicator on the other ranks
+ * (ncclCommAbort) -- RCCL has no timeout of its own -- and rebuild it before evaluating again. */
 #define NIDREG_RCCL_ID_BYTES 128
 int nidreg_rccl_unique_id(unsigned char* id128);
 int nidreg_shard_comm_init(nidreg_handle* h, int world_size, int rank, const unsigned char* id128);
@@ -351,9 +359,12 @@ int nidreg_get_timing(nidreg_handle* h, float* ms6);
  * [2]=columns per group, [3]=fixed-point fraction bits, [4]=LDS bytes per workgroup,
  * [5]=padded image pitch, [6]=points stored, [7]=bit0: float32 records, bit1: the gradient-pass chunk table has chunks that run
  * across column groups (the looped kernel instantiations, csrc/nid_kernels.hpp Segments), bit2: so has the WIDE histogram
- * kernel's table, bit3: NEAREST handle whose evaluations use the fast decision tier (plumb_bob, fp64, FoV cone below ~84 degrees;
+ * kernel's table, bit3: NEAREST handle whose evaluations use the fast decision tier (plumb_bob with a FoV cone below ~84 degrees,
+ * fisheye, omnidir with xi >= 0, equirectangular; the other models and degenerate cones run the exact tier only;
  * csrc/nid_kernels.hpp NearestFast), bit4: cost+Jacobian evaluations launch no entropy kernel (bins <= 32: the gradient workgroups
- * sum the table themselves, csrc/nid_kernels.hpp kSelfEntropyCells), bits 8..: LDS copies per histogram cell */
+ * sum the table themselves, csrc/nid_kernels.hpp kSelfEntropyCells), bit5: a synchronous cost+Jacobian evaluation that has its device to
+ * itself runs as ONE launch (csrc/nid_fused.hpp: bins <= 32 and a cloud whose chunks fit the LDS stash), bits 8..15: LDS copies per
+ * histogram cell, bits 16..27: workgroups of that launch, bit 28: its stash holds the projection context too (not only u, v) */
 int nidreg_get_info(nidreg_handle* h, int64_t* info8);
 
 const char* nidreg_last_error(void);

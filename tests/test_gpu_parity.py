@@ -1595,3 +1595,106 @@ def test_cohort_gives_concurrent_callers_one_round_of_workgroups(monkeypatch):
     assert ok and c == sum(r[1] for r in ref[1]) and np.allclose(g, sum(r[2] for r in ref[1]), rtol=1e-11, atol=1e-14)
     for m in members + solo:
         m.close()
+
+
+@pytest.mark.parametrize("model", list(CAMERAS))
+def test_fused_single_launch_has_the_bits_of_the_three_kernel_route(model, monkeypatch):
+    """Small tables (bins <= 32), a cloud that fits on chip, an evaluation that has the device to itself: ONE launch (csrc/nid_fused.hpp:
+    pass A stashes what it knows about its points in LDS, grid barrier, entropy tail, pass B from the stash).  It runs over the handle's
+    own chunk table with k_spline_grad's thread <-> point mapping and reductions, so cost AND gradient are the same bits as the
+    three-kernel route's (NIDREG_FUSED=0) -- for both stash formats, with outliers, when cost-only evaluations alternate with it on the
+    double-buffered histogram -- and both match the oracle."""
+    s = scene_for(model, n=40_000, seed=31)
+    proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
+    rng = np.random.default_rng(5)
+    far = se3.plus(s.T_camera_lidar_true, np.array([0.4, -0.3, 0.2, 0.08, -0.05, 0.1]))  # a third of the cloud leaves the image
+    poses = [s.T_camera_lidar_init, far] + [synth.random_pose_near(s.T_camera_lidar_true, rng) for _ in range(4)]
+    for bins, tuning in ((16, {}), (2, {}), (7, {}), (32, {}), (16, {"target_blocks": 3}), (16, {"columns_per_group": 4})):
+        monkeypatch.setenv("NIDREG_FUSED", "0")
+        plain = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, bins, **tuning)
+        ref = [plain(x) for x in poses]
+        assert plain.info()["fused"] == 0
+        monkeypatch.delenv("NIDREG_FUSED")
+        for stash in ("full", "uv"):
+            monkeypatch.setenv("NIDREG_FUSED_STASH", stash)
+            fused = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, bins, **tuning)
+            got = []
+            for j, x in enumerate(poses):
+                if j % 2:
+                    okc, cc, _ = fused(x, want_grad=False)  # (three kernels: k_entropy with its tail) between two fused launches
+                    assert okc == ref[j][0] and cc == ref[j][1]
+                got.append(fused(x))
+            info = fused.info()
+            if tuning.get("target_blocks") == 3:  # 13 333 points per chunk: beyond either stash format -- three kernels, as before
+                assert info["fused"] == 0, info
+            else:
+                assert info["fused"] == 1 and info["fused_full_stash"] == (1 if stash == "full" else 0) and info["fused_chunks"] == info["num_chunks"], (bins, tuning, stash, info)
+            for j, (a, b) in enumerate(zip(got, ref)):
+                assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2]), (model, bins, tuning, stash, j, a, b)
+            for a, b in zip(fused.histograms(), plain.histograms()):
+                assert np.array_equal(a, b)
+            fused.close()
+        monkeypatch.delenv("NIDREG_FUSED_STASH")
+        o = oracle_nid(s, bins, poses[1])
+        parity.check_cost(ref[1][1], o["cost"])
+        parity.check_grad(ref[1][2], o["grad"])
+        plain.close()
+
+
+def test_fused_single_launch_other_shapes_and_its_fallback(monkeypatch):
+    """(a) records that do not round-trip through float (Rec64 stash); (b) a cloud whose chunks only fit the (u, v) stash with two
+    workgroups per CU; (c) a cloud beyond the stash: three kernels as before; (d) a grid barrier that times out (test hook): the
+    kernel ends without its tag, the evaluation is repeated on the three-kernel route -- same results -- and the handle stops using the
+    fused route; (e) eight evaluations through submit / wait (never fused) give the synchronous (fused) route's bits."""
+    proj_of = lambda sc: nid.create_camera(sc.model, sc.intrinsics, sc.distortion)
+    rng = np.random.default_rng(6)
+
+    def both(sc, pts, bins, expect_fused, expect_full=None):
+        poses = [sc.T_camera_lidar_init] + [synth.random_pose_near(sc.T_camera_lidar_true, rng) for _ in range(3)]
+        monkeypatch.setenv("NIDREG_FUSED", "0")
+        plain = nid.NIDCost(proj_of(sc), sc.image_f64, pts, sc.intensities, bins)
+        ref = [plain(x) for x in poses]
+        monkeypatch.delenv("NIDREG_FUSED")
+        fused = nid.NIDCost(proj_of(sc), sc.image_f64, pts, sc.intensities, bins)
+        got = [fused(x) for x in poses]
+        info = fused.info()
+        assert info["fused"] == expect_fused, info
+        if expect_full is not None:
+            assert info["fused_full_stash"] == expect_full, info
+        for a, b in zip(got, ref):
+            assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2])
+        oks, cs, gs = fused.eval_batch(np.ascontiguousarray(poses), pipelined=True)
+        assert oks and [float(v) for v in cs] == [r[1] for r in ref] and np.array_equal(gs, np.array([r[2] for r in ref]))
+        plain.close()
+        return fused, poses, ref
+
+    s = scene_for("plumb_bob", n=50_000, seed=32)
+    pts64 = s.points.copy()
+    pts64[:, :3] += 1e-9 * rng.standard_normal((pts64.shape[0], 3))  # not float32-representable: Rec64 records
+    f, _, _ = both(s, pts64, 16, 1)
+    assert f.info()["float32_records"] == 0
+    f.close()
+    big = synth.make_scene(CAMERAS["plumb_bob"], num_points=700_000, seed=33)
+    f, _, _ = both(big, big.points, 16, 1, expect_full=0)
+    f.close()
+    huge = synth.make_scene(CAMERAS["plumb_bob"], num_points=3_000_000, seed=34)
+    f, _, _ = both(huge, huge.points, 16, 0)
+    f.close()
+    f, _, _ = both(s, s.points, 64, 0)  # 64 bins: not a small table
+    f.close()
+    # (d) the barrier gives up
+    monkeypatch.setenv("NIDREG_FUSED_TIMEOUT_US", "300")
+    h = nid.NIDCost(proj_of(s), s.image_f64, s.points, s.intensities, 16)
+    x = s.T_camera_lidar_init
+    ok0, c0, g0 = h(x)
+    assert h.info()["fused"] == 1
+    monkeypatch.setenv("NIDREG_FUSED_TEST_HANG", "1")
+    ok1, c1, g1 = h(x)
+    monkeypatch.delenv("NIDREG_FUSED_TEST_HANG")
+    assert ok1 == ok0 and c1 == c0 and np.array_equal(g1, g0)
+    assert h.info()["fused"] == 0
+    ok2, c2, g2 = h(synth.random_pose_near(s.T_camera_lidar_true, rng))
+    assert ok2 and np.isfinite(c2)
+    ok3, c3, g3 = h(x)
+    assert c3 == c0 and np.array_equal(g3, g0)
+    h.close()

@@ -56,6 +56,7 @@ for n in points_list:
                 ts.append((time.perf_counter() - t0) / len(poses))
             row["us_per_eval"][str(tb)] = round(1e6 * float(np.median(ts)), 2)
             row["chunks"][str(tb)] = c.info()["num_chunks"]
+            row.setdefault("fused", {})[str(tb)] = [c.info()["fused"], c.info()["fused_full_stash"]]  # one launch per evaluation (nid_fused.hpp), stash format
             if tb == 0:
                 row["segmented"] = [c.info()["segmented"], c.info()["segmented_hist"]]
                 c.set_timing(True)
