@@ -126,6 +126,7 @@ __global__ __launch_bounds__(kThreads) void k_spline_fused(
   const real fW = real(W), fH = real(H);
 
   // ------------------------------------------------------------------ phase A (spline_hist_body, generic tiling, one segment)
+  stamp_stage(0);  // (-DNID_STAMP builds, tools/fused_stage_times.py: 0 entry, 1 points done, 2 flush issued, 3 barrier passed, 4 G tile built, 5 taps done, 6 ticket drawn, 7 results written)
   for (int k = tid; k < tile_w; k += kT) tile[k] = 0;
   if (tid < 64) s_cols[tid] = 0;  // (s_cols and s_rows, for phase P)
   __syncthreads();
@@ -212,6 +213,7 @@ __global__ __launch_bounds__(kThreads) void k_spline_fused(
       }
     }
     __syncthreads();
+    stamp_stage(1);
     // flush: contiguous in the [bin_points][bin_image] device layout
     u64* dst = hist + size_t(ch.group) * size_t(tile_n);
     for (int k = tid; k < tile_n; k += kT) {
@@ -226,9 +228,11 @@ __global__ __launch_bounds__(kThreads) void k_spline_fused(
   if (gt.zero_buf)
     for (long long k = (long long)blockIdx.x * kT + tid; k < gt.zero_words; k += (long long)gridDim.x * kT) gt.zero_buf[k] = 0;
 
+  stamp_stage(2);
   // ------------------------------------------------------------------ grid barrier: the histogram is complete
   if (!fused_grid_barrier(barrier, barrier_target, barrier_flags, barrier_epoch, timeout_ticks, s_flag)) return;  // no tag: the host falls back (see the header)
 
+  stamp_stage(3);
   // ------------------------------------------------------------------ phase P: entropy tail + G tile from ONE round of loads
   // The integers and the floating-point expressions are those of grad_scalars_from_partials<SELF> / build_gtile (nid_kernels.hpp), so
   // the cost, the marginals and the G values have the bits of the three-kernel route; what differs is where the integers come from:
@@ -329,12 +333,15 @@ __global__ __launch_bounds__(kThreads) void k_spline_fused(
   }
   __syncthreads();
 
+  stamp_stage(4);
   // ------------------------------------------------------------------ phase B (spline_grad_loop's point body, fed from the stash)
   double acc[12];
 #pragma unroll
   for (int k = 0; k < 12; k++) acc[k] = 0.0;
   {
     const char* rec_base = reinterpret_cast<const char*>(pts + ch.start);
+    // (A branch-free form of this loop -- the thread's four points of a batch interleaved, outliers masked by selects -- was measured on
+    // the FULL stash: 100k points 23.5 -> 23.5 us, 300k 29.4 -> 31.5 (182 VGPRs); profiles/r06_experiments.md.  Not kept.)
     for (uint32_t base = 0; base < cnt; base += kT * kUnroll) {
       RawBatch<Rec, kUnroll> rb;
       if constexpr (!FULL) {
@@ -410,8 +417,16 @@ __global__ __launch_bounds__(kThreads) void k_spline_fused(
     }
   }
   // ------------------------------------------------------------------ end (k_spline_grad's epilogue)
+  stamp_stage(5);
   grad_reduce_store<kT>(acc, s_red, gtile, partials, blockIdx.x, gridDim.x);
-  if (last_workgroup_arrives<true>(counter, gridDim.x, s_flag)) grad_final_body<kT>(partials, int(gridDim.x), qx, qy, qz, qw, out, out_host, tag, s_red, s_fin);
+  // (the finalising workgroup reads the partials with agent-scope loads instead of an acquire fence + plain loads: no difference
+  // measured -- 23.1 / 38.9 us either way at 100k / 1M points --, one L2 invalidation less)
+  const bool last = last_workgroup_arrives<true, false>(counter, gridDim.x, s_flag);
+  stamp_stage(6);
+  if (last) {
+    grad_final_body<kT, true>(partials, int(gridDim.x), qx, qy, qz, qw, out, out_host, tag, s_red, s_fin);
+    stamp_stage(7);
+  }
 }
 
 }  // namespace nidreg

@@ -165,7 +165,8 @@ __device__ __forceinline__ double ent_value(long long k) { return double(k) * 0x
 // WRITE_THROUGH = the payload was stored by wave 0 with agent-scope (sc1, write-through) stores, so
 // no release fence is needed -- a buffer_wbl2 per workgroup costs ~2 us and, with thousands of
 // workgroups, made the fused gradient kernel 50 % slower than a separate finalisation launch.
-template <bool WRITE_THROUGH>
+// ACQUIRE = false: the caller reads the others' payload with agent-scope loads instead (nid_fused.hpp: no L2 invalidation).
+template <bool WRITE_THROUGH, bool ACQUIRE = true>
 __device__ __forceinline__ bool last_workgroup_arrives(unsigned int* counter, unsigned int nblocks, int* s_flag) {
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -174,7 +175,7 @@ __device__ __forceinline__ bool last_workgroup_arrives(unsigned int* counter, un
     const unsigned int t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = (t == nblocks - 1u) ? 1 : 0;
     if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (ACQUIRE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     *s_flag = last;
@@ -189,7 +190,8 @@ __device__ __forceinline__ bool last_workgroup_arrives(unsigned int* counter, un
 //   grad_v = 2 w A + 2 (M v + M^T v - 2 tr(M) v);  grad_t = gt.
 // out[1..7] = d NID / d [qx qy qz qw tx ty tz]; out_host (nullable) = host-mapped mirror.
 // s_red: kWaves * 12 doubles of LDS.
-template <int kT>
+// COH: the partials are read with agent-scope loads (written by this kernel's other workgroups with agent-scope stores; no acquire fence)
+template <int kT, bool COH = false>
 __device__ __forceinline__ void grad_final_body(const double* partials, int nblocks, double qx, double qy, double qz, double qw, double* out, double* out_host, double tag, double* s_red,
                                                 const double* s_fin = nullptr) {
   const int tid = threadIdx.x;
@@ -198,7 +200,7 @@ __device__ __forceinline__ void grad_final_body(const double* partials, int nblo
   for (int k = 0; k < 12; k++) acc[k] = 0.0;
   for (int b = tid; b < nblocks; b += kT) {
 #pragma unroll
-    for (int k = 0; k < 12; k++) acc[k] += partials[size_t(k) * nblocks + b];
+    for (int k = 0; k < 12; k++) acc[k] += COH ? __hip_atomic_load(&partials[size_t(k) * nblocks + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : partials[size_t(k) * nblocks + b];
   }
   __syncthreads();  // s_red may still be in use by the caller's own reduction
 #pragma unroll

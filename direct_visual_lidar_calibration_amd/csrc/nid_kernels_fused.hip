@@ -52,3 +52,10 @@ int occupancy_spline_fused(const PassArgs& a, const FusedArgs& f) {
 }
 
 }  // namespace nidreg
+
+#ifdef NID_STAMP
+// development aid (tools/fused_stage_times.py, an instrumented build loaded through NIDREG_LIB): the fused kernel's stage stamps
+extern "C" int nidreg_debug_fused_stage_stamps(unsigned long long* out, int words) {
+  return int(hipMemcpyFromSymbol(out, HIP_SYMBOL(nidreg::g_stage), size_t(words) * sizeof(unsigned long long)));
+}
+#endif
