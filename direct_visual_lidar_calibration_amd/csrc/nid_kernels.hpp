@@ -619,16 +619,47 @@ __global__ __launch_bounds__(WIDE ? kWideThreads : kThreads) void k_spline_hist(
 //             Bc also carries the relative error of 1 / den (one rsqrt and one reciprocal with one Newton step each);
 //   fisheye   u - cx = fx s x, s = theta_d(theta) / r, theta = atan2(r, |z|):  |d (s x)| <= e1 (1.5 D / |c| + 2 s), D = sup |theta_d'|
 //             on [0, pi/2] (host):                                                  bu = e1 (A / |c| + C s) + Brel (|u - cx| + |v - cy| + 1);
-//   equirect  u = W (1/2 + atan2(x, z) / 2 pi), v = H (1/2 + atan2(y, rho) / pi):  |d lon| <= 2 e1 / rho, |d lat| <= 2 e1 / |c|;
-//             the REFERENCE's own latitude, -asin(y / |c|), carries its rounding amplified by |c| / rho towards the poles,
-//             which the band must cover too:                                        bu = A e1 / rho + Bc,  bv = C e1 / |c| + Bc2 + D |c| / rho;
-//             a point within 2e-3 m^2 of the |c|^2 < 1e-3 rule (equirectangular.hpp:16) or on the vertical axis goes to the exact tier.
+//   equirect  (round 5: u, v by two full-precision atan2 with bands A e1 / rho + Bc and C e1 / |c| + Bc2 + D |c| / rho -- 84 us for 10M
+//             points; round 6 decides on the pixel BOUNDARIES instead, without the angles: see below NearestFast)
 struct NearestFast {
   double er, et;  // 8 eps rmax, 8 eps tmax
   double A, Bc;
   double C, D, Bc2;  // (wide-angle models, see above)
   int on;         // 0: exact tier only (atan / rational_polynomial, or a cone too wide for the model's bound)
+  // equirectangular (round 6): pixel BOUNDARIES instead of pixel coordinates (below)
+  const double* tab_c;  // [kmax + 1][2]: (cos, sin) of theta_k = 2 pi (k / W - 1/2), the longitude of column boundary u = k
+  const double* tab_r;  // [jmax + 1]: t_j = s_j |s_j|, s_j = sin(pi (j / H - 1/2)): the signed squared sine of row boundary v = j
+  int kmax, jmax;       // ceil(W), ceil(H) of the intrinsics
 };
+
+// Round 6, equirectangular: the decisions WITHOUT the angles.  u = W (1/2 + lon / 2 pi) with lon = atan2(x, z) and v = H (1/2 + lat' / pi)
+// with lat' = asin(y / |c|) are monotone in their angle, so "which column" is "between which two boundary longitudes", and a point lies
+// on the far side of the boundary theta_k exactly when  d_k = x cos(theta_k) - z sin(theta_k) = rho sin(lon - theta_k) >= 0;  "which row" is
+// e_j = y |y| - t_j |c|^2 >= 0 (s -> s |s| is monotone: no square root); the cone  z / |c| >= cos(fov)  is  z |z| - cf |cf| |c|^2 >= 0.
+// Products and sums only -- the round-5 tier spent 68 of its instructions on two full-precision atan2 and 16 on two reciprocal square
+// roots, at 163 VGPRs (84 us for 10M points against 45 for plumb_bob).  A CANDIDATE column / row comes from a single-precision atan2
+// (a degree-9 odd polynomial after the octant reduction: ~1e-5 rad, a few hundredths of a pixel); it is then confirmed against FOUR
+// consecutive boundaries k - 1 ... k + 2, which fixes a candidate that is one off and needs nothing from the approximation but "within a
+// pixel": d_{k-1} > 0 and d_{k+2} < 0 put lon inside three columns (sin changes sign once over less than pi), the signs of d_k, d_{k+1} say
+// which.  A lane is DECIDED when every one of its tests is outside its band; the bands bound how far the value can be from zero while the
+// REFERENCE's floating-point evaluation (cost_calculator_nid.cpp:30-47 through equirectangular.hpp:14-28) still decides otherwise:
+//   d:  4 e1 + 7e-15 (|x| + |z|)     e1 = the camera-frame error of the fused transform (above); the reference's column flips within
+//                                    W 4e-16 of an integer u (atan2 and the bearing's normalisation 1-1.5 ulp each, three more roundings),
+//                                    i.e. 2.5e-15 rad, times rho <= |x| + |z|; 3 eps (|x| + |z|) for this side's table entries and products;
+//   e:  8 e1 (|x|+|y|+|z|) + 60 eps |c|^2   the reference's asin(y / |c|) carries 1.5 ulp of its argument amplified by |c| / rho -- which the
+//                                    factor 2 |b| cos(lat) of d e / d lat takes back: 13 eps |c|^2 in all; 5 eps for this side;
+//   g:  8 e1 (|x|+|y|+|z|) + 16 eps |c|^2   (the cone; z / sqrt(n2) on the reference's side: 2 eps relative, squared).
+// Undecided lanes (a few per 10^7 points), |c|^2 <= 2e-3 (the model's centre rule) and the vertical axis go to the exact tier.
+__device__ __forceinline__ float approx_atan2f(float y, float x) {  // |error| ~ 1e-5 rad; NaN / garbage in -> a candidate the tests reject
+  const float ax = fabsf(x), ay = fabsf(y);
+  const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+  const float t = mn * __builtin_amdgcn_rcpf(mx);
+  const float t2 = t * t;
+  float p = t * fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, 0.0208351f, -0.0851330f), 0.1801410f), -0.3302995f), 0.9998660f);
+  p = ay > ax ? 1.57079637f - p : p;
+  p = x < 0.0f ? 3.14159274f - p : p;
+  return copysignf(p, y);
+}
 
 // LDS of the NEAREST kernel: the tile counts POINTS, and a workgroup's chunk holds fewer than 2^32 of them -- 32-bit cells
 // (ds_add_u32, half the LDS of the SPLINE tiles: 16 KB at 256 cells x 16 copies), summed to 64 bits in the flush
@@ -636,7 +667,7 @@ __host__ __device__ __forceinline__ size_t nearest_hist_lds_bytes(int B, int GW,
 // five waves per SIMD for the plumb_bob fast-tier instantiation (96 VGPRs, nothing spilled; 104-106 without the bound)
 // (round 5: fisheye lands at 132 and equirectangular at 173 by themselves -- asked for four and three waves)
 #ifndef NID_NEAREST_EQUIRECT_WAVES
-#define NID_NEAREST_EQUIRECT_WAVES 3
+#define NID_NEAREST_EQUIRECT_WAVES 4
 #endif
 constexpr int nearest_min_waves(int model, bool is_double, bool rec32, bool seg) {
   return (is_double && rec32 && !seg) ? (model == MODEL_PLUMB_BOB ? 5 : (model == MODEL_FISHEYE ? 4 : (model == MODEL_EQUIRECT ? NID_NEAREST_EQUIRECT_WAVES : 1))) : 1;
@@ -728,8 +759,54 @@ __global__ __launch_bounds__(kThreads, nearest_min_waves(MODEL, std::is_same<rea
           const double cy = fma(double(iso.m[6]), z, fma(double(iso.m[5]), y, fma(double(iso.m[4]), x, double(iso.m[7]))));
           const double cz = fma(double(iso.m[10]), z, fma(double(iso.m[9]), y, fma(double(iso.m[8]), x, double(iso.m[11]))));
           const double n2 = fma(cx, cx, fma(cy, cy, cz * cz));
-          const double rs = fast_rsq(n2);  // NaN for n2 == 0
           const double e1 = fma(fast.er, (fabs(x) + fabs(y)) + fabs(z), fast.et);
+          if constexpr (MODEL == MODEL_EQUIRECT) {
+            // the bands from ONE per-point magnitude, S = |x| + |y| + |z| of the LiDAR-frame point (e1 is linear in it already; the
+            // camera-frame magnitudes are bounded through it: |c|_1 <= 3 (rmax S + tmax), with er = 8 eps rmax, et = 8 eps tmax):
+            //   b1 >= 8 e1 |c|_1,  bd >= 4 e1 + 7e-15 (|cx| + |cz|)   -- looser by the factor |c|_1 bound / |c|_1 <= ~3, still 1e-13 of a pixel
+            const double eps = 0x1p-52;
+            const double S = (fabs(x) + fabs(y)) + fabs(z);
+            const double m1 = fma(fast.er, S, fast.et) * (3.0 / (8.0 * eps));  // >= |c|_1
+            const double b1 = (8.0 * e1) * m1;
+            const double bd = fma(7e-15, m1, 4.0 * e1);
+            // the cone
+            const double cf = double(cos_fov);
+            const double g = fma(-(cf * fabs(cf)), n2, cz * fabs(cz));
+            const bool fov_safe = fabs(g) > fma(16.0 * eps, n2, b1);
+            const bool in_fov = g >= 0.0;
+            // candidates from single precision
+            const float xf = float(cx), yf = float(cy), zf = float(cz);
+            const float lonf = approx_atan2f(xf, zf);
+            const float latf = approx_atan2f(yf, __builtin_amdgcn_sqrtf(fmaf(xf, xf, zf * zf)));
+            const float uf = fmaf(float(cam.intr[0]) * 0.159154943f, lonf, float(cam.intr[0]) * 0.5f);
+            const float vf = fmaf(float(cam.intr[1]) * 0.318309886f, latf, float(cam.intr[1]) * 0.5f);
+            const int kc = min(max(int(uf), 1), fast.kmax - 2), jc = min(max(int(vf), 1), fast.jmax - 2);  // (NaN converts to 0)
+            // columns: boundaries kc - 1 ... kc + 2 (uniform base + 32-bit byte offset per lane)
+            const char* tcb = reinterpret_cast<const char*>(fast.tab_c) + uint32_t(kc - 1) * 16u;
+            const double2 c0 = reinterpret_cast<const double2*>(tcb)[0], c1 = reinterpret_cast<const double2*>(tcb)[1], c2 = reinterpret_cast<const double2*>(tcb)[2],
+                          c3 = reinterpret_cast<const double2*>(tcb)[3];
+            const double d0 = fma(cx, c0.x, -(cz * c0.y)), d1 = fma(cx, c1.x, -(cz * c1.y)), d2 = fma(cx, c2.x, -(cz * c2.y)), d3 = fma(cx, c3.x, -(cz * c3.y));
+            // decided when d0, -d3, |d1|, |d2| are all beyond the band (with d0 > 0 > d3 the signs of d1, d2 can only be + +, + - or - -:
+            // sin(lon - theta) changes sign once over three columns; rho = 0 gives d = 0: undecided by itself)
+            const bool col_ok = fmin(fmin(d0, -d3), fmin(fabs(d1), fabs(d2))) > bd;
+            const int col = (kc - 1) + int(d1 > 0.0) + int(d2 > 0.0);
+            // rows: boundaries jc - 1 ... jc + 2
+            const char* trb = reinterpret_cast<const char*>(fast.tab_r) + uint32_t(jc - 1) * 8u;
+            const double t0 = reinterpret_cast<const double*>(trb)[0], t1 = reinterpret_cast<const double*>(trb)[1], t2 = reinterpret_cast<const double*>(trb)[2],
+                         t3 = reinterpret_cast<const double*>(trb)[3];
+            const double yy = cy * fabs(cy);
+            const double q0 = fma(-t0, n2, yy), q1 = fma(-t1, n2, yy), q2 = fma(-t2, n2, yy), q3 = fma(-t3, n2, yy);
+            const bool row_ok = fmin(fmin(q0, -q3), fmin(fabs(q1), fabs(q2))) > fma(60.0 * eps, n2, b1);
+            const int row = (jc - 1) + int(q1 > 0.0) + int(q2 > 0.0);
+            const bool uv_safe = bool(int(n2 > 2e-3) & int(col_ok) & int(row_ok));
+            const bool in_rng = bool(int(col < W) & int(row < H));  // (col, row >= 0 by construction: u, v >= 0 for this model)
+            const bool decided = bool(int(fov_safe) & (int(!in_fov) | int(uv_safe)));
+            need[k] = bool(int(valid) & int(!decided));
+            ins[k] = bool(int(valid) & int(decided) & int(in_fov) & int(in_rng));
+            pxs[k] = ins[k] ? col : 0;
+            pys[k] = ins[k] ? row : 0;
+          } else {
+          const double rs = fast_rsq(n2);  // NaN for n2 == 0
           const double dz = fma(cz, rs, -double(cos_fov));
           const bool fov_safe = fabs(dz) > fma(8.0 * e1, rs, 4e-14);
           const bool in_fov = !(dz < 0.0);
@@ -746,12 +823,6 @@ __global__ __launch_bounds__(kThreads, nearest_min_waves(MODEL, std::is_same<rea
             u = fma(cam.intr[0], kc.s * real(cx), cam.intr[2]);
             v = fma(cam.intr[1], kc.s * real(cy), cam.intr[3]);
             bu = bv = fma(e1, fma(fast.A, rs, fast.C * fabs(double(kc.s))), fast.Bc * ((fabs(double(u) - double(cam.intr[2])) + fabs(double(v) - double(cam.intr[3]))) + 1.0));
-          } else if constexpr (MODEL == MODEL_EQUIRECT) {
-            const EquirectCore<real> kc = equirect_core<real>(cam, real(cx), real(cy), real(cz), u, v);
-            const double irho = double(kc.irho);  // 0 on the vertical axis (rho = 0): sent to the exact tier below
-            bu = fma(fast.A * e1, irho, fast.Bc);
-            bv = fma(fast.C * e1, rs, fast.Bc2) + fast.D * ((n2 * rs) * irho);
-            model_ok = bool(int(n2 > 2e-3) & int(double(kc.rho2) > 0.0));
           } else {
             project<MODEL, real, real, true>(cam, real(cx), real(cy), real(cz), u, v);
             bu = bv = fma(fast.A * e1, fabs(fast_rcp(cz)), fast.Bc);
@@ -764,6 +835,7 @@ __global__ __launch_bounds__(kThreads, nearest_min_waves(MODEL, std::is_same<rea
           ins[k] = bool(int(valid) & int(decided) & int(in_fov) & int(in_rng));
           pxs[k] = ins[k] ? int(u) : 0;
           pys[k] = ins[k] ? int(v) : 0;
+          }
         }
       }
 #pragma unroll

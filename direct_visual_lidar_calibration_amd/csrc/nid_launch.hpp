@@ -22,6 +22,9 @@ struct NearestFastArgs {
   double er, et, A, Bc;
   double C, D, Bc2;
   int on;
+  const double* tab_c;  // equirectangular: boundary tables of the handle (device memory; nid_kernels.hpp NearestFast)
+  const double* tab_r;
+  int kmax, jmax;
 };
 
 struct PassArgs {

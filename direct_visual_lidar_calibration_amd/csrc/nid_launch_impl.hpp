@@ -257,6 +257,7 @@ static hipError_t launch_nearest_hist_rec(const PassArgs& a) {
   const CamParams<real> cam = make_cam<real>(a.intr, a.dist);
   NearestFast fast;
   fast.er = a.nfast.er, fast.et = a.nfast.et, fast.A = a.nfast.A, fast.Bc = a.nfast.Bc, fast.C = a.nfast.C, fast.D = a.nfast.D, fast.Bc2 = a.nfast.Bc2, fast.on = a.nfast.on;
+  fast.tab_c = a.nfast.tab_c, fast.tab_r = a.nfast.tab_r, fast.kmax = a.nfast.kmax, fast.jmax = a.nfast.jmax;
 #define NID_LAUNCH_N(M, SEG)                                                                                                                           \
   if (a.multi) {                                                                                                                                       \
     auto k = k_nearest_hist<M, Rec, real, true, SEG>;                                                                                                       \

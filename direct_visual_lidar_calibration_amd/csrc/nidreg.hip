@@ -184,6 +184,11 @@ struct nidreg_handle {
   uint64_t fused_launches = 0;       // fused launches so far (the barrier's epoch)
   bool fused_last = false;           // the evaluation in flight (or last finished) ran on the fused route
 
+  // NEAREST, equirectangular: (cos, sin) of the column-boundary longitudes, then the signed squared sines of the row-boundary
+  // latitudes (nid_kernels.hpp NearestFast); eq_kmax / eq_jmax = ceil of the intrinsics' W / H
+  double* d_eq_tab = nullptr;
+  int eq_kmax = 0, eq_jmax = 0;
+
   int timing = 0;  // 1: per-kernel events (three-kernel path), 2: events around whichever path runs
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool ev_grad = false;
@@ -363,6 +368,7 @@ void free_handle(nidreg_handle* h) {
   if (h->d_chunks) (void)hipFree(h->d_chunks);
   if (h->d_chunks_hist) (void)hipFree(h->d_chunks_hist);
   if (h->d_fused_scratch) (void)hipFree(h->d_fused_scratch);
+  if (h->d_eq_tab) (void)hipFree(h->d_eq_tab);
   if (h->d_gend) (void)hipFree(h->d_gend);
   if (h->d_img) (void)hipFree(h->d_img);
   if (h->own_hist) {
@@ -589,12 +595,12 @@ NearestFastArgs nearest_fast_args(const nidreg_handle* h, const double* T) {
     f.C = 2.0 * 2.0 * fmax;
     f.Bc = 2e-13 * std::max(1.0, D);  // relative: the one-step rsqrt (2.1e-14), its share of theta through atan2, theta_d's four fmas, s x
   } else if (h->model == NIDREG_MODEL_EQUIRECTANGULAR) {
-    const double Wd = std::fabs(h->intr[0]), Hd = std::fabs(h->intr[1]);
-    f.A = 2.0 * 2.0 * Wd / (2.0 * pi);  // |d lon| <= 2 e1 / rho, doubled
-    f.C = 2.0 * 2.0 * Hd / pi;         // |d lat| <= 2 e1 / |c|, doubled
-    f.Bc = Wd / (2.0 * pi) * 2e-14;    // fast_atan2 (3e-16) + libm's atan2 on the reference's side, the normalisations: < 1e-14 rad
-    f.Bc2 = Hd / pi * 3e-14;           // rho through a one-step rsqrt: <= 1.1e-14 rad at 45 degrees
-    f.D = Hd / pi * 16.0 * eps;        // the reference's asin(y / |c|): its argument's rounding amplified by |c| / rho
+    // round 6: decided on the pixel boundaries (nid_kernels.hpp below NearestFast): the tables built at creation, bands per point
+    if (!h->d_eq_tab) return f;
+    f.tab_c = h->d_eq_tab;
+    f.tab_r = h->d_eq_tab + 2 * size_t(h->eq_kmax + 1);
+    f.kmax = h->eq_kmax;
+    f.jmax = h->eq_jmax;
   } else {
     return f;
   }
@@ -1494,6 +1500,27 @@ int create_impl(const nidreg_desc* d, const nidreg_cloud* cloud, const double* T
       CREATE_TRY(hipMalloc(&h->d_chunks_hist, h->chunks_hist_cap * sizeof(Chunk)));
       if (!wide_chunks.empty()) CREATE_TRY(hipMemcpy(h->d_chunks_hist, wide_chunks.data(), wide_chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice));
     }
+  }
+
+  // ---- NEAREST on an equirectangular camera: the pixel-boundary tables of the fast decision tier (nid_kernels.hpp NearestFast).
+  // Boundary u = k sits at longitude theta_k = 2 pi (k / W - 1/2), boundary v = j at latitude pi (j / H - 1/2), W and H the
+  // INTRINSICS (equirectangular.hpp:14-28 projects with them; the image size only enters the in-image test).
+  if (d->mode == NIDREG_MODE_NEAREST && h->model == NIDREG_MODEL_EQUIRECTANGULAR && h->intr[0] >= 8.0 && h->intr[1] >= 8.0 && h->intr[0] <= 65536.0 && h->intr[1] <= 65536.0) {
+    const double pi = 3.14159265358979323846;
+    h->eq_kmax = int(std::ceil(h->intr[0]));
+    h->eq_jmax = int(std::ceil(h->intr[1]));
+    std::vector<double> tab(2 * size_t(h->eq_kmax + 1) + size_t(h->eq_jmax + 1));
+    for (int k = 0; k <= h->eq_kmax; k++) {
+      const double th = 2.0 * pi * (double(k) / h->intr[0] - 0.5);
+      tab[2 * size_t(k)] = std::cos(th);
+      tab[2 * size_t(k) + 1] = std::sin(th);
+    }
+    for (int j = 0; j <= h->eq_jmax; j++) {
+      const double sj = std::sin(pi * (double(j) / h->intr[1] - 0.5));
+      tab[2 * size_t(h->eq_kmax + 1) + size_t(j)] = sj * std::fabs(sj);
+    }
+    CREATE_TRY(hipMalloc(&h->d_eq_tab, tab.size() * sizeof(double)));
+    CREATE_TRY(hipMemcpy(h->d_eq_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
   }
 
 #ifdef NID_EXP_HANDOFF
