@@ -27,8 +27,26 @@ def build_exe():
     return EXE
 
 
+STUB = os.path.join(ROOT, "tests", "cxx", "librccl_stub.so")
+
+
+def build_stub():
+    """tests/cxx/rccl_stub.cpp: the six RCCL entry points libnidreg.so resolves, with a shared-memory reduction between PROCESSES --
+    lets two ranks share the one GPU of a test box (RCCL refuses two ranks on one device)."""
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include", os.path.join(ROOT, "tests", "cxx", "rccl_stub.cpp"),
+           "-L", "/opt/rocm/lib", "-lamdhip64", "-lrt", "-pthread", "-Wl,-rpath,/opt/rocm/lib", "-o", STUB]
+    subprocess.check_call(cmd)
+    return STUB
+
+
 def test_rccl_program_compiles_and_links():
     assert os.path.exists(build_exe())
+    assert os.path.exists(build_stub())
+    import ctypes
+
+    lib = ctypes.CDLL(STUB)
+    for sym in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclCommCount", "ncclAllReduce", "ncclGetErrorString"):
+        assert hasattr(lib, sym)  # exactly what csrc/nidreg.hip RcclApi resolves
 
 
 def test_library_does_not_link_rccl():
@@ -100,3 +118,64 @@ def test_inlib_sharded_cost_python_world1():
     assert np.array_equal(b.histogram_fixed()[0], a.histogram_fixed()[0])
     a.close()
     b.close()
+
+
+def _run_two_ranks(tmp_path, case):
+    import json
+    import sys
+
+    stub = STUB if os.path.exists(STUB) else build_stub()
+    tmp_path = tmp_path / case  # (rank 0 leaves the communicator's id in a file: one directory per run)
+    os.makedirs(tmp_path)
+    env = dict(os.environ, NIDREG_RCCL_LIB=stub, OMP_NUM_THREADS="8", MKL_NUM_THREADS="8")  # (two torch processes each spinning on every core of the box took 40-200 s to build a 60k-point scene)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "run_rccl_stub_rank.py"), str(r), "2", str(tmp_path), case], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+             for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se.decode()[-3000:]
+    return [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
+
+
+@pytest.mark.gpu
+def test_two_ranks_all_reduce_through_the_library_chain(tmp_path):
+    """nidreg_shard_comm_init -> nidreg_eval with world = 2 and a reduction that is NOT the identity: two processes, each with half
+    of the cloud (index slices, desc.scale_points = the pair's total), share the GPU; librccl.so is replaced by a shared-memory stub
+    (NIDREG_RCCL_LIB) since RCCL refuses two ranks on one device.  Every rank must return the unsharded handle's cost bit for bit
+    (integer histogram, exact all-reduce) and its gradient up to the order of two partial sums; cost-only evaluations and the
+    derivative-free twin go through the same chain."""
+    from direct_visual_lidar_calibration_amd import nid, se3, synth
+
+    ranks = _run_two_ranks(tmp_path, "spline")
+    s = synth.make_scene("pinhole_vga", num_points=60_000, seed=91)
+    proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
+    rng = np.random.default_rng(4)
+    poses = [s.T_camera_lidar_init] + [synth.random_pose_near(s.T_camera_lidar_true, rng) for _ in range(3)]
+    plain = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, 64)
+    ref = [plain(x) for x in poses]
+    plain.close()
+    for r in ranks:
+        assert r["attached"] and all(r["ok"])
+        assert r["costs"] == [v[1] for v in ref] and r["cost_only"] == [v[1] for v in ref]
+        assert np.allclose(np.array(r["grads"]), np.array([v[2] for v in ref]), rtol=1e-12, atol=1e-15)
+    assert ranks[0]["grads"] == ranks[1]["grads"]  # the same reduced 7 doubles on every rank
+    import oracle_lib
+
+    near = _run_two_ranks(tmp_path, "nearest")
+    max_fov = oracle_lib.estimate_camera_fov(s.model, s.intrinsics, s.distortion, s.width, s.height)
+    a = nid.CostCalculatorNID(proj, s.image_u8, s.points, s.intensities, nid.NIDCostParams(64), max_fov=max_fov)
+    want = [a.calculate(se3.to_matrix(x)) for x in poses]
+    total = int(a.histogram_fixed()[0].sum())
+    a.close()
+    for r in near:
+        assert r["costs"] == want and r["hist_sum"] == total
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["mismatch_unit", "mismatch_bins"])
+def test_ranks_that_disagree_on_the_table_are_refused_on_every_rank(tmp_path, case):
+    """a rank created without desc.scale_points (another fixed-point unit) or with other bins would add incompatible
+    integers into a cost that is wrong yet identical everywhere.  nidreg_shard_comm_init max-/min-reduces the table parameters
+    once and refuses on every rank alike."""
+    ranks = _run_two_ranks(tmp_path, case)
+    for r in ranks:
+        assert not r["attached"] and "disagree" in r["error"], r
