@@ -20,6 +20,7 @@
 
 #include <type_traits>
 
+#include <cmath>
 #include <cstring>
 #include "nid_atan_table.hpp"
 #include "nid_log_table.hpp"
@@ -140,6 +141,10 @@ struct CamParams {
 };
 // p_cam = R p + t with R = I + 2 w [v]x + 2 [v]x^2 built on the host from the UN-normalised
 // quaternion exactly as Sophus' SO3 * point expands (nid_cost.hpp:47)
+// `atan` model: the distortion slots behind its one coefficient carry the two constants its projection derives from it
+constexpr int kAtanD1 = 6, kAtanD2 = 7;
+template <typename real>
+inline void cam_derive(int model, CamParams<real>& c);  // (host side: defined below the model ids)
 template <typename real>
 struct PoseParams {
   real R[9];
@@ -152,6 +157,15 @@ struct IsoParams {
 };
 
 enum { MODEL_PLUMB_BOB = 0, MODEL_FISHEYE = 1, MODEL_OMNIDIR = 2, MODEL_EQUIRECT = 3, MODEL_ATAN = 4, MODEL_RATIONAL = 5 };
+// constants a model derives from its coefficients, in the reference's expressions, once per camera on the host
+template <typename real>
+inline void cam_derive(int model, CamParams<real>& c) {
+  if (model == MODEL_ATAN) {  // atan.hpp:21-22
+    const double d0 = double(c.dist[0]);
+    c.dist[kAtanD1] = real(1.0 / d0);
+    c.dist[kAtanD2] = real(2.0 * std::tan(d0 / 2.0));
+  }
+}
 
 // ------------------------------------------------------------------------------------------
 // a*b + c: one fused multiply-add in the FAST (SPLINE) instantiation when all operands are plain
@@ -513,9 +527,19 @@ NID_HD void project(const CamParams<real>& c, const T& x, const T& y, const T& z
     const T r = m_sqrt(mad<FAST>(px, px, py * py));
     T dx = px, dy = py;
     if (!(r < real(1e-3) || d0 < real(1e-7))) {
-      const real d1 = real(1) / d0;
-      const real d2 = real(2) * tan(d0 / real(2));
-      const T factor = d1 * m_atan(r * d2) / r;
+      // d1 = 1 / d0 and d2 = 2 tan(d0 / 2) (atan.hpp:21-22) are camera constants: computed once on the HOST (cam_derive below) --
+      // the reference's own libm, and no call into the device's tan() in a point kernel (the call alone pinned the gradient
+      // kernel of this model at 165 VGPRs, whatever its arithmetic)
+      const real d1 = c.dist[kAtanD1];
+      const real d2 = c.dist[kAtanD2];
+      T factor;
+      if constexpr (FAST && std::is_floating_point<T>::value) {
+        // SPLINE kernels: the table atan2 of the wide-angle models (4.4e-16 absolute) instead of the library's atan -- which held
+        // this model's gradient kernel at 166 VGPRs where the others need 124-130
+        factor = d1 * fast_atan2(r * d2, T(1)) * fast_rcp(r);
+      } else {
+        factor = d1 * m_atan(r * d2) / r;
+      }
       dx = factor * px;
       dy = factor * py;
     }
@@ -546,6 +570,34 @@ NID_HD void project(const CamParams<real>& c, const T& x, const T& y, const T& z
     u = mad<FAST>(c.intr[0], dx, c.intr[2]);
     v = mad<FAST>(c.intr[1], dy, c.intr[3]);
   }
+}
+
+// `atan` (FOV) model, atan.hpp:14-39: (dx, dy) = f(r) (px, py), f = atan(d2 r) / (d0 r), d2 = 2 tan(d0 / 2), p = (x, y) / z -- and the
+// identity where r < 1e-3 or d0 < 1e-7.  d(dx, dy)/d(px, py) = f I + q p p^T with q = f'(r) / r = (d2 / (d0 (1 + d2^2 r^2)) - f) / r^2.
+// Round 6: the gradient pass contracts (gx, gy) through these two scalars like the other models do through theirs; until round 5
+// it pushed three partials through every operation (Dual3, 164-170 VGPRs: three waves per SIMD).
+template <typename real>
+struct AtanCore {
+  real iz, px, py, f, q;
+};
+template <typename real>
+NID_HD AtanCore<real> atan_core(const CamParams<real>& c, real x, real y, real z) {
+  AtanCore<real> k;
+  k.iz = fast_rcp(z);
+  k.px = x * k.iz;
+  k.py = y * k.iz;
+  const real r2 = fma(k.px, k.px, k.py * k.py);
+  const real r = m_sqrt(r2);
+  const real d0 = c.dist[0];
+  k.f = real(1);
+  k.q = real(0);
+  if (!(r < real(1e-3) || d0 < real(1e-7))) {
+    const real d1 = c.dist[kAtanD1], d2 = c.dist[kAtanD2];
+    const real ir2 = fast_rcp(r2);
+    k.f = d1 * fast_atan2(r * d2, real(1)) * fast_rcp(r);  // the value pass's own factor (project<MODEL_ATAN, FAST>)
+    k.q = fma(d1 * d2, fast_rcp(fma(d2 * d2, r2, real(1))), -k.f) * ir2;
+  }
+  return k;
 }
 
 // what the wide-angle models' Jacobians need beyond their cores
@@ -677,6 +729,17 @@ NID_HD void project_jac(const CamParams<real>& c, real x, real y, real z, real& 
     dv[0] = t * x;
     dv[1] = kvr;
     dv[2] = t * z;
+  } else if (MODEL == MODEL_ATAN) {
+    project<MODEL, real, real, true>(c, x, y, z, u, v);  // value: the histogram pass's own expression
+    const AtanCore<real> k = atan_core<real>(c, x, y, z);
+    const real fx = c.intr[0] * k.iz, fy = c.intr[1] * k.iz;
+    const real qxy = k.q * (k.px * k.py);
+    du[0] = fx * fma(k.q * k.px, k.px, k.f);
+    du[1] = fx * qxy;
+    du[2] = -fma(du[0], k.px, du[1] * k.py);
+    dv[0] = fy * qxy;
+    dv[1] = fy * fma(k.q * k.py, k.py, k.f);
+    dv[2] = -fma(dv[0], k.px, dv[1] * k.py);
   } else {
     typedef Dual3<real> D;
     D uu, vv;
@@ -701,12 +764,13 @@ NID_HD void project_jac(const CamParams<real>& c, real x, real y, real z, real& 
 //                    (p = den m in x and y, p_z = den - xi |p|): nothing of the camera-frame point stays alive across the taps
 //   fisheye          g' = (fx gx, fy gy), k = x g'0 + y g'1:  gp = (s g'0 + x q k, s g'1 + y q k, wz k)
 //   equirectangular  gp = (a z + b x, gy kvr, b z - a x),  a = gx ku, b = gy t
-// -- 10 / 14 / 10 / 7 operations where the explicit Jacobian and its contraction took 18 / 36 / 20 / 14.  `atan` keeps the
-// generic 2x3 Jacobian (project_jac) and contracts it here.
+//   atan (FOV)       g' = (fx gx, fy gy), k = px g'0 + py g'1:  h = f g' + q k (px, py),  gp = (h0 / z, h1 / z, -(gp0 px + gp1 py))   (round 6)
+// -- 10 / 14 / 10 / 7 / 11 operations where the explicit Jacobian and its contraction took 18 / 36 / 20 / 14.  A model without a
+// branch of its own (none of the six today) would fall back to the generic 2x3 Jacobian (project_jac) contracted here.
 template <typename real>
 struct ProjCtx {
   real a[6];  // pinhole family: iz, px, py, A00, off, A11;  omnidir: (A00, off, A11) / den, ux, uy, xi den / |p|;
-              // fisheye: s, q, wz, x, y;  equirectangular: ku, kvr, t, x, z;  atan: du[0..2], dv[0..2]
+              // fisheye: s, q, wz, x, y;  equirectangular: ku, kvr, t, x, z;  atan: iz, px, py, f, q
 };
 template <int MODEL, typename real>
 NID_HD void project_fwd(const CamParams<real>& c, real x, real y, real z, real& u, real& v, ProjCtx<real>& ctx) {
@@ -756,6 +820,14 @@ NID_HD void project_fwd(const CamParams<real>& c, real x, real y, real z, real& 
     equirect_partials<real>(c, k, y, ctx.a[0], ctx.a[1], ctx.a[2]);
     ctx.a[3] = x;
     ctx.a[4] = z;
+  } else if (MODEL == MODEL_ATAN) {
+    project<MODEL, real, real, true>(c, x, y, z, u, v);
+    const AtanCore<real> k = atan_core<real>(c, x, y, z);
+    ctx.a[0] = k.iz;
+    ctx.a[1] = k.px;
+    ctx.a[2] = k.py;
+    ctx.a[3] = k.f;
+    ctx.a[4] = k.q;
   } else {
     project_jac<MODEL, real>(c, x, y, z, u, v, ctx.a, ctx.a + 3);
   }
@@ -791,6 +863,12 @@ NID_HD void project_bwd(const CamParams<real>& c, const ProjCtx<real>& ctx, real
     gp[0] = fma(a, ctx.a[4], b * ctx.a[3]);
     gp[1] = gy * ctx.a[1];
     gp[2] = fma(b, ctx.a[4], -(a * ctx.a[3]));
+  } else if (MODEL == MODEL_ATAN) {
+    const real g0 = gx * c.intr[0], g1 = gy * c.intr[1];
+    const real kq = fma(ctx.a[1], g0, ctx.a[2] * g1) * ctx.a[4];
+    gp[0] = fma(kq, ctx.a[1], ctx.a[3] * g0) * ctx.a[0];
+    gp[1] = fma(kq, ctx.a[2], ctx.a[3] * g1) * ctx.a[0];
+    gp[2] = -fma(gp[0], ctx.a[1], gp[1] * ctx.a[2]);
   } else {
     gp[0] = fma(gx, ctx.a[0], gy * ctx.a[3]);
     gp[1] = fma(gx, ctx.a[1], gy * ctx.a[4]);

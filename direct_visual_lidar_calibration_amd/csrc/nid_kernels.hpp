@@ -1564,10 +1564,10 @@ __device__ __forceinline__ void build_gtile(const u64* __restrict__ hist, uint32
     for (uint32_t j = 0; j <= cmask; j++) gtile[(uint32_t(k) << cshift) + ((j + uint32_t(k)) & cmask)] = gval;
   }
 }
-// the `atan` model keeps the generic Dual3 forward mode and sits at the edge of three waves per SIMD (164-170 VGPRs; the
-// allocation granule is 8): ask for three explicitly
+// (until round 5 the `atan` model ran the generic Dual3 forward mode at 164-170 VGPRs and was asked for three waves; with its own
+// vector-Jacobian product -- nid_device.hpp atan_core -- it lands where the other models do)
 // (the looped instantiations on float records are told to stay at four -- they land at 126-130 by themselves)
-constexpr int grad_min_waves(int model, bool seg = false, bool rec32 = false) { return model == MODEL_ATAN ? 3 : ((seg && rec32) ? 4 : NID_GRAD_MIN_WAVES); }
+constexpr int grad_min_waves(int model, bool seg = false, bool rec32 = false) { return (seg && rec32) ? 4 : NID_GRAD_MIN_WAVES; }
 // LDS of the gradient kernel: G tile (one copy of one column when GW = 1, else 2^cshift copies of GW columns), reduction scratch,
 // phi(q_r), flag, the workgroup's own copy of cost / status / inlier count (s_fin); SEG (GW = 1 only): kMaxSegs - 1 staged G columns behind them
 // the region at the start of the gradient kernel's LDS: the G tile during the point loop, the reduction's scratch after it

@@ -18,7 +18,7 @@ template <> int occupancy_spline_grad<double>(const PassArgs& a) { return a.rec6
 template <> hipError_t launch_project<double>(int model, const double* intr, const double* dist, const double* p3, long long n, double* uv, double* jac, hipStream_t stream) {
   if (n == 0) return hipSuccess;
   struct { int model; } a{model};
-  const CamParams<double> cam = make_cam<double>(intr, dist);
+  const CamParams<double> cam = make_cam<double>(model, intr, dist);
   const unsigned grid = unsigned((n + 255) / 256);
 #define NID_LAUNCH(M) hipLaunchKernelGGL((k_project<M, double>), dim3(grid), dim3(256), 0, stream, p3, n, cam, uv, jac)
   NID_MODEL_SWITCH(NID_LAUNCH)
@@ -35,7 +35,7 @@ hipError_t set_handoff_buffer(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_u
 // of ONE point (src/vlcal/common/estimate_fov.cpp:17-51), host work in the reference as well
 int project_host(int model, const double* intr, const double* dist, const double* p3, long long n, double* uv, double* jac) {
   struct { int model; } a{model};
-  const CamParams<double> cam = make_cam<double>(intr, dist);
+  const CamParams<double> cam = make_cam<double>(model, intr, dist);
 #define NID_LAUNCH(M)                                                                                      \
   for (long long i = 0; i < n; i++) {                                                                      \
     double u, v, du[3], dv[3];                                                                             \

@@ -16,7 +16,7 @@ hipError_t launch_cull(int model, const double* intr, const double* dist, const 
                        int depth, int* d_pix, unsigned int* d_zbuf, unsigned char* d_keep, hipStream_t stream) {
   if (n == 0) return hipSuccess;
   struct { int model; } a{model};
-  const CamParams<double> cam = make_cam<double>(intr, dist);
+  const CamParams<double> cam = make_cam<double>(model, intr, dist);
   IsoParams<double> iso;
   for (int k = 0; k < 12; k++) iso.m[k] = T[k];
   const unsigned grid = unsigned((n + 255) / 256);
@@ -34,7 +34,7 @@ hipError_t launch_colorize(int model, const double* intr, const double* dist, co
                            double min_nz, const float* d_icolor, double blend_weight, float* d_out, hipStream_t stream) {
   if (n == 0) return hipSuccess;
   struct { int model; } a{model};
-  const CamParams<double> cam = make_cam<double>(intr, dist);
+  const CamParams<double> cam = make_cam<double>(model, intr, dist);
   IsoParams<double> iso;
   for (int k = 0; k < 12; k++) iso.m[k] = T[k];
   // Eigen: Vector4f * double converts the scalar to float first (points_color_updater.cpp:57)
@@ -51,7 +51,7 @@ hipError_t launch_colorize(int model, const double* intr, const double* dist, co
 hipError_t launch_lidar_image(int model, const double* intr, const double* dist, const double* d_pts, long long stride_d, const double* d_intensities, long long n, const double* T, int W,
                               int H, double min_nz, int* d_pix, u64* d_zmin, int* d_index_image, double* d_intensity_image, hipStream_t stream) {
   struct { int model; } a{model};
-  const CamParams<double> cam = make_cam<double>(intr, dist);
+  const CamParams<double> cam = make_cam<double>(model, intr, dist);
   IsoParams<double> iso;
   for (int k = 0; k < 12; k++) iso.m[k] = T[k];
   const long long npix = (long long)W * H;

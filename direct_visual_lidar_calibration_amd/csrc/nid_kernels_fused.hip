@@ -10,7 +10,7 @@ size_t fused_lds_bytes_for(const PassArgs& a, int full, int cap) { return fused_
 template <typename Rec, bool FULL>
 static hipError_t launch_fused_rec(const PassArgs& a, const FusedArgs& f, bool occupancy_only, int* occ) {
   const PoseParams<double> pose = make_pose<double>(a);
-  const CamParams<double> cam = make_cam<double>(a.intr, a.dist);
+  const CamParams<double> cam = make_cam<double>(a.model, a.intr, a.dist);
   GradTail gt;
   gt.phi_q = a.gt_phi_q;
   gt.hist_image = a.gt_hist_image;

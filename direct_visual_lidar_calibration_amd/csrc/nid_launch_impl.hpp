@@ -10,10 +10,11 @@
 namespace nidreg {
 
 template <typename real>
-static CamParams<real> make_cam(const double* intr, const double* dist) {
+static CamParams<real> make_cam(int model, const double* intr, const double* dist) {
   CamParams<real> c;
   for (int i = 0; i < 5; i++) c.intr[i] = real(intr[i]);
   for (int i = 0; i < 8; i++) c.dist[i] = real(dist[i]);
+  cam_derive<real>(model, c);  // (constants a model derives from its coefficients: nid_device.hpp)
   return c;
 }
 template <typename real>
@@ -63,7 +64,7 @@ static hipError_t ensure_lds(K kernel, size_t bytes) {
 template <typename real, typename Rec>
 static hipError_t launch_spline_hist_rec(const PassArgs& a) {
   const PoseParams<real> pose = make_pose<real>(a);
-  const CamParams<real> cam = make_cam<real>(a.intr, a.dist);
+  const CamParams<real> cam = make_cam<real>(a.model, a.intr, a.dist);
   // SEG: the table has chunks that run across column-group boundaries (nid_kernels.hpp Segments)
 #define NID_LAUNCH_W(M, WIDE, THREADS, SEG)                                                                                                            \
   if (a.multi) {                                                                                                                                       \
@@ -107,7 +108,7 @@ static hipError_t launch_spline_hist_rec(const PassArgs& a) {
 template <typename real, typename Rec>
 static hipError_t launch_spline_grad_rec(const PassArgs& a) {
   const PoseParams<real> pose = make_pose<real>(a);
-  const CamParams<real> cam = make_cam<real>(a.intr, a.dist);
+  const CamParams<real> cam = make_cam<real>(a.model, a.intr, a.dist);
   GradTail gt;
   gt.phi_q = a.gt_phi_q;
   gt.hist_image = a.gt_hist_image;
@@ -254,7 +255,7 @@ static int occupancy_nearest_hist_rec(const PassArgs& a) {
 template <typename real, typename Rec>
 static hipError_t launch_nearest_hist_rec(const PassArgs& a) {
   const IsoParams<real> iso = make_iso<real>(a);
-  const CamParams<real> cam = make_cam<real>(a.intr, a.dist);
+  const CamParams<real> cam = make_cam<real>(a.model, a.intr, a.dist);
   NearestFast fast;
   fast.er = a.nfast.er, fast.et = a.nfast.et, fast.A = a.nfast.A, fast.Bc = a.nfast.Bc, fast.C = a.nfast.C, fast.D = a.nfast.D, fast.Bc2 = a.nfast.Bc2, fast.on = a.nfast.on;
   fast.tab_c = a.nfast.tab_c, fast.tab_r = a.nfast.tab_r, fast.kmax = a.nfast.kmax, fast.jmax = a.nfast.jmax;

@@ -175,6 +175,7 @@ int main(int argc, char** argv) {
   for (int i = 0; i < 5; i++) cam.intr[i] = intr[i];
   for (int i = 0; i < 8; i++) cam.dist[i] = dist[i];
   const std::string m(model);
+  if (m == "atan") cam_derive<double>(MODEL_ATAN, cam);
   if (m == "plumb_bob") return run<MODEL_PLUMB_BOB>(cam, W, H, bins, src_bins, pts, ints, se3);
   if (m == "fisheye" || m == "equidistant") return run<MODEL_FISHEYE>(cam, W, H, bins, src_bins, pts, ints, se3);
   if (m == "omnidir") return run<MODEL_OMNIDIR>(cam, W, H, bins, src_bins, pts, ints, se3);

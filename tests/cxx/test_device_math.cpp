@@ -21,6 +21,7 @@ static int check(const char* name, const double* intr, int ni, const double* dis
   double I[5] = {0, 0, 0, 0, 0}, D[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int i = 0; i < 5; i++) c.intr[i] = I[i] = i < ni ? intr[i] : 0.0;
   for (int i = 0; i < 8; i++) c.dist[i] = D[i] = i < nd ? dist[i] : 0.0;
+  cam_derive<double>(MODEL, c);  // (the constants a model derives from its coefficients on the host, as the library's make_cam does)
   std::mt19937_64 rng(1234 + MODEL);
   std::uniform_real_distribution<double> U(-1.0, 1.0);
   Proj proj;
