@@ -145,7 +145,7 @@ def kernel_source_hash():
     import hashlib
 
     h = hashlib.sha256()
-    names = ["nid_device.hpp", "nid_atan_table.hpp", "nid_log_table.hpp", "nid_multi.hpp", "nid_kernels.hpp", "nid_launch_impl.hpp", "nid_kernels_f64.hip", "nid_kernels_f64_exact.hip", "Makefile"]
+    names = ["nid_device.hpp", "nid_atan_table.hpp", "nid_log_table.hpp", "nid_multi.hpp", "nid_kernels.hpp", "nid_fused.hpp", "nid_launch_impl.hpp", "nid_kernels_f64.hip", "nid_kernels_f64_exact.hip", "nid_kernels_fused.hip", "Makefile"]
     for path in [os.path.join(CSRC_DIR, n) for n in names]:
         h.update(os.path.basename(path).encode())
         with open(path, "rb") as f:

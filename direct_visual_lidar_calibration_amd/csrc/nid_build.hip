@@ -1,7 +1,7 @@
 // nid_build.hip -- device-side construction of a handle's point records from a device-resident cloud:
 //   [view culling (nid_cull_kernels.hpp)] -> histogram column + Morton key per surviving point ->
 //   rocPRIM radix sort by (column group, Morton code) -> gather into Rec32 / Rec64.
-// This is the host bucketing of nidreg_create (nidreg.hip) moved onto the GPU, so that the reference's
+// This is the host bucketing of nidreg_create (nidreg_plan.hip) moved onto the GPU, so that the reference's
 // per-outer-iteration sequence  ViewCulling::cull -> new NIDCost  (visual_camera_calibration.cpp:201-206)
 // never round-trips the cloud through the host.  The record ORDER may differ from the host path (device
 // vs host atan2 rounding in the Morton key); the histogram does not (fixed point, order independent).
@@ -25,7 +25,7 @@ __device__ __forceinline__ int cast_int_dev(double d) {  // x86 cvttsd2si semant
 }
 
 // bin_points = max(0, min(bins - 1, int(intensity * bins))) (nid_cost.hpp:49, cost_calculator_nid.cpp:47) with the CALLER's bin
-// count; `lut` (nullable: bins > 256, nidreg.hip WideBins) then maps the occupied bins onto the compact range the kernels use
+// count; `lut` (nullable: bins > 256, nidreg_plan.hip WideBins) then maps the occupied bins onto the compact range the kernels use
 __device__ __forceinline__ int point_bin(double intensity, int Bsrc, const uint16_t* __restrict__ lut) {
   const int b = max(0, min(Bsrc - 1, cast_int_dev(intensity * double(Bsrc))));
   return lut ? int(lut[b]) : b;
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void k_build_bin_image(const unsigned char* __
     const double v = double(src[size_t(sy) * size_t(row_stride) + size_t(sx)]) / 255.0;
     b = max(0, min(B - 1, cast_int_dev(v * double(B))));
   }
-  if (lut) b = int(lut[b]);  // bins > 256: the occupied bins, compacted (nidreg.hip WideBins)
+  if (lut) b = int(lut[b]);  // bins > 256: the occupied bins, compacted (nidreg_plan.hip WideBins)
   dst[size_t(py >> 2) * size_t(pitch) * 4 + size_t(px) * 4 + size_t(py & 3)] = uint8_t(b);
 }
 }  // namespace
@@ -273,7 +273,7 @@ hipError_t build_bin_image_device(const void* d_src, int is_f64, long long row_s
   return hipGetLastError();
 }
 
-// which of the B bins the n device-resident values v occupy (bins > 256 on a device-resident cloud: nidreg.hip resolve_wide_bins)
+// which of the B bins the n device-resident values v occupy (bins > 256 on a device-resident cloud: nidreg_plan.hip resolve_wide_bins)
 hipError_t mark_bins_device(const double* d_v, long long n, int B, unsigned char* used_host) {
   unsigned char* d_used = nullptr;
   hipError_t e = hipMalloc(&d_used, size_t(B));

@@ -977,7 +977,7 @@ NID_HD void bspline_deriv2(real s, real* d) {
 // then adds exact zeros), so b'[a] = 6 bx[a] * U/36 needs no multiply of its own and bits(b'[a] * 6 by[b]) is the
 // integer weight bx by U (to_fixed_dn).  All of this arithmetic happens in the SUBNORMAL range, i.e. on the integer
 // grid of 2^-1074: the constants are k, 3k, 4k, 6k grid steps with k = round(2^frac / 36), so they are exact, the
-// fixed-point unit is U = 36k (within 18 of 2^frac; nidreg.hip fixed_unit) and no constant carries a rounding bias
+// fixed-point unit is U = 36k (within 18 of 2^frac; nidreg_internal.hpp fixed_unit) and no constant carries a rounding bias
 // into the histogram; each operation rounds to the grid (a few grid steps per weight after the multiplication by
 // 6 by <= 4 -- unbiased, deterministic, order independent; bound checked by tests/cxx/test_device_math.cpp).
 struct BsplineScale {

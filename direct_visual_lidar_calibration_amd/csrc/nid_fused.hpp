@@ -24,7 +24,7 @@
 // other evaluation of this process in flight there).  Another PROCESS running the same kernel on the same GPU could still
 // interleave two half-resident grids; the barrier therefore gives up after `timeout_ticks` of the 100 MHz wall clock, the
 // kernel ends without its completion tag, and the host re-runs the evaluation on the three-kernel route and stops using this
-// one for the handle (nidreg.hip eval_one).
+// one for the handle (nidreg_core.hip eval_one).
 #pragma once
 #include "nid_kernels.hpp"
 

@@ -355,14 +355,14 @@ constexpr int kWideThreads = NID_WIDE_THREADS;
 constexpr int kWideShift = 5;
 // Chunks and segments.  A chunk is one workgroup's slice [start, start + count) of the bucketed records; `group` is the
 // column group its first record belongs to.  Since round 4 the chunks of a table are EQUAL slices of the whole record array
-// (nidreg.hip split_even), so a chunk may run across column-group boundaries: the workgroup then works through it segment
+// (nidreg_plan.hip split_groups), so a chunk may run across column-group boundaries: the workgroup then works through it segment
 // by segment -- the records of one group each --, flushing (and re-zeroing) its histogram tile, or rebuilding its G tile,
 // at every boundary.  gend[g] = index one past the last record of group g (the groups' end offsets; empty groups repeat the
 // previous value and are skipped).  Everything about a segment is wave-uniform (scalar loads, scalar branches).
 // The segment loop costs registers (the hot loops sit at the 128-VGPR edge of four waves per SIMD) and ~3 VALU instructions
 // per point of re-materialised constants, so every point kernel exists twice: SEG = false is the straight-line kernel of
 // rounds 1-3 for tables whose chunks all lie inside one group (any cloud with equally full columns: the headline), SEG =
-// true the loop; the host picks per table (nidreg.hip).  A chunk holds at most kMaxSegs segments (the gradient kernel
+// true the loop; the host picks per table (nidreg_plan.hip).  A chunk holds at most kMaxSegs segments (the gradient kernel
 // stages the G columns of all of them in LDS up front).
 constexpr int kMaxSegs = 4;
 struct Segments {
@@ -559,7 +559,7 @@ __device__ __forceinline__ void spline_hist_body(
   stamp_end();
 }
 
-// LDS bytes spline_hist_body uses (nidreg.hip sizes lds_hist the same way)
+// LDS bytes spline_hist_body uses (nidreg_plan.hip sizes lds_hist the same way)
 __host__ __device__ __forceinline__ size_t spline_hist_lds_bytes(int B, int GW, int cshift) { return (size_t(GW) * size_t(B) * 8 << cshift) + size_t(GW) * 8 + 16; }
 
 // waves per SIMD the WIDE kernel is compiled for: two 8-wave workgroups per CU need <= 128 VGPRs; both the straight-line and
@@ -961,6 +961,7 @@ __device__ __forceinline__ void entropy_final_body(
   }
 }
 
+#endif  // NID_COMMON_KERNELS
 // NID_ENTROPY_COLS columns per workgroup of NID_ENTROPY_THREADS threads: thread (r = tid & 255, q = tid >> 8) takes row r of
 // columns 4q .. 4q+3, i.e. 4 loads and 4 logs per thread (with one 256-thread workgroup per 16 columns the 16 dependent log
 // chains of a wave ran at single-wave latency: 13.8 us); the quarter-row partials meet in LDS.
@@ -976,6 +977,7 @@ constexpr int kEntropyColsMax = NID_ENTROPY_COLS;
 constexpr int kEntropyThreads = NID_ENTROPY_THREADS;
 static_assert(kEntropyThreads % 256 == 0 && kEntropyThreads <= 1024 && kEntropyColsMax % (kEntropyThreads / 256) == 0, "k_entropy: thread (r, q) takes row r of columns q kPer ... q kPer + kPer - 1");
 constexpr int kEntropyWaves = kEntropyThreads / 64;
+#ifdef NID_COMMON_KERNELS
 template <bool MULTI>
 __global__ __launch_bounds__(kEntropyThreads) void k_entropy(
   u64* __restrict__ hist, int B, int CB, double inv_unit, long long* part_hj, u64* row_part, double* phi_q, double* hist_image_out, double* hist_points_out,
@@ -1008,7 +1010,7 @@ __global__ __launch_bounds__(kEntropyThreads) void k_entropy(
     tag = dyn.want_grad ? 0.0 : dyn.tag[pair];
     tail = (!dyn.want_grad || e.nchunks == 0) ? 1 : 0;  // a pair without points has no gradient workgroup to run the tail
   }
-  // double-buffered histogram: clear the buffer the NEXT evaluation accumulates into (nidreg.hip,
+  // double-buffered histogram: clear the buffer the NEXT evaluation accumulates into (nidreg_core.hip,
   // begin_histogram) -- ~0.5 MB of stores that replace a memset launch per evaluation
   if (zero_buf)
     for (long long k = (long long)j * kEntropyThreads + tid; k < zero_words; k += (long long)nblocks * kEntropyThreads) zero_buf[k] = 0;
@@ -1069,9 +1071,9 @@ __global__ __launch_bounds__(kEntropyThreads) void k_entropy(
 
 #endif  // NID_COMMON_KERNELS
 
-#ifdef NID_COMMON_KERNELS
+#ifdef NID_SHARD_KERNELS  // (defined by the one translation unit that launches them: nidreg_shard.hip)
 // ------------------------------------------------------------------------------------------
-// One pair spread over several GPUs by ONE host process (nidreg.hip ShardSet): the points are partitioned by
+// One pair spread over several GPUs by ONE host process (nidreg_internal.hpp ShardSet, nidreg_shard.hip): the points are partitioned by
 // their pose-independent histogram column -- GPU g owns a contiguous range of column groups, balanced by their point
 // counts -- so the shards' joint histograms have DISJOINT support: the "all-reduce of the 2-D histogram" is an all-gather of
 // columns, and since no two shards write the same word it needs no reduction at all -- plain stores.
@@ -1252,7 +1254,7 @@ __global__ __launch_bounds__(kEntropyThreads) void k_entropy_repl(
   }
 }
 
-#endif  // NID_COMMON_KERNELS
+#endif  // NID_SHARD_KERNELS
 
 // ------------------------------------------------------------------------------------------
 // pass B (SPLINE): gradient.  G[c][r] = coefA * phi(h[c][r] / S) + coefB * phi_q[r] with
@@ -1707,13 +1709,13 @@ __global__ __launch_bounds__(kThreads, grad_min_waves(MODEL, SEG, sizeof(Rec) ==
   }
 }
 
-#ifdef NID_COMMON_KERNELS
+#ifdef NID_FINAL_KERNEL  // (nidreg_core.hip: launch_grad_final)
 // standalone finalisation (only launched for an empty cloud, where k_spline_grad has no workgroups)
 __global__ __launch_bounds__(kThreads) void k_grad_final(const double* partials, int nblocks, double qx, double qy, double qz, double qw, double* out, double* out_host, double tag) {
   __shared__ double s_red[kWaves * 12];
   grad_final_body<kThreads>(partials, nblocks, qx, qy, qz, qw, out, out_host, tag, s_red);
 }
-#endif  // NID_COMMON_KERNELS
+#endif  // NID_FINAL_KERNEL
 
 // GenericCameraBase::project on the device (test / utility path): uv and the 2x3 Jacobian
 template <int MODEL, typename real>

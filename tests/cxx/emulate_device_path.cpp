@@ -21,7 +21,7 @@ using namespace nidreg;
 template <int MODEL>
 static int run(const CamParams<double>& cam, int W, int H, int B, const std::vector<uint8_t>& src_bins, const std::vector<double>& pts, const std::vector<double>& ints, const double* se3) {
   const int64_t N = int64_t(ints.size());
-  // ---- padded, strip-tiled bin image (nidreg.hip create: 1 px left / top, >= 2 right / bottom, edge replicated)
+  // ---- padded, strip-tiled bin image (nidreg_plan.hip create_impl: 1 px left / top, >= 2 right / bottom, edge replicated)
   const int pitch = ((W + 8) + 3) & ~3, nstrips = (H + 3 + 3) / 4 + 1;
   std::vector<uint8_t> img(size_t(pitch) * 4 * nstrips + 64, 0);
   for (int py = 0; py < nstrips * 4; py++)
@@ -29,7 +29,7 @@ static int run(const CamParams<double>& cam, int W, int H, int B, const std::vec
       const int sy = std::min(std::max(py - 1, 0), H - 1), sx = std::min(std::max(px - 1, 0), W - 1);
       img[size_t(py >> 2) * pitch * 4 + size_t(px) * 4 + (py & 3)] = src_bins[size_t(sy) * W + sx];
     }
-  // ---- pose: R from the UN-normalised quaternion exactly as p + 2 w (v x p) + 2 v x (v x p) expands (nidreg.hip pose_from_se3)
+  // ---- pose: R from the UN-normalised quaternion exactly as p + 2 w (v x p) + 2 v x (v x p) expands (nidreg_plan.hip pose_from_se3)
   const double qx = se3[0], qy = se3[1], qz = se3[2], qw = se3[3];
   PoseParams<double> pose;
   pose.R[0] = 1 - 2 * (qy * qy + qz * qz), pose.R[1] = 2 * (qx * qy - qz * qw), pose.R[2] = 2 * (qx * qz + qy * qw);
@@ -39,7 +39,7 @@ static int run(const CamParams<double>& cam, int W, int H, int B, const std::vec
   int nbits = 1;
   while ((int64_t(1) << nbits) <= N) nbits++;
   const int frac = std::min(40, 62 - nbits);
-  const double unit = 36.0 * std::rint(std::ldexp(1.0, frac) / 36.0), inv_unit = 1.0 / unit;  // nidreg.hip fixed_unit
+  const double unit = 36.0 * std::rint(std::ldexp(1.0, frac) / 36.0), inv_unit = 1.0 / unit;  // nidreg_plan.hip fixed_unit
   const BsplineScale KS = bspline_scale(std::ldexp(unit / 36.0, -1074));
 
   // ---- pass A (k_spline_hist body): fixed-point joint histogram [bin_points][bin_image], inlier count

@@ -1,5 +1,5 @@
 // TEST INFRASTRUCTURE: a stand-in for librccl.so exporting the six entry points libnidreg.so resolves with dlsym
-// (csrc/nidreg.hip RcclApi), so that the in-library point-sharded evaluation (nidreg_shard_comm_init -> nidreg_eval: histogram ->
+// (csrc/nidreg_rccl.hip RcclApi), so that the in-library point-sharded evaluation (nidreg_shard_comm_init -> nidreg_eval: histogram ->
 // ncclAllReduce(int64) -> entropy -> gradient -> ncclAllReduce(f64 x 7)) can run with TWO ranks -- two processes -- on a box
 // with ONE GPU, where RCCL itself refuses two ranks on one device.  The "collective" goes through POSIX shared memory: every rank
 // drains its stream, copies its buffer to its slot, meets the others at a barrier, reduces all slots in rank order and copies the

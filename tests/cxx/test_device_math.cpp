@@ -174,7 +174,7 @@ int main() {
     std::uniform_real_distribution<double> U(0.0, 1.0);
     double worst = 0, worst_sum = 0;
     for (int frac = 34; frac <= 40; frac += 2) {
-      // the fixed-point unit is U = 36 round(2^frac / 36) grid steps (nidreg.hip fixed_unit), so that k = U/36, 3k, 4k, 6k are integers
+      // the fixed-point unit is U = 36 round(2^frac / 36) grid steps (nidreg_internal.hpp fixed_unit), so that k = U/36, 3k, 4k, 6k are integers
       const double unit = 36.0 * std::rint(std::ldexp(1.0, frac) / 36.0), dn = std::ldexp(unit, -1074);
       const BsplineScale KS = bspline_scale(std::ldexp(unit / 36.0, -1074));
       if (KS.k46 != std::ldexp(unit / 9.0, -1074) || KS.k05 != std::ldexp(unit / 12.0, -1074) || KS.k1 != std::ldexp(unit / 6.0, -1074)) bad++;  // exact constants

@@ -1136,7 +1136,7 @@ def test_chunks_across_column_groups_match_one_group_per_chunk(model, monkeypatc
 
 def test_destroyed_handles_leave_their_stream_and_result_blocks_to_the_next():
     """The reference builds a new NIDCost per pair in every outer iteration (visual_camera_calibration.cpp:199-208): a destroyed
-    handle's stream and host-mapped result blocks are kept for the next handle on the device (nidreg.hip ResourcePool; creating
+    handle's stream and host-mapped result blocks are kept for the next handle on the device (nidreg_core.hip ResourcePool; creating
     them anew cost 0.9 of the 1.0 ms a small handle took).  A recycled block must not leak its previous owner's results or
     completion tags: handles of different clouds and bin counts created, evaluated (synchronously, through submit / wait and as
     a multi-pair grid) and destroyed in an interleaved order give what fresh handles gave; nidreg_trim() empties the lists."""

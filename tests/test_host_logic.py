@@ -143,7 +143,7 @@ def test_bench_helpers_algorithmic_bytes_labels_and_committed_traffic():
 
 
 def test_column_group_partition_of_a_sharded_pair():
-    """The cut of a pair's column groups over n GPUs (csrc/nidreg.hip partition_groups, through a test hook of the library --
+    """The cut of a pair's column groups over n GPUs (csrc/nidreg_shard.hip partition_groups, through a test hook of the library --
     host arithmetic, no GPU): contiguous, exhaustive, balanced to within one group, well defined for empty clouds and more
     GPUs than groups."""
     import ctypes
@@ -179,7 +179,7 @@ def test_column_group_partition_of_a_sharded_pair():
 
 
 def test_chunk_tables_fit_one_round_of_workgroups():
-    """The chunk table of a pass (csrc/nidreg.hip split_groups, through a test hook -- host arithmetic, no GPU).  Since round 4 a
+    """The chunk table of a pass (csrc/nidreg_plan.hip split_groups, through a test hook -- host arithmetic, no GPU).  Since round 4 a
     chunk is a contiguous range of records that may run across column-group boundaries (the workgroup flushes its tile at each
     one), and the table minimises the longest chunk under the cost model  cost = sum over segments of (overhead + records):
     every record in exactly one chunk, `group` = the group of the chunk's first record, never more chunks than the round
@@ -258,7 +258,7 @@ def test_chunk_tables_fit_one_round_of_workgroups():
 
 
 def test_small_clouds_get_fewer_chunks_than_a_full_round():
-    """The number of chunks of a pass (csrc/nidreg.hip round_chunks / snap_to_groups, through a test hook): CUs/2 at 100k points,
+    """The number of chunks of a pass (csrc/nidreg_plan.hip round_chunks / snap_to_groups, through a test hook): CUs/2 at 100k points,
     growing with the square root of the cloud, the full round of co-resident workgroups from 6.4M points on; whole multiples of
     the non-empty column groups and never fewer chunks than groups (profiles/archive/r04i_small_cloud_sweep.jsonl: what each of
     these choices was measured against)."""

@@ -1,7 +1,7 @@
 """Register / scratch budget of the hot kernels, read from the gfx950 assembly hipcc emits for the double-precision
 translation unit (no GPU needed: hipcc cross-compiles).  The two spline passes of the headline configuration run 16 waves
 per CU -- two 8-wave histogram workgroups, four 4-wave gradient workgroups -- which needs <= 128 VGPRs per lane and no
-scratch; the chunk tables are sized from that occupancy (nidreg.hip), so a change that pushes a kernel over the limit
+scratch; the chunk tables are sized from that occupancy (nidreg_plan.hip), so a change that pushes a kernel over the limit
 silently costs a quarter of the latency hiding ("forcing 4 waves/EU ... +55 %")."""
 import os
 import re

@@ -46,7 +46,7 @@ def test_rccl_program_compiles_and_links():
 
     lib = ctypes.CDLL(STUB)
     for sym in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclCommCount", "ncclAllReduce", "ncclGetErrorString"):
-        assert hasattr(lib, sym)  # exactly what csrc/nidreg.hip RcclApi resolves
+        assert hasattr(lib, sym)  # exactly what csrc/nidreg_rccl.hip RcclApi resolves
 
 
 def test_library_does_not_link_rccl():

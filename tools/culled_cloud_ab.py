@@ -3,7 +3,7 @@
 culls before every inner solve).  The rank equalisation makes the columns of the whole cloud equally full; the culled
 subset's columns are not.  Builds the cost object with nidreg_create_from_cloud (device-resident cull + build) with chunk
 tables of one column group per chunk (NIDREG_MAX_SEGS=1: the constraint of rounds 1-3) and with chunks that may run across
-groups (round 4, csrc/nidreg.hip split_groups), prints table sizes, microseconds per evaluation, per-kernel event times and
+groups (round 4, csrc/nidreg_plan.hip split_groups), prints table sizes, microseconds per evaluation, per-kernel event times and
 nanoseconds per kept point.
 `skew`: the pushed-out copy carries darker surfaces (intensity^2) and the intensities are rank-equalised over the WHOLE cloud,
 as preprocess.cpp:464-473 does for a whole map: the culled subset's histogram columns are then far from equally full.

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Small clouds (configs[0] is 100k points, VGA pinhole, 16 bins): microseconds per synchronous cost+Jacobian evaluation
-against the number of chunks -- the rule that sizes chunk tables (nidreg.hip target_chunks) is set from this table.
+against the number of chunks -- the rule that sizes chunk tables (nidreg_plan.hip round_chunks) is set from this table.
 Usage: small_cloud_sweep.py [bins,bins,...] [points,points,...] [target_blocks,...] [nearest]   (target_blocks 0 = the library's rule;
 "nearest": the NEAREST twin, CostCalculatorNID::calculate, cost only)"""
 import json
