@@ -434,7 +434,7 @@ def main():
         kt = {key: float(np.mean(v)) for key, v in acc.items()}
         whole_ms = float(np.mean(whole))
         n_local = pts.shape[0]
-        build = _lib.kernel_source_hash()
+        build = _lib.library_kernel_build()  # (what the loaded library was built from: a committed summary matches it or is not quoted)
         kstats = _matching_kernel_stats(n_local, scene.width, scene.height, args.bins, args.precision, build, camera=args.camera)
         ks = {k_: v["avg_ns"] * 1e-6 for k_, v in kstats["kernels"].items()} if kstats else {}
         eval_bytes = algorithmic_bytes(n_local, scene.width, scene.height, args.bins)
@@ -708,7 +708,7 @@ def main():
                                 "frac": round(ab / (msl * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
                 # this camera model's kernels from the committed rocprofv3 passes of THIS kernel build (profiles/*_<camera>_*_kernel_stats.json,
                 # *_traffic.json; tools/round_pass.sh stats= / pmc=): average kernel durations, VALU wave-instructions per point
-                bld = _lib.kernel_source_hash()
+                bld = _lib.library_kernel_build()
                 ks_ = _matching_kernel_stats(int(s_.points.shape[0]), s_.width, s_.height, bins_, args.precision, bld, camera=camera)
                 if ks_:
                     configs[key]["kernel_ms"] = {k_: round(v["avg_ns"] * 1e-6, 5) for k_, v in ks_["kernels"].items() if k_ in ("k_spline_hist", "k_entropy", "k_spline_grad")}

@@ -67,7 +67,7 @@ EXPORTS = [
     "nidreg_shard_entropy", "nidreg_shard_grad", "nidreg_shard_finish", "nidreg_set_timing", "nidreg_get_timing", "nidreg_get_info", "nidreg_last_error",
     "nidreg_version", "nidreg_colorizer_create", "nidreg_colorizer_update", "nidreg_colorizer_device_colors", "nidreg_colorizer_destroy", "nidreg_generate_lidar_image",
     "nidreg_equalize_intensities", "nidreg_num_shards", "nidreg_shard_devices", "nidreg_trim", "nidreg_eval_batch", "nidreg_submit", "nidreg_submit_iso", "nidreg_wait", "nidreg_eval_pipelined",
-    "nidreg_estimate_camera_fov", "nidreg_rccl_unique_id", "nidreg_shard_comm_init", "nidreg_shard_attach_rccl",
+    "nidreg_estimate_camera_fov", "nidreg_rccl_unique_id", "nidreg_shard_comm_init", "nidreg_shard_attach_rccl", "nidreg_kernel_build",
 ]
 
 _lib = None
@@ -151,6 +151,23 @@ def kernel_source_hash():
         with open(path, "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
+
+
+def library_kernel_build():
+    """The kernel-source hash libnidreg.so was BUILT from (nidreg_kernel_build): equals kernel_source_hash() unless the library is
+    stale against the sources next to it."""
+    lib = load()
+    lib.nidreg_kernel_build.restype = ctypes.c_char_p
+    return lib.nidreg_kernel_build().decode()
+
+
+def stamp_or_refuse():
+    """For the measurement tools: the hash to stamp a summary with -- refuses (SystemExit) when the loaded library was not built from the
+    sources on disk, because the summary would then be attributed to kernels that did not produce it."""
+    built, tree = library_kernel_build(), kernel_source_hash()
+    if built != tree:
+        raise SystemExit(f"refusing to stamp: libnidreg.so was built from kernel sources {built}, the tree holds {tree} (rebuild, then measure again)")
+    return built
 
 
 def last_error():

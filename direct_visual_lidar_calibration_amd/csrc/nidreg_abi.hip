@@ -3,7 +3,11 @@
 extern "C" {
 
 const char* nidreg_last_error(void) { return g_last_error.c_str(); }
-const char* nidreg_version(void) { return "nidreg 0.5 (gfx950, hand-written HIP)"; }
+const char* nidreg_version(void) { return "nidreg 0.6 (gfx950, hand-written HIP)"; }
+#ifndef NIDREG_KERNEL_BUILD
+#define NIDREG_KERNEL_BUILD "unstamped"
+#endif
+const char* nidreg_kernel_build(void) { return NIDREG_KERNEL_BUILD; }
 
 int nidreg_model_from_name(const char* name, int* num_intrinsics, int* num_distortion) {
   if (!name) return -1;

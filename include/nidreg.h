@@ -369,6 +369,10 @@ int nidreg_get_info(nidreg_handle* h, int64_t* info8);
 
 const char* nidreg_last_error(void);
 const char* nidreg_version(void);
+/* 16 hex digits: sha256 over the kernel sources (csrc/nid_*.hpp, nid_kernels_*.hip, Makefile) this library was BUILT from.  The
+ * measurement tooling stamps rocprofv3 summaries with it and refuses to stamp when it differs from the sources next to the library
+ * (tools/kernel_stats_json.py, tools/traffic_from_pmc.py): a summary can then only ever describe the kernels that produced it. */
+const char* nidreg_kernel_build(void);
 
 #ifdef __cplusplus
 }

@@ -82,3 +82,15 @@ def test_model_table_and_no_device_error():
         cam = nid.create_camera("plumb_bob", [100, 100, 50, 50], [])
         with pytest.raises(RuntimeError, match="no HIP device"):
             nid.NIDCost(cam, np.zeros((100, 100)), np.zeros((4, 4)), np.zeros(4), 16)
+
+
+def test_library_carries_the_hash_of_the_kernel_sources_it_was_built_from(monkeypatch):
+    """nidreg_kernel_build() = sha256 over the kernel sources at build time; the measurement tools stamp rocprofv3 summaries with it
+    and REFUSE when the library is stale against the sources on disk (a summary re-stamped by hand)."""
+    from direct_visual_lidar_calibration_amd import _lib
+
+    built = _lib.library_kernel_build()
+    assert len(built) == 16 and built == _lib.kernel_source_hash() == _lib.stamp_or_refuse()
+    monkeypatch.setattr(_lib, "kernel_source_hash", lambda: "0123456789abcdef")
+    with pytest.raises(SystemExit, match="refusing to stamp"):
+        _lib.stamp_or_refuse()

@@ -31,6 +31,6 @@ for r in csv.DictReader(open(src)):
     k["instantiations"].append({"name": r["Name"][:160], "calls": calls, "avg_ns": float(r["AverageNs"])})
 for k in kernels.values():
     k["avg_ns"] = k["total_ns"] / max(k["calls"], 1)
-json.dump({"source": src, "note": note, "kernel_build": _lib.kernel_source_hash(), "workload": dict(points=points, width=width, height=height, bins=bins, precision=precision, camera=camera), "kernels": kernels},
+json.dump({"source": src, "note": note, "kernel_build": _lib.stamp_or_refuse(), "workload": dict(points=points, width=width, height=height, bins=bins, precision=precision, camera=camera), "kernels": kernels},
           open(dst, "w"), indent=1)
 print(json.dumps({k: round(v["avg_ns"] / 1e3, 2) for k, v in kernels.items()}))

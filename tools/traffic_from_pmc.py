@@ -40,6 +40,6 @@ for k, v in kernels.items():
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from direct_visual_lidar_calibration_amd import _lib  # noqa: E402
 
-json.dump({"source": src, "kernel_build": _lib.kernel_source_hash(), "workload": dict(points=points, width=width, height=height, bins=bins, precision=precision, camera=sys.argv[8] if len(sys.argv) > 8 else "pinhole_1080p"), "kernels": out},
+json.dump({"source": src, "kernel_build": _lib.stamp_or_refuse(), "workload": dict(points=points, width=width, height=height, bins=bins, precision=precision, camera=sys.argv[8] if len(sys.argv) > 8 else "pinhole_1080p"), "kernels": out},
           open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1))
