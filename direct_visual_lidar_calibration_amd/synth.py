@@ -33,6 +33,9 @@ CONFIG_CAMERAS = {
     "equirect_2k": ("equirectangular", [2048.0, 2048.0], [], 2048, 2048),
     "omnidir_2k": ("omnidir", [600.0, 600.0, 1024.0, 1024.0, 1.0], [-0.02, 0.003, 1e-4, -2e-4], 2048, 2048),
     "fisheye_1080p": ("fisheye", [800.0, 800.0, 960.0, 540.0], [-0.01, 0.002, -1e-4, 1e-5], 1920, 1080),
+    # the two models no BASELINE config names, for their kernel-stats lines
+    "atan_1080p": ("atan", [1100.0, 1100.0, 960.0, 540.0], [0.6], 1920, 1080),
+    "rational_1080p": ("rational_polynomial", [1100.0, 1100.0, 960.0, 540.0], [0.05, -0.02, 1e-4, -2e-4, 0.01, 0.03, -0.01, 0.002], 1920, 1080),
 }
 
 

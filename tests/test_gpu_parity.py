@@ -1674,10 +1674,10 @@ def test_fused_single_launch_other_shapes_and_its_fallback(monkeypatch):
     f, _, _ = both(s, pts64, 16, 1)
     assert f.info()["float32_records"] == 0
     f.close()
-    big = synth.make_scene(CAMERAS["plumb_bob"], num_points=700_000, seed=33)
+    big = synth.make_scene(CAMERAS["plumb_bob"], num_points=700_000, seed=33, device="cuda:0")
     f, _, _ = both(big, big.points, 16, 1, expect_full=0)
     f.close()
-    huge = synth.make_scene(CAMERAS["plumb_bob"], num_points=3_000_000, seed=34)
+    huge = synth.make_scene(CAMERAS["plumb_bob"], num_points=3_000_000, seed=34, device="cuda:0")
     f, _, _ = both(huge, huge.points, 16, 0)
     f.close()
     f, _, _ = both(s, s.points, 64, 0)  # 64 bins: not a small table
