@@ -489,8 +489,22 @@ __device__ __forceinline__ void spline_hist_body(
       real us[kUnroll], vs[kUnroll];
       bool ins[kUnroll];
       bool all_in = true;
+      // Round 6: a slot of the batch that lies past the end of the segment for EVERY lane of this wave is skipped (a scalar compare on
+      // the wave's first slot index).  The last batch of a chunk used to cost a full batch whatever it held -- all four slots run the
+      // same instructions on clamped records and add exact zeros --: a fifth of the WIDE kernel's point loop at 1.25M points / 256 bins
+      // (2441 records per workgroup = one full batch + 393 records: 9.5 -> 6 us), and slot 3 of seven waves out of eight in the last batch of
+      // the 10M-point headline (9766 = 4 x 2048 + 1574).  The skipped slots contributed zeros: the histogram's bits are unchanged.
+      bool live[kUnroll];
+#pragma unroll
+      for (int k = 0; k < kUnroll; k++) live[k] = !GUARDED || uint32_t(__builtin_amdgcn_readfirstlane(int(base + uint32_t(k) * kT + tid))) < cnt;
 #pragma unroll
       for (int k = 0; k < kUnroll; k++) {
+        if (!live[k]) {
+          us[k] = vs[k] = real(0);
+          ins[k] = false;
+          all_in = false;  // (the batch takes the per-lane-constant tap path below, which skips this slot)
+          continue;
+        }
         const bool valid = !GUARDED || base + uint32_t(k) * kT + tid < cnt;
         real cx, cy, cz;
         transform_fma<real>(pose, xs[k], ys[k], zs[k], cx, cy, cz);
@@ -510,6 +524,7 @@ __device__ __forceinline__ void spline_hist_body(
       } else {
 #pragma unroll
         for (int k = 0; k < kUnroll; k++) {
+          if (!live[k]) continue;
           // an outlier (or a slot past the end of the segment) runs the same instructions with its knot at pixel (0,0)
           // and zeroed constants: it adds exact zeros
           const bool in = ins[k];

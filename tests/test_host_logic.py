@@ -289,7 +289,7 @@ def test_small_clouds_get_fewer_chunks_than_a_full_round():
 
 
 def test_chunk_rule_lands_near_the_best_measured_count():
-    """The rule against the sweep it was drawn through (profiles/r05z_small_cloud_sweep_b16.jsonl: microseconds per synchronous
+    """The rule against the sweep it was drawn through (profiles/archive/r05z_small_cloud_sweep_b16.jsonl: microseconds per synchronous
     cost+Jacobian evaluation on an MI355X with the number of chunks forced, 100k ... 6.4M points, 16 bins, this round's kernels;
     round 4's sweep of the earlier kernels: profiles/archive/r04i_small_cloud_sweep.jsonl): at the rule's count the measured time
     -- interpolated between the two nearest measured counts -- is within 5 % of the best measured one."""
@@ -301,7 +301,7 @@ def test_chunk_rule_lands_near_the_best_measured_count():
 
     lib = _lib.load()
     lib.nidreg_debug_round_chunks.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.c_int]
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05z_small_cloud_sweep_b16.jsonl")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "archive", "r05z_small_cloud_sweep_b16.jsonl")
     rows = [json.loads(line) for line in open(path)]
     assert len(rows) == 11
     worst = 0.0
