@@ -553,7 +553,7 @@ int group_eval_iso(MultiGroup* g, const double* T, double* costs) {
 }
 
 // handles[0..n) all distinct, compatible and on one device?
-// Measured on the same clouds in one harness (tools/omp_pairs.cpp on the 10M-point scene split into n pairs,
+// Measured on the same clouds in one harness (tools/archive/omp_pairs.cpp on the 10M-point scene split into n pairs,
 // profiles/archive/r03q_omp_pairs.jsonl), microseconds per evaluation of all pairs: single grid 152 / 149 / 172 at 2 / 4 / 8
 // pairs, per-pair launches 154 / 198 / 274, one OpenMP caller per pair 173 / 215 / 282.  (Until the chunk tables were made
 // to fit one round -- split_groups -- the single grid took 191 / 185 / 178 and two or three pairs ran as per-pair launches.)
