@@ -198,6 +198,9 @@ __device__ __forceinline__ void grad_final_body(const double* partials, int nblo
   double acc[12];
 #pragma unroll
   for (int k = 0; k < 12; k++) acc[k] = 0.0;
+  // (Round 6 tried four rounds of these 12 loads in flight per thread -- the full round's 1024 partials take four dependent trips to
+  // the coherence point here --: the finalising workgroup's stage 4.9 -> 4.2 us at 10M points, the gradient kernel 73.9 -> 73.4 us,
+  // and +1 us on a 100k-point evaluation (the predicated rounds still issue); profiles/r06_experiments.md section 5.  One round per trip.)
   for (int b = tid; b < nblocks; b += kT) {
 #pragma unroll
     for (int k = 0; k < 12; k++) acc[k] += COH ? __hip_atomic_load(&partials[size_t(k) * nblocks + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : partials[size_t(k) * nblocks + b];
@@ -473,10 +476,7 @@ __device__ __forceinline__ void spline_hist_body(
     // kUnroll records per thread are fetched before any of them is processed (memory-level parallelism); the
     // geometry of all of them comes first, then -- wave-uniform choice -- the tap code with uniform or per-lane
     // constants.  Both are branch-free per point, so the scheduler interleaves the kUnroll independent points.
-    // GUARDED = the batch may reach past the end of the segment (clamped loads, per-slot validity).  -DNID_EXP_NOCLAMP runs
-    // every full batch without the checks and only the last one with them, as the gradient loop does: no gain HERE (the
-    // compiler restructures the two tap paths: 927 against 887 instructions per batch; 51.2-52.1 us either way,
-    // profiles/archive/r04g_variants.txt)
+    // GUARDED = the batch may reach past the end of the segment (clamped loads, per-slot validity): the last batch of a segment only
     auto batch = [&](uint32_t base, auto guarded) {
       constexpr bool GUARDED = decltype(guarded)::value;
       set_progress_priority(prio, seg.pos - ch.start + base, ch.count);
@@ -537,15 +537,15 @@ __device__ __forceinline__ void spline_hist_body(
         }
       }
     };
-#ifdef NID_EXP_NOCLAMP
+    // every full batch without the bounds checks (branch-free: the four points interleave), the last one with them and with the
+    // per-wave skip of dead slots.  (Until round 5 one guarded form ran every batch -- the split alone measured the same at 10M points,
+    // profiles/archive/r04g_variants.txt; putting the dead-slot branches into EVERY batch cost the fisheye kernel 6 %: its four atan2
+    // chains no longer interleaved, 164 -> 173 instructions per point, profiles/r06_experiments.md.)
     {
       uint32_t base = 0;
       for (; base + uint32_t(kT * kUnroll) <= cnt; base += kT * kUnroll) batch(base, std::false_type());
       if (base < cnt) batch(base, std::true_type());
     }
-#else
-    for (uint32_t base = 0; base < cnt; base += kT * kUnroll) batch(base, std::true_type());
-#endif
     __syncthreads();
     stamp_stage(2);
 
@@ -746,6 +746,9 @@ __global__ __launch_bounds__(kThreads, nearest_min_waves(MODEL, std::is_same<rea
     // first pixel gather, and the gathers before the first LDS add: every memory latency of an iteration is paid once.
     // (Until round 3 the four points ran one after the other, each through its own gather: 40 % of the wave cycles waited
     // on memory, profiles/archive/r04a_pmc_summary_nearest.txt.)  No progress priority here (profiles/archive/r02g_kernel_gaps.txt).
+    // (Round 6 tried the SPLINE kernels' split here -- full batches without the bounds checks, a guarded last one --: two copies of
+    // the body under this kernel's register bounds spill: plumb_bob 60 -> 98 us per evaluation, fisheye 53 -> 57, omnidir 66 -> 72,
+    // equirectangular 87 -> 85; profiles/r06_experiments.md.  One guarded loop.)
     for (uint32_t base = 0; base < cnt; base += kThreads * kUnroll) {
       real xs[kUnroll], ys[kUnroll], zs[kUnroll];
       uint32_t bins_[kUnroll];
