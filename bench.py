@@ -466,8 +466,17 @@ def main():
                 t_ms = ks.get(k_) or {"k_spline_hist": kt.get("hist"), "k_spline_grad": kt.get("grad")}.get(k_)
                 if act and t_ms:
                     busy[k_] = round(act / (256 * t_ms * 1e-3 * SHADER_GHZ * 1e9), 3)
+            # ... and over the mean LIFETIME of a wave instead of the kernel's duration (SQ_WAVE_CYCLES / SQ_WAVES, quad-cycles like
+            # SQ_ACTIVE_INST_VALU): what the SIMDs do while the point loops run -- the duration also holds launch, prologue, the
+            # staggered end and the finalising workgroup (profiles/r06_experiments.md section 5)
+            alive = {}
+            for k_ in insts:
+                c_ = pk[k_].get("counters", {})
+                if c_.get("SQ_WAVE_CYCLES") and c_.get("SQ_WAVES") and c_.get("SQ_ACTIVE_INST_VALU"):
+                    alive[k_] = round(c_["SQ_ACTIVE_INST_VALU"] / NUM_SIMDS / (c_["SQ_WAVE_CYCLES"] / c_["SQ_WAVES"]), 3)
             valu = {
                 "busy_frac": busy or None,
+                "busy_frac_while_waves_alive": alive or None,
                 "insts_per_point": {k_: round(v * 64.0 / n_local, 1) for k_, v in insts.items()},
                 "issue_floor_us": {k_: round(v, 2) for k_, v in floor_us.items()},
                 "frac_of_evaluation": round(sum(floor_us.values()) / (ms_per_step * 1e3), 3),
@@ -488,7 +497,11 @@ def main():
             "kernel_achieved": round(kernel_achieved, 1),
             "kernel_frac": round(kernel_achieved / HBM_PEAK_GBS, 4),
             "kernel_ms_used": round(dom_ms, 4),
-            "kernel_ms_source": "HIP events on the handle's stream around the launch, this run (the markers' few us included)",
+            "kernel_ms_source": "HIP events on the handle's stream around the launch, this run (the markers' few us included: see empty_event_interval_ms)",
+            # the interval between two event records with NO work between them, same stream, same evaluations (the `memset` slot: the
+            # histogram buffer is pre-cleared by the previous evaluation's kernels, nothing is launched there): what a marker pair costs
+            # in this run -- the event figure of a long kernel exceeds its rocprofv3 duration by about this much
+            "empty_event_interval_ms": round(kt.get("memset", 0.0), 4),
             "kernel_frac_profiled": round(launch_bytes / (ks[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dom in ks else None,
             "kernel_frac_profiled_source": (kstats["_file"] + " (rocprofv3 --kernel-trace --stats average of the bench command, measured on this kernel build)") if dom in ks else None,
             "achieved_side": "algorithmic bytes / time; the counter figures (`traffic`) are fabric side: L2 -> fabric requests, Infinity-Cache hits included (the 160 MB record array fits the 256 MiB cache)",
