@@ -803,7 +803,7 @@ def main():
         blocks2 = max(3, args.blocks // 5)
 
         t_legs = time.time()
-        leg_budget_s = float(os.environ.get("NIDREG_BENCH_LEG_BUDGET_S", "600"))
+        leg_budget_s = float(os.environ.get("NIDREG_BENCH_LEG_BUDGET_S", "300"))
 
         def leg(name, fn):
             # every optional case is bounded: a case that fails (an exchange that times out: NIDREG_SHARD_TIMEOUT_MS, one
