@@ -138,6 +138,44 @@ def relaunch_one_process_per_gpu(n):
     return subprocess.call(cmd, env=env)
 
 
+def single_process_sharded_leg(world, one_gpu, ps, steps2, blocks2, bins, precision):
+    """The single-process route of the C ABI (what an unchanged one-process calibrate uses): ONE process drives every GPU of the
+    job -- desc.device_ids, cross-device stores and in-kernel waits.  Runs in a CHILD process of rank 0 (`bench.py
+    --single-process-leg <json>`): the route has never met two physical GPUs, and a GPU memory fault there aborts the process that
+    caused it -- which must not be the one that owes the driver its JSON line."""
+    import numpy as np
+
+    from direct_visual_lidar_calibration_amd import nid, synth
+
+    rng = np.random.default_rng(4321)
+    out = {}
+    if os.environ.get("NIDREG_BENCH_TEST_CRASH_CHILD"):  # test hook (tests/test_bench_launch.py): die the way a GPU memory fault kills a process
+        os.abort()
+    # (the first time this route meets two physical GPUs should say WHICH exchange path fails, if one does: every ordered
+    # pair of shards ping-pongs once at creation, 200 ms timeout, report on stderr)
+    os.environ.setdefault("NIDREG_SHARD_SELFTEST", "1")
+    devs = [0] * world if one_gpu else list(range(world))
+    for camera, n_points, key, seed in (("equirect_2k", int(10_000_000 * ps), "configs2", 20250523 + 3), ("pinhole_4k", int(50_000_000 * ps), "configs4", 20250523 + 5)):
+        s = synth.make_scene(camera, num_points=n_points, seed=seed, device="cuda:0")
+        pr = nid.create_camera(s.model, s.intrinsics, s.distortion)
+        t1 = time.perf_counter()
+        c = nid.NIDCost(pr, s.image_f64, s.points, s.intensities, bins, precision=precision, devices=devs)
+        setup = time.perf_counter() - t1
+        ps_ = np.ascontiguousarray([synth.random_pose_near(s.T_camera_lidar_true, rng) for _ in range(steps2)])
+        c.eval_batch(ps_[:3])
+        secs = []
+        for _ in range(blocks2):
+            t1 = time.perf_counter()
+            c.eval_batch(ps_)
+            secs.append(time.perf_counter() - t1)
+        med = float(np.median(secs)) / steps2
+        out[key] = {"value": round(1.0 / med, 2), "unit": "evals/s", "ms_per_step": round(1e3 * med, 5), "points": n_points, "devices": c.shard_devices(), "setup_s": round(setup, 3)}
+        c.close()
+        del s
+    out["route"] = "one process, desc.device_ids: the cloud cut along the histogram column, every GPU stores its columns of the integer histogram into every other GPU's replica inside nidreg_eval (one exchange), host sums the gradient partials"
+    return out
+
+
 POSE_POOL = 4096  # distinct evaluation poses a timed window draws from (SURVEY 8d: >= 50 evaluations at DISTINCT poses)
 
 
@@ -172,7 +210,19 @@ def main():
     ap.add_argument("--no-extra-legs", action="store_true", help="N>1: skip the multi_gpu.* cases (configs[2], [3], [4], single-process route)")
     ap.add_argument("--no-config-legs", action="store_true", help="N=1: skip the other BASELINE configs and the view-culled form of the workload")
     ap.add_argument("--extra-points-scale", type=float, default=1.0, help="scale the point counts of the multi_gpu.* cases (tests)")
+    ap.add_argument("--single-process-leg", default=None, help=argparse.SUPPRESS)  # internal: the child process of multi_gpu.single_process_sharded
     args = ap.parse_args()
+
+    if args.single_process_leg:
+        if os.environ.get("NIDREG_BENCH_ONE_GPU"):
+            os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+        kw = json.loads(args.single_process_leg)
+        sys.stdout.flush()
+        real = os.dup(1)
+        os.dup2(2, 1)  # (library / runtime chatter goes to stderr: stdout carries the leg's one JSON object)
+        res = single_process_sharded_leg(**kw)
+        os.write(real, (json.dumps(res) + "\n").encode())
+        return
 
     if os.environ.get("NIDREG_BENCH_ONE_GPU"):
         # test hook: co-located shards wait for each other inside kernels and must not share an in-order hardware queue
@@ -863,34 +913,22 @@ def main():
         if backend == "nccl" and os.environ.get("NIDREG_BENCH_INLIB_RCCL"):
             leg("shard_configs2_inlib", lambda: shard_leg("equirect_2k", int(10_000_000 * ps), "BASELINE configs[2]: 10M-pt equirectangular, points sharded, RCCL inside the library", 20250523 + 3, inlib=True))
 
-        # the single-process route of the C ABI (what an unchanged one-process calibrate uses): rank 0 drives every GPU
-        # of the job itself, the other ranks wait on the host
+        # the single-process route of the C ABI (what an unchanged one-process calibrate uses): a CHILD process of rank 0 drives every
+        # GPU of the job itself (single_process_sharded_leg above), the ranks wait on the host
         def single_process_leg():
-            out = {}
-            if rank == 0:
-                # (the first time this route meets two physical GPUs should say WHICH exchange path fails, if one does: every ordered
-                # pair of shards ping-pongs once at creation, 200 ms timeout, report on stderr)
-                os.environ.setdefault("NIDREG_SHARD_SELFTEST", "1")
-                devs = [0] * world if one_gpu else list(range(world))
-                for camera, n_points, key, seed in (("equirect_2k", int(10_000_000 * ps), "configs2", 20250523 + 3), ("pinhole_4k", int(50_000_000 * ps), "configs4", 20250523 + 5)):
-                    s = synth.make_scene(camera, num_points=n_points, seed=seed, device="cuda:0")
-                    pr = nid.create_camera(s.model, s.intrinsics, s.distortion)
-                    t1 = time.perf_counter()
-                    c = nid.NIDCost(pr, s.image_f64, s.points, s.intensities, args.bins, precision=args.precision, devices=devs)
-                    setup = time.perf_counter() - t1
-                    ps_ = np.ascontiguousarray([synth.random_pose_near(s.T_camera_lidar_true, rng) for _ in range(steps2)])
-                    c.eval_batch(ps_[:3])
-                    secs = []
-                    for _ in range(blocks2):
-                        t1 = time.perf_counter()
-                        c.eval_batch(ps_)
-                        secs.append(time.perf_counter() - t1)
-                    med = float(np.median(secs)) / steps2
-                    out[key] = {"value": round(1.0 / med, 2), "unit": "evals/s", "ms_per_step": round(1e3 * med, 5), "points": n_points, "devices": c.shard_devices(), "setup_s": round(setup, 3)}
-                    c.close()
-                    del s
-                out["route"] = "one process, desc.device_ids: the cloud cut along the histogram column, every GPU stores its columns of the integer histogram into every other GPU's replica inside nidreg_eval (one exchange), host sums the gradient partials"
-            return out
+            if rank != 0:
+                return {}
+            kw = dict(world=world, one_gpu=one_gpu, ps=ps, steps2=steps2, blocks2=blocks2, bins=args.bins, precision=args.precision)
+            env = {k_: v for k_, v in os.environ.items() if k_ not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                                      "TORCHELASTIC_RUN_ID", "NIDREG_BENCH_TEST_HANG_LEG")}
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--single-process-leg", json.dumps(kw)], env=env, capture_output=True, text=True, timeout=max(30.0, leg_watchdog_s - 5.0))
+            except subprocess.TimeoutExpired:
+                return {"error": f"the child process did not finish within {leg_watchdog_s - 5.0:.0f} s (killed)"}
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines:
+                return {"error": f"child process exit code {r.returncode}: " + (r.stderr or "").strip()[-240:]}
+            return json.loads(lines[-1])
 
         leg("single_process_sharded", single_process_leg)
 

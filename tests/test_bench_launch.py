@@ -56,6 +56,24 @@ def test_two_ranks_on_one_gpu_produce_the_full_line():
 
 
 @pytest.mark.gpu
+def test_a_crash_in_the_single_process_leg_does_not_cost_the_line():
+    """multi_gpu.single_process_sharded (one process driving every GPU: cross-device stores and in-kernel waits, never run on two
+    physical GPUs) runs in a CHILD process of rank 0: when it dies -- here by abort(), as a GPU memory fault would kill it -- the leg
+    records the exit code and the one JSON line still comes out, with the headline and the other legs in it."""
+    r = subprocess.run(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--blocks", "3", "--points", "300000", "--extra-points-scale", "0.02", "--no-cpu-baseline"],
+        capture_output=True, text=True, env=_env(NIDREG_BENCH_ONE_GPU="1", NIDREG_BENCH_BACKEND="gloo", NIDREG_BENCH_TEST_CRASH_CHILD="1"), timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    mg = d["multi_gpu"]
+    assert "error" not in mg["shard_configs2"], mg["shard_configs2"]
+    assert "child process exit code" in mg["single_process_sharded"].get("error", ""), mg["single_process_sharded"]
+
+
+@pytest.mark.gpu
 def test_one_gpu_bench_stdout_is_exactly_one_json_line():
     """`python bench.py` at N = 1 creates a one-rank RCCL communicator inside the library (other_entry_points.inlib_rccl_world1):
     RCCL's version banner must not reach stdout, which carries the JSON line and nothing else."""
