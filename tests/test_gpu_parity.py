@@ -193,6 +193,42 @@ def test_spline_edge_cases():
     cost.close()
 
 
+@pytest.mark.parametrize("bins", [16, 256])
+def test_ragged_cloud_sizes_around_the_batch_and_wave_boundaries(bins):
+    """Clouds of 1 ... 4097 points around every boundary of the point loops: one wave (64), one batch slot (256 / 512 threads), one
+    full batch (1024 records for the 256-thread kernels, 2048 for the WIDE histogram kernel), and one record more or less.  The
+    full batches run straight-line, the last batch of a segment is guarded and skips the slots that lie past the end for a whole
+    wave (nid_kernels.hpp spline_hist_body): every size must give the oracle's histogram, cost and gradient."""
+    s = scene_for("plumb_bob", n=4097)
+    proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
+    x = s.T_camera_lidar_init
+    for n in (1, 2, 63, 64, 65, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096, 4097):
+        pts, ints = s.points[:n], s.intensities[:n]
+        ref = oracle_lib.nid_cost(s.model, s.intrinsics, s.distortion, s.image_f64, pts, ints, bins, x, want_hist=True)
+        for tuning in ({}, {"target_blocks": 1}):  # the library's chunk rule, and everything in ONE workgroup (several batches + a ragged tail)
+            cost = nid.NIDCost(proj, s.image_f64, pts, ints, bins, **tuning)
+            ok, c, g = cost(x)
+            assert ok == ref["ok"], (n, tuning)
+            joint, hi, hp = cost.histograms()
+            assert np.array_equal(hp, ref["hist_points"]), (n, tuning)
+            parity.check_hist(joint, ref["hist"])
+            if ok:
+                parity.check_cost(c, ref["cost"])
+                parity.check_grad(g, ref["grad"])
+            cost.close()
+    # the NEAREST twin (one guarded loop, four records per thread): integer histogram bit for bit at the same sizes
+    max_fov = oracle_lib.estimate_camera_fov(s.model, s.intrinsics, s.distortion, s.width, s.height)
+    T = se3.to_matrix(x)
+    for n in (1, 63, 64, 65, 1023, 1024, 1025, 4097):
+        pts, ints = s.points[:n], s.intensities[:n]
+        ref_cost, ref_hist = oracle_lib.cost_calculator_nid(s.model, s.intrinsics, s.distortion, s.image_u8, pts, ints, bins, max_fov, T, want_hist=True)
+        calc = nid.CostCalculatorNID(proj, s.image_u8, pts, ints, nid.NIDCostParams(bins), max_fov=max_fov)
+        calc.calculate(T)
+        fx, inl, frac = calc.histogram_fixed()
+        assert frac == 0 and np.array_equal(fx, ref_hist) and inl == ref_hist.sum(), n
+        calc.close()
+
+
 def test_border_points_contribute_clamped_taps():
     """Knots on the image border keep their 16 taps with clamped pixel coordinates
     (nid_cost.hpp:70-73): a cloud projected onto the first/last rows and columns."""
