@@ -92,7 +92,7 @@ def test_watchdog_prints_the_headline_line_when_a_leg_hangs():
     headline with the leg marked and every rank leaves."""
     r = subprocess.run(
         [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--blocks", "3", "--points", "300000", "--extra-points-scale", "0.02", "--no-cpu-baseline"],
-        capture_output=True, text=True, env=_env(NIDREG_BENCH_ONE_GPU="1", NIDREG_BENCH_BACKEND="gloo", NIDREG_BENCH_TEST_HANG_LEG="shard_configs2", NIDREG_BENCH_LEG_WATCHDOG_S="20"), timeout=900)
+        capture_output=True, text=True, env=_env(NIDREG_BENCH_ONE_GPU="1", NIDREG_BENCH_BACKEND="gloo", NIDREG_BENCH_TEST_HANG_LEG="shard_configs2", NIDREG_BENCH_LEG_WATCHDOG_S="12"), timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]

@@ -335,7 +335,7 @@ def test_full_size_properties_cfg2_like():
     bins, 2M points: partition of unity (sum of the joint histogram == number of inliers, row sums ==
     hist_image, column sums == hist_points), shard additivity of the fixed-point histogram, and a
     central finite-difference check of the tangent gradient."""
-    s = synth.make_scene("pinhole_1080p", num_points=2_000_000, seed=20250525)
+    s = synth.make_scene("pinhole_1080p", num_points=2_000_000, seed=20250525, device="cuda:0")
     proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
     x = s.T_camera_lidar_init
     full = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, 256)
@@ -485,7 +485,7 @@ def test_baseline_config_cameras_at_scale(camera, n):
     bench line is quoted on (configs[1], 1920x1080 plumb_bob) and configs[4]'s 3840x2160 image, which
     no longer fits one XCD's L2 -- with the cloud reduced so the oracle finishes in seconds: value,
     gradient, histogram; and the NEAREST twin's integer histogram bit for bit."""
-    s = synth.make_scene(camera, num_points=n, seed=20250530)
+    s = synth.make_scene(camera, num_points=n, seed=20250530, device="cuda:0")
     proj = nid.create_camera(s.model, s.intrinsics, s.distortion)
     x = s.T_camera_lidar_init
     cost = nid.NIDCost(proj, s.image_f64, s.points, s.intensities, 256)

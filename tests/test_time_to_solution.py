@@ -37,7 +37,7 @@ def _record(key, rec):
 def test_configs0_time_to_solution(label, bags, reg):
     import time_to_solution as tts
 
-    rec = tts.compare("configs0", reg, bags=bags, threads=1, repeats=3)
+    rec = tts.compare("configs0", reg, bags=bags, threads=1, repeats=3, device="cuda:0")
     _record("configs0_" + label, rec)
     dt, dr = rec["dT"]
     assert dt <= 1e-3 and dr <= 1e-3, rec
